@@ -1,0 +1,171 @@
+"""Deterministic synthetic weights and RGB-D frames (no datasets, no checkpoints, no network).
+
+The reference ships no weights ("Checkpoint / resume"), so parity tests, the golden
+generator (tools/gen_golden.py) and bench.py all need weights that
+
+  * carry exactly the reference's state-dict key names and shapes
+    (PoseNet: 77 tensors, PoseRefineNet: 24 tensors -- DenseFusion/lib/network.py:70-132,170-206,
+    pspnet.py:40-62, extractors.py:78-112), so they load into the reference modules with strict=True
+    (that is how gen_golden.py proves the key layout), and
+  * can be regenerated bit-identically anywhere from (name, seed) alone -- an 86 MB PoseNet state
+    dict cannot be committed as a fixture.  numpy's PCG64 `default_rng` stream is stable across
+    platforms and numpy versions, torch's generator is not guaranteed to be.
+
+Scales are chosen so that activations stay O(1..100) from the raw 0-255 ImageNet-"normalised" crop
+(pipeline/utils.py:559-560 feeds (rgb-0.485)/0.229, i.e. values up to ~1100) down to O(0.1) pose
+outputs, the way a trained network's would; He-style fan-in scaling elsewhere.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+
+def _rng(seed, key):
+    return np.random.default_rng([int(seed), zlib.crc32(key.encode())])
+
+
+def _normal(seed, key, shape, std):
+    return torch.from_numpy((_rng(seed, key).standard_normal(shape, dtype=np.float32) * np.float32(std)))
+
+
+def _uniform(seed, key, shape, bound):
+    return torch.from_numpy(((_rng(seed, key).random(shape, dtype=np.float32) * 2 - 1) * np.float32(bound)))
+
+
+def pspnet_spec(backend="resnet18", n_classes=21):
+    """[(key, shape)] of DenseFusion/lib/pspnet.py:PSPNet with a BasicBlock encoder, in state_dict order."""
+    spec = [("feats.conv1.weight", (64, 3, 7, 7))]
+    inplanes = 64
+    for li, (planes, nblk, stride) in enumerate(zip((64, 128, 256, 512), _BLOCKS[backend], (1, 2, 1, 1)), start=1):
+        for b in range(nblk):
+            cin = inplanes if b == 0 else planes
+            spec.append((f"feats.layer{li}.{b}.conv1.weight", (planes, cin, 3, 3)))
+            spec.append((f"feats.layer{li}.{b}.conv2.weight", (planes, planes, 3, 3)))
+            if b == 0 and (stride != 1 or inplanes != planes):
+                spec.append((f"feats.layer{li}.{b}.downsample.0.weight", (planes, inplanes, 1, 1)))
+        inplanes = planes
+    for s in range(4):
+        spec.append((f"psp.stages.{s}.1.weight", (512, 512, 1, 1)))
+    spec += [("psp.bottleneck.weight", (1024, 2560, 1, 1)), ("psp.bottleneck.bias", (1024,))]
+    for name, cin, cout in (("up_1", 1024, 256), ("up_2", 256, 64), ("up_3", 64, 64)):
+        spec += [(f"{name}.conv.1.weight", (cout, cin, 3, 3)), (f"{name}.conv.1.bias", (cout,)),
+                 (f"{name}.conv.2.weight", (1,))]
+    spec += [("final.0.weight", (32, 64, 1, 1)), ("final.0.bias", (32,))]
+    spec += [("classifier.0.weight", (256, 256)), ("classifier.0.bias", (256,)),
+             ("classifier.2.weight", (n_classes, 256)), ("classifier.2.bias", (n_classes,))]
+    return spec
+
+
+def _fill(spec, seed, prefix="", overrides=None):
+    """He-normal (fan-in) weights, small uniform biases, PReLU slope 0.25; `overrides[key]` scales std."""
+    overrides = overrides or {}
+    sd = OrderedDict()
+    for key, shape in spec:
+        full = prefix + key
+        if len(shape) == 1 and key.endswith(".conv.2.weight"):  # nn.PReLU single slope (pspnet.py:33)
+            sd[full] = torch.full(shape, 0.25, dtype=torch.float32)
+            continue
+        if key.endswith(".bias"):
+            sd[full] = _uniform(seed, full, shape, 0.05 * overrides.get(key, 1.0))
+            continue
+        fan_in = int(np.prod(shape[1:]))
+        std = (2.0 / fan_in) ** 0.5 * overrides.get(key, 1.0)
+        sd[full] = _normal(seed, full, shape, std)
+    return sd
+
+
+def pspnet_state_dict(backend="resnet18", seed=0, prefix="", n_classes=21):
+    # the stem sees raw 0-255-scale pixels: bring them to O(1) like a trained first layer would
+    spec = pspnet_spec(backend, n_classes)
+    over = {"feats.conv1.weight": 1.0 / 256.0, "final.0.weight": 0.35}
+    # residual branches at half gain so 8..16 un-normalised blocks do not blow the variance up
+    over.update({k: 0.5 for k, _ in spec if k.startswith("feats.layer") and k.endswith("conv2.weight")})
+    return _fill(spec, seed, prefix, over)
+
+
+def _pointnet_spec(refine):
+    c5 = 384 if refine else 256
+    return [("feat.conv1.weight", (64, 3, 1)), ("feat.conv1.bias", (64,)),
+            ("feat.conv2.weight", (128, 64, 1)), ("feat.conv2.bias", (128,)),
+            ("feat.e_conv1.weight", (64, 32, 1)), ("feat.e_conv1.bias", (64,)),
+            ("feat.e_conv2.weight", (128, 64, 1)), ("feat.e_conv2.bias", (128,)),
+            ("feat.conv5.weight", (512, c5, 1)), ("feat.conv5.bias", (512,)),
+            ("feat.conv6.weight", (1024, 512, 1)), ("feat.conv6.bias", (1024,))]
+
+
+def posenet_state_dict(num_obj, seed=0):
+    """77 tensors with the key names of DenseFusion/lib/network.py:PoseNet (incl. `cnn.model.module.`)."""
+    sd = pspnet_state_dict("resnet18", seed, prefix="cnn.model.module.")
+    spec = _pointnet_spec(False)
+    for i, (cin, cout) in enumerate(((1408, 640), (640, 256), (256, 128)), start=1):
+        for h in "rtc":
+            spec += [(f"conv{i}_{h}.weight", (cout, cin, 1)), (f"conv{i}_{h}.bias", (cout,))]
+    for h, m in (("r", 4), ("t", 3), ("c", 1)):
+        spec += [(f"conv4_{h}.weight", (num_obj * m, 128, 1)), (f"conv4_{h}.bias", (num_obj * m,))]
+    # point coordinates are metres (O(0.5)): lift conv1 so geometry and colour features have equal weight;
+    # keep translation offsets ~cm and confidence logits O(1)
+    over = {"feat.conv1.weight": 2.0, "conv4_t.weight": 0.02, "conv4_t.bias": 0.2, "conv4_c.weight": 0.5}
+    sd.update(_fill(spec, seed, "", over))
+    return sd
+
+
+def refiner_state_dict(num_obj, seed=0):
+    """24 tensors with the key names of DenseFusion/lib/network.py:PoseRefineNet."""
+    spec = _pointnet_spec(True)
+    for i, (cin, cout) in enumerate(((1024, 512), (512, 128)), start=1):
+        for h in "rt":
+            spec += [(f"conv{i}_{h}.weight", (cout, cin)), (f"conv{i}_{h}.bias", (cout,))]
+    for h, m in (("r", 4), ("t", 3)):
+        spec += [(f"conv3_{h}.weight", (num_obj * m, 128)), (f"conv3_{h}.bias", (num_obj * m,))]
+    over = {"feat.conv1.weight": 2.0, "conv3_t.weight": 0.02, "conv3_t.bias": 0.2}
+    sd = _fill(spec, seed + 1, "", over)
+    # a refiner predicts a *residual* rotation: bias the quaternion head towards identity (w dominant)
+    b = sd["conv3_r.bias"].view(num_obj, 4)
+    b[:, 0] += 1.0
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic RGB-D frames
+# ----------------------------------------------------------------------------------------------
+REALSENSE_META = {"intr": {"fx": 615.0, "fy": 615.0, "ppx": 320.0, "ppy": 240.0}, "depth_scale": 0.001}
+YCB_META = {"intr": {"fx": 1066.778, "fy": 1067.487, "ppx": 312.9869, "ppy": 241.3109}, "depth_scale": 1.0 / 10000}
+
+CLASS_COLOURS = np.array([[230, 40, 40], [40, 200, 60], [50, 80, 230], [230, 210, 40], [200, 50, 200],
+                          [40, 210, 210], [250, 140, 30], [130, 60, 20], [120, 120, 250], [20, 120, 70],
+                          [250, 160, 200], [90, 90, 90]], dtype=np.uint8)
+
+
+def synthetic_frame(frame_id, cls=1, box=(150, 250), size=(150, 150), h=480, w=640):
+    """One 640x480 RGB u8 + depth u16 frame with a single painted box "object" of class `cls` (1-based).
+
+    Returns (rgb[h,w,3] u8, depth[h,w] u16, label[h,w] u8 with {0, cls}).  The default 150x150 box
+    makes `get_bbox` (myDatasetAugmented/dataset.py:342-380) round the crop up to 160x160.
+    Background: uniform noise in [96,160); depth: plane at 600 mm, object 80 mm closer with a
+    smooth bump, 2 % of all pixels invalid (0).
+    """
+    rng = np.random.default_rng(int(frame_id))
+    rgb = rng.integers(96, 160, size=(h, w, 3), dtype=np.uint8)
+    r0, c0 = box
+    rh, rw = size
+    label = np.zeros((h, w), np.uint8)
+    label[r0:r0 + rh, c0:c0 + rw] = cls
+    col = CLASS_COLOURS[(cls - 1) % len(CLASS_COLOURS)].astype(np.int16)
+    jitter = rng.integers(-12, 13, size=(rh, rw, 3), dtype=np.int16)
+    rgb[r0:r0 + rh, c0:c0 + rw] = np.clip(col + jitter, 0, 255).astype(np.uint8)
+    depth = np.full((h, w), 600, np.uint16)
+    yy, xx = np.mgrid[0:rh, 0:rw]
+    bump = 40.0 * np.exp(-(((yy - rh / 2) / (rh / 3)) ** 2 + ((xx - rw / 2) / (rw / 3)) ** 2))
+    depth[r0:r0 + rh, c0:c0 + rw] = (520 - bump).astype(np.uint16)
+    depth[rng.random((h, w)) < 0.02] = 0
+    return rgb, depth, label
+
+
+def model_cloud(cls, m=1000, seed=1234):
+    """`m` model points uniform in a 0.1 m cube (metres), per class."""
+    rng = np.random.default_rng([seed, int(cls)])
+    return ((rng.random((m, 3), dtype=np.float32) - 0.5) * np.float32(0.1)).astype(np.float32)
