@@ -1,0 +1,68 @@
+"""ctypes binding of libape_hip.so (the C ABI declared in include/ape_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a tensor is not on the GPU the call
+raises.  torch is used only for device memory and streams (tensor.data_ptr(), current stream)."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libape_hip.so")
+
+_c = ctypes
+_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+
+# symbol -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ape_hip.h one to one
+SIGNATURES = {
+    "ape_abi_version": [],
+    "ape_last_error": [],
+    "ape_knn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+}
+_RESTYPES = {"ape_last_error": _c.c_char_p}
+
+_lib = None
+
+
+class ApeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libape_hip.so once; raise loudly when it is absent (never fall back to a CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C autoposeestimation_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError here = header and library disagree
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _c.c_int)
+        _lib = h
+    return _lib
+
+
+def stream_ptr():
+    return _c.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor; refuses host tensors."""
+    if t is None:
+        return _c.c_void_p(0)
+    if not t.is_cuda:
+        raise ApeError("tensor is on %s; the HIP path needs device memory (no CPU fallback)" % t.device)
+    if not t.is_contiguous():
+        raise ApeError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise ApeError("expected %s, got %s" % (dtype, t.dtype))
+    return _c.c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ape_last_error()
+        raise ApeError("%s failed: code %d (%s)" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,139 @@
+// k-NN for gfx950 -- replaces DenseFusion/lib/knn/src/{knn.h:12-66, cpu/knn_cpu.cpp, cuda/knn.cu}.
+//
+// The reference CUDA path materialises a ref_nb x query_nb distance matrix in HBM (knn.h:33, 4 GB at
+// 1000 x 10^6) and then scans it column-strided (knn.cu:113-176).  Here distances never leave registers:
+//
+//   knn1_d3<S>  (dim = 3, k = 1: every call site in the reference)
+//     - refs are staged once per workgroup through LDS as float4 (x,y,z,-) tiles: one ds_read_b128 per
+//       ref per lane, a broadcast when S = 1, conflict-free consecutive 16-B slots when S = 64;
+//     - each query is owned by S lanes (S = 1,4,16,64 picked on the host so that the launch has enough
+//       wavefronts to fill 256 CUs even for 1000 queries); lane s scans refs s, s+S, ... in ascending
+//       order with a strict '<', then the S partial minima are merged by wave shuffles with the
+//       (distance, index) lexicographic rule -> exactly "lowest index wins ties" (knn_cpu.cpp:30).
+//   knn_general  (any dim, k <= 64): one query per lane, stable insertion into a k-entry list.
+//
+// Bit-exactness: d = ((dx*dx) + (dy*dy)) + (dz*dz) with __fmul_rn/__fadd_rn (no FMA contraction), the
+// same roundings as the reference's scalar x86 build (`dist = 0; dist += diff*diff` per dimension).
+//
+// Roofline: N_q*N_r pair evaluations at ~11 VALU lane-ops each; refs (12 B) and queries (12 B in, 8 B
+// out) are read/written once -> fp32-VALU bound, not HBM bound.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 2048;  // refs per LDS tile: 32 KB of float4
+
+template <int S>
+__global__ __launch_bounds__(kBlock) void knn1_d3(const float* __restrict__ ref, const float* __restrict__ query,
+                                                  int64_t* __restrict__ idx, int ref_nb, int query_nb)
+{
+    __shared__ float4 tile[kTile];
+    const int b = blockIdx.y;
+    ref += (size_t)b * 3 * ref_nb;
+    query += (size_t)b * 3 * query_nb;
+    idx += (size_t)b * query_nb;
+
+    constexpr int kQueriesPerBlock = kBlock / S;
+    const int s = threadIdx.x % S;
+    const int q = blockIdx.x * kQueriesPerBlock + threadIdx.x / S;
+    const bool valid = q < query_nb;
+    const int qc = valid ? q : query_nb - 1;
+    const float qx = query[qc], qy = query[query_nb + qc], qz = query[2 * (size_t)query_nb + qc];
+
+    float best = __builtin_inff();
+    int besti = s;  // all-inf distances must still yield the lowest index (stable sort of equal keys)
+
+    for (int t0 = 0; t0 < ref_nb; t0 += kTile) {
+        const int n = min(kTile, ref_nb - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock)
+            tile[i] = make_float4(ref[t0 + i], ref[ref_nb + t0 + i], ref[2 * (size_t)ref_nb + t0 + i], 0.f);
+        __syncthreads();
+#pragma unroll 4
+        for (int r = s; r < n; r += S) {
+            const float4 p = tile[r];
+            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (d < best) { best = d; besti = t0 + r; }
+        }
+    }
+#pragma unroll
+    for (int off = S / 2; off > 0; off >>= 1) {
+        const float od = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (od < best || (od == best && oi < besti)) { best = od; besti = oi; }
+    }
+    if (valid && s == 0) idx[q] = (int64_t)besti + 1;
+}
+
+constexpr int kMaxK = 64;
+
+__global__ __launch_bounds__(kBlock) void knn_general(const float* __restrict__ ref, const float* __restrict__ query,
+                                                      int64_t* __restrict__ idx, int dim, int ref_nb, int query_nb, int k)
+{
+    const int b = blockIdx.y;
+    ref += (size_t)b * dim * ref_nb;
+    query += (size_t)b * dim * query_nb;
+    idx += (size_t)b * k * query_nb;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= query_nb) return;
+
+    float bd[kMaxK];
+    int bi[kMaxK];
+    int filled = 0;
+    for (int r = 0; r < ref_nb; ++r) {
+        float d = 0.f;
+        for (int h = 0; h < dim; ++h) {
+            const float diff = ref[(size_t)h * ref_nb + r] - query[(size_t)h * query_nb + q];
+            d = __fadd_rn(d, __fmul_rn(diff, diff));
+        }
+        // stable insertion: new entry goes after every entry with distance <= d
+        if (filled < k) {
+            int j = filled++;
+            while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+            bd[j] = d; bi[j] = r;
+        } else if (bd[k - 1] > d) {
+            int j = k - 1;
+            while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+            bd[j] = d; bi[j] = r;
+        }
+    }
+    for (int i = 0; i < k; ++i) idx[(size_t)i * query_nb + q] = (int64_t)bi[i] + 1;
+}
+
+template <int S>
+void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, int ref_nb, int query_nb, hipStream_t st)
+{
+    dim3 grid(ape::ceil_div(query_nb, kBlock / S), batch);
+    hipLaunchKernelGGL(knn1_d3<S>, grid, dim3(kBlock), 0, st, ref, query, idx, ref_nb, query_nb);
+}
+
+}  // namespace
+
+extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
+                           int batch, int dim, int ref_nb, int query_nb, int k, void* stream)
+{
+    if (batch < 0 || dim < 1 || ref_nb < 1 || query_nb < 0 || k < 1 || k > ref_nb) return APE_EINVAL;
+    if (batch == 0 || query_nb == 0) return APE_OK;
+    if (!ref || !query || !idx) return APE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dim == 3 && k == 1) {
+        // lanes per query: aim for >= 8 waves per CU worth of work (256 CUs x 8 x 64 lanes)
+        const long target = 256L * 8 * 64;
+        const long total = (long)batch * query_nb;
+        int s = 1;
+        while (s < 64 && total * s < target && s * 4 <= ref_nb) s *= 4;
+        switch (s) {
+            case 1: launch_knn1<1>(ref, query, idx, batch, ref_nb, query_nb, st); break;
+            case 4: launch_knn1<4>(ref, query, idx, batch, ref_nb, query_nb, st); break;
+            case 16: launch_knn1<16>(ref, query, idx, batch, ref_nb, query_nb, st); break;
+            default: launch_knn1<64>(ref, query, idx, batch, ref_nb, query_nb, st); break;
+        }
+    } else {
+        if (k > kMaxK) return APE_EINVAL;
+        dim3 grid(ape::ceil_div(query_nb, kBlock), batch);
+        hipLaunchKernelGGL(knn_general, grid, dim3(kBlock), 0, st, ref, query, idx, dim, ref_nb, query_nb, k);
+    }
+    return ape::check_launch("ape_knn_f32");
+}
