@@ -8,7 +8,7 @@ The reference wrapper is a legacy autograd Function that .float().cuda()s its in
 does the same conversion and is a plain callable (it never had a backward)."""
 import torch
 
-from ... import _lib
+from autoposeestimation_amd import _lib
 
 
 class _KnnPytorch:

@@ -1,0 +1,307 @@
+"""Drop-in for DenseFusion/lib/network.py (+ pspnet.py, extractors.py): `PoseNet`, `PoseRefineNet`, `PSPNet`
+with the reference's constructor/forward signatures and state-dict key names, executed by hand-written gfx950
+kernels through the C ABI (include/ape_hip.h).  There is no CPU path: forward() on host tensors raises.
+
+    estimator = PoseNet(num_points=1000, num_obj=12); estimator.load_state_dict(torch.load('pose_model.pth'))
+    estimator.to('cuda').eval()
+    pred_r, pred_t, pred_c, emb = estimator(img[1,3,Hc,Wc], points[1,N,3], choose[1,1,N], idx[1,1])   # network.py:95,132
+
+Differences from the reference that do not change results beyond fp32 rounding:
+  * the three heads' 1408-wide first layer is split into  W[:, :384] . pointfeat  +  (W[:, 384:] . ap_x + b)  -- the
+    1024-vector broadcast of network.py:67-68 becomes a per-crop bias instead of a materialised 1408 x N tensor;
+  * the PSP bottleneck (pspnet.py:22-24) is evaluated as  W_f . feats + sum_s up(W_s . prior_s)  (1x1 conv and bilinear
+    resize commute), so the 2560-channel concat is never built;
+  * the heads evaluate only the selected object's output rows (network.py:119-126 computes all, then index_selects);
+  * the 32-channel log-softmax embedding is evaluated only at the `choose`d pixels (network.py:100-102 gathers them
+    from the full map);  `PSPNet.forward` still returns the full map;
+  * `forward_batch` generalises the reference's batch-1-only forward (network.py:123, b = 0) to B independent crops.
+"""
+import torch
+import torch.nn as nn
+
+from autoposeestimation_amd import engine as E
+
+_BLOCKS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+
+def _register(root, dotted, tensor):
+    """Create `root.a.b.c` as nn.Parameter, making bare nn.Module containers on the way (state-dict key = dotted)."""
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: the MI355X path has no CPU fallback -- move the module and its inputs to 'cuda'"
+                           % (what, t.device))
+
+
+class _HipModule(nn.Module):
+    """nn.Module holding reference-named parameters; the device plan (repacked weights) is rebuilt lazily whenever the
+    parameters may have changed (load_state_dict / .to / .cuda)."""
+
+    def __init__(self):
+        super().__init__()
+        self._plan = None
+
+    def _apply(self, fn, *a, **k):
+        self._plan = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **k):
+        self._plan = None
+        return super().load_state_dict(state_dict, strict=strict, **k)
+
+    def _sd(self):
+        return {k: v for k, v in self.state_dict().items()}
+
+    def plan(self):
+        if self._plan is None:
+            sd = self._sd()
+            dev = next(iter(sd.values())).device
+            _need_cuda(next(iter(sd.values())), type(self).__name__ + " parameters")
+            self._plan = self._build_plan(sd, dev)
+        return self._plan
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# PSPNet  (pspnet.py:40-77 over the BN-free dilated ResNet of extractors.py:78-124)
+# ----------------------------------------------------------------------------------------------------------------
+def _pspnet_param_shapes(backend, n_classes):
+    from autoposeestimation_amd.synthetic import pspnet_spec
+    return pspnet_spec(backend, n_classes)
+
+
+class _PSPPlan:
+    def __init__(self, sd, prefix, backend, dev):
+        g = lambda k: sd[prefix + k]  # noqa: E731
+        self.stem = E.Conv(g("feats.conv1.weight"), None, 2, 3, 1, E.ACT_RELU, device=dev)
+        self.blocks = []
+        inplanes = 64
+        for li, (planes, nblk, stride, dil) in enumerate(zip((64, 128, 256, 512), _BLOCKS[backend], (1, 2, 1, 1), (1, 1, 2, 4)), 1):
+            for b in range(nblk):
+                first = b == 0
+                s = stride if first else 1
+                d = 1 if first else dil      # extractors.py:107 does not forward `dilation` to the first block
+                p = f"feats.layer{li}.{b}."
+                c1 = E.Conv(g(p + "conv1.weight"), None, s, d, d, E.ACT_RELU, device=dev)
+                c2 = E.Conv(g(p + "conv2.weight"), None, 1, d, d, E.ACT_RELU, device=dev)   # relu after the residual add
+                down = None
+                if first and (stride != 1 or inplanes != planes):
+                    down = E.Conv(g(p + "downsample.0.weight"), None, s, 0, 1, E.ACT_NONE, device=dev)
+                self.blocks.append((c1, c2, down))
+            inplanes = planes
+        wb = g("psp.bottleneck.weight")           # [1024, 2560, 1, 1] = [prior_1 | prior_2 | prior_3 | prior_6 | feats]
+        self.stage = [E.Conv(g(f"psp.stages.{i}.1.weight"), None, device=dev) for i in range(4)]
+        self.bott_prior = [E.Conv(wb[:, i * 512:(i + 1) * 512], None, device=dev) for i in range(4)]
+        self.bott_feats = E.Conv(wb[:, 2048:2560], g("psp.bottleneck.bias"), act=E.ACT_RELU, device=dev)
+        self.up = [E.Conv(g(f"{n}.conv.1.weight"), g(f"{n}.conv.1.bias"), 1, 1, 1, E.ACT_PRELU,
+                          alpha=float(g(f"{n}.conv.2.weight").reshape(-1)[0]), device=dev) for n in ("up_1", "up_2", "up_3")]
+        self.final = E.Conv(g("final.0.weight"), g("final.0.bias"), device=dev)
+
+    def features(self, x, taps=None):
+        """x[B,H,W,4] (RGB + zero pad) -> up_3 activation [B,H,W,64]"""
+        y = E.maxpool3x3s2(self.stem(x))
+        for c1, c2, down in self.blocks:
+            res = y if down is None else down(y)
+            y = c2(c1(y), residual=res)
+        f = y
+        b, h, w, _ = f.shape
+        acc = None
+        for i, s in enumerate((1, 2, 3, 6)):
+            z = self.bott_prior[i](self.stage[i](E.adaptive_avgpool(f, s)))
+            acc = E.bilinear(z, h, w, False, out=acc, accumulate=acc is not None)
+        p = self.bott_feats(f, residual=acc)
+        if taps is not None:
+            taps["feats"], taps["psp"] = f, p
+        for i, up in enumerate(self.up):
+            p = up(E.bilinear(p, p.shape[1] * 2, p.shape[2] * 2, True))
+            if taps is not None:
+                taps["up_%d" % (i + 1)] = p
+        return p
+
+
+class PSPNet(_HipModule):
+    """pspnet.py:40-77.  forward(x[B,3,H,W]) -> log_softmax(final 1x1 conv) [B,32,H,W] (eval semantics)."""
+
+    def __init__(self, n_classes=21, sizes=(1, 2, 3, 6), psp_size=512, deep_features_size=256, backend="resnet18",
+                 pretrained=False):
+        super().__init__()
+        if backend not in _BLOCKS or tuple(sizes) != (1, 2, 3, 6) or psp_size != 512:
+            raise NotImplementedError("BasicBlock backends (resnet18/34) with sizes (1,2,3,6) only")
+        self.backend = backend
+        for key, shape in _pspnet_param_shapes(backend, n_classes):
+            _register(self, key, torch.zeros(shape))
+
+    def _build_plan(self, sd, dev):
+        return _PSPPlan(sd, "", self.backend, dev)
+
+    def forward_nhwc(self, x4, logits_only=False):
+        """x4[B,H,W,4] -> [B,H,W,32] log-softmax (or raw logits)"""
+        pl = self.plan()
+        logits = pl.final(pl.features(x4))
+        return logits if logits_only else E.log_softmax_rows(logits)
+
+    def forward(self, x):
+        _need_cuda(x, "input")
+        x4 = torch.zeros(x.shape[0], x.shape[2], x.shape[3], 4, dtype=torch.float32, device=x.device)
+        x4[..., :3] = x.permute(0, 2, 3, 1)
+        return self.forward_nhwc(x4).permute(0, 3, 1, 2).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# PointNet trunks and heads
+# ----------------------------------------------------------------------------------------------------------------
+class _FeatPlan:
+    """PoseNetFeat / PoseRefineNetFeat (network.py:39-68, 136-168) writing straight into the concatenated buffer
+    pf[B*N, 384] = [conv1(x) 64 | e_conv1(emb) 64 | conv2 128 | e_conv2 128]."""
+
+    def __init__(self, sd, dev, refine):
+        g = lambda k: (sd[f"feat.{k}.weight"], sd[f"feat.{k}.bias"])  # noqa: E731
+        self.conv1 = E.Conv(*g("conv1"), act=E.ACT_RELU, device=dev)
+        self.e_conv1 = E.Conv(*g("e_conv1"), act=E.ACT_RELU, device=dev)
+        self.conv2 = E.Conv(*g("conv2"), act=E.ACT_RELU, device=dev)
+        self.e_conv2 = E.Conv(*g("e_conv2"), act=E.ACT_RELU, device=dev)
+        self.conv5 = E.Conv(*g("conv5"), act=E.ACT_RELU, device=dev)
+        self.conv6 = E.Conv(*g("conv6"), act=E.ACT_RELU, device=dev)
+        self.refine = refine
+
+    def __call__(self, x4, emb):
+        """x4[B,N,4], emb[B,N,32] -> pf[B,N,1,384], ap[B,1024]"""
+        b, n, _ = x4.shape
+        x4 = x4.view(b, n, 1, 4)
+        emb = emb.view(b, n, 1, 32)
+        pf = torch.empty(b, n, 1, 384, dtype=torch.float32, device=x4.device)
+        self.conv1(x4, out=pf, yoff=0)
+        self.e_conv1(emb, out=pf, yoff=64)
+        self.conv2(pf, out=pf, xoff=0, yoff=128)
+        self.e_conv2(pf, out=pf, xoff=64, yoff=256)
+        x5 = self.conv5(pf, xoff=0 if self.refine else 128)
+        x6 = self.conv6(x5)
+        return pf, E.mean_rows(x6.view(b, n, 1024))
+
+
+class PoseNet(_HipModule):
+    """DenseFusion/lib/network.py:70-132."""
+
+    def __init__(self, num_points, num_obj):
+        super().__init__()
+        from autoposeestimation_amd.synthetic import posenet_state_dict
+        self.num_points, self.num_obj = num_points, num_obj
+        for key, t in posenet_state_dict(num_obj, seed=0).items():   # key names + shapes; values are placeholders
+            _register(self, key, torch.zeros_like(t))
+
+    def _build_plan(self, sd, dev):
+        pl = type("Plan", (), {})()
+        pl.cnn = _PSPPlan(sd, "cnn.model.module.", "resnet18", dev)
+        pl.feat = _FeatPlan(sd, dev, refine=False)
+        w1 = torch.cat([sd[f"conv1_{h}.weight"] for h in "rtc"], 0)[:, :, 0]      # [1920, 1408]
+        b1 = torch.cat([sd[f"conv1_{h}.bias"] for h in "rtc"], 0)
+        pl.l1_point = E.Conv(w1[:, :384], None, act=E.ACT_RELU, device=dev)           # per-point part
+        pl.l1_global = E.Conv(w1[:, 384:], b1, act=E.ACT_NONE, device=dev)            # per-crop bias from ap_x
+        pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev) for h in "rtc"]
+        pl.l3 = [E.Conv(sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"], act=E.ACT_RELU, device=dev) for h in "rtc"]
+        pl.l4 = [t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).contiguous()
+                 for h in "rtc" for t in (sd[f"conv4_{h}.weight"], sd[f"conv4_{h}.bias"])]
+        return pl
+
+    def forward_batch(self, img4, points4, choose, obj, taps=None):
+        """img4[B,Hc,Wc,4] f32 (normalised RGB + 0), points4[B,N,4], choose[B,N] i64, obj[B] i64
+        -> heads[B,N,8] (qw,qx,qy,qz,tx,ty,tz,c), emb[B,N,32]"""
+        pl = self.plan()
+        for t, name in ((img4, "img"), (points4, "points"), (choose, "choose"), (obj, "obj")):
+            _need_cuda(t, name)
+        b, hc, wc, _ = img4.shape
+        n = points4.shape[1]
+        up3 = pl.cnn.features(img4, taps)
+        g = E.gather_rows(up3.view(b, hc * wc, 64), choose)                 # [B,N,64]
+        emb = E.log_softmax_rows(pl.cnn.final(g.view(b, n, 1, 64)).view(b, n, 32))
+        pf, ap = pl.feat(points4, emb)
+        gb = pl.l1_global(ap.view(b, 1, 1, 1024)).view(b, 1920)            # W[:, 384:] . ap_x + b
+        h1 = pl.l1_point(pf, bias=gb, bias_bstride=1920)                    # [B,N,1,1920]
+        h2 = torch.empty(b, n, 1, 768, dtype=torch.float32, device=img4.device)
+        h3 = torch.empty(b, n, 1, 384, dtype=torch.float32, device=img4.device)
+        for i in range(3):
+            pl.l2[i](h1, out=h2, xoff=640 * i, yoff=256 * i)
+            pl.l3[i](h2, out=h3, xoff=256 * i, yoff=128 * i)
+        heads = E.head_select(h3.view(b * n, 384), 0, 128, 256, *pl.l4, obj, b, n, 128)
+        if taps is not None:
+            taps["pf"], taps["ap"], taps["emb"] = pf, ap, emb
+        return heads, emb
+
+    def forward(self, img, x, choose, obj):
+        """Reference signature (network.py:95): img[1,3,Hc,Wc], x[1,N,3], choose[1,1,N] i64, obj[1,1] i64 ->
+        (out_rx[1,N,4], out_tx[1,N,3], out_cx[1,N,1], emb[1,32,N])"""
+        _need_cuda(img, "img")
+        if img.shape[0] != 1:
+            raise ValueError("reference forward is batch-1 (network.py:123); use forward_batch for B crops")
+        o = int(obj.reshape(-1)[0])
+        if not 0 <= o < self.num_obj:
+            raise IndexError("obj index %d out of range" % o)
+        img4 = torch.zeros(1, img.shape[2], img.shape[3], 4, dtype=torch.float32, device=img.device)
+        img4[..., :3] = img.permute(0, 2, 3, 1)
+        heads, emb = self.forward_batch(img4, E.pad3to4(x.float().contiguous()), choose.reshape(1, -1).contiguous(),
+                                        obj.reshape(1).contiguous())
+        return (heads[:, :, 0:4].contiguous(), heads[:, :, 4:7].contiguous(), heads[:, :, 7:8].contiguous(),
+                emb.transpose(1, 2).contiguous())
+
+
+class PoseRefineNet(_HipModule):
+    """DenseFusion/lib/network.py:170-206."""
+
+    def __init__(self, num_points, num_obj):
+        super().__init__()
+        from autoposeestimation_amd.synthetic import refiner_state_dict
+        self.num_points, self.num_obj = num_points, num_obj
+        for key, t in refiner_state_dict(num_obj, seed=0).items():
+            _register(self, key, torch.zeros_like(t))
+
+    def _build_plan(self, sd, dev):
+        pl = type("Plan", (), {})()
+        pl.feat = _FeatPlan(sd, dev, refine=True)
+        pl.l1 = E.Conv(torch.cat([sd["conv1_r.weight"], sd["conv1_t.weight"]], 0),
+                       torch.cat([sd["conv1_r.bias"], sd["conv1_t.bias"]], 0), act=E.ACT_RELU, device=dev)   # 1024 -> 512|512
+        pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev) for h in "rt"]
+        pl.l3 = [t.detach().to(dev, torch.float32).contiguous()
+                 for h in "rt" for t in (sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"])]
+        return pl
+
+    def forward_batch(self, points4, emb, obj):
+        """points4[B,N,4], emb[B,N,32], obj[B] -> out[B,8] (qw,qx,qy,qz,tx,ty,tz,0)"""
+        pl = self.plan()
+        for t, name in ((points4, "points"), (emb, "emb"), (obj, "obj")):
+            _need_cuda(t, name)
+        b = points4.shape[0]
+        _, ap = pl.feat(points4, emb)
+        h1 = pl.l1(ap.view(b, 1, 1, 1024))                                   # [B,1,1,1024]
+        h2 = torch.empty(b, 1, 1, 256, dtype=torch.float32, device=points4.device)
+        pl.l2[0](h1, out=h2, xoff=0, yoff=0)
+        pl.l2[1](h1, out=h2, xoff=512, yoff=128)
+        return E.head_select(h2.view(b, 256), 0, 128, 0, *pl.l3, None, None, obj, b, 1, 128).view(b, 8)
+
+    def forward(self, x, emb, obj):
+        """Reference signature (network.py:187): x[1,N,3], emb[1,32,N], obj[1,1] -> (out_rx[1,4], out_tx[1,3])"""
+        _need_cuda(x, "x")
+        o = int(obj.reshape(-1)[0])
+        if not 0 <= o < self.num_obj:
+            raise IndexError("obj index %d out of range" % o)
+        out = self.forward_batch(E.pad3to4(x.float().contiguous()), emb.transpose(1, 2).contiguous(), obj.reshape(1).contiguous())
+        return out[:, 0:4].contiguous(), out[:, 4:7].contiguous()
+
+
+class ModifiedResnet(nn.Module):
+    """network.py:27-37 -- kept for import compatibility; PoseNet above owns the PSPNet weights directly
+    (the `cnn.model.module.` key prefix is what nn.DataParallel produced in the reference)."""
+
+    def __init__(self, usegpu=True):
+        super().__init__()
+        self.model = nn.Module()
+        self.model.add_module("module", PSPNet(backend="resnet18"))
+
+    def forward(self, x):
+        return self.model.module(x)

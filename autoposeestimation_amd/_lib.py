@@ -18,7 +18,29 @@ SIGNATURES = {
     "ape_abi_version": [],
     "ape_last_error": [],
     "ape_knn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ape_conv2d_nhwc_f32": [_P, _P, _P, _P, _P, _P, _P],
+    "ape_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "ape_adaptive_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ape_bilinear_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ape_gather_rows_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ape_log_softmax_rows_f32": [_P, _P, _c.c_long, _I, _P],
+    "ape_mean_rows_f32": [_P, _P, _I, _I, _I, _P],
+    "ape_pad3to4_f32": [_P, _P, _c.c_long, _P],
+    "ape_head_select_f32": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "ape_pose_select_f32": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "ape_pose_compose_f64": [_P, _P, _I, _P, _I, _I, _P],
+    "ape_pose_recentre_f32": [_P, _P, _P, _I, _I, _P],
 }
+
+
+class ConvParams(_c.Structure):
+    """Mirror of `ape_conv_params` (include/ape_hip.h)."""
+    _fields_ = [(n, _c.c_int32) for n in ("B", "H", "W", "Cin", "ldx", "xoff", "Ho", "Wo", "Cout", "ldy", "yoff",
+                                          "KH", "KW", "stride", "pad", "dil", "act")] + \
+               [("alpha", _c.c_float), ("bias_bstride", _c.c_int32), ("ldr", _c.c_int32), ("roff", _c.c_int32)]
+
+
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 _RESTYPES = {"ape_last_error": _c.c_char_p}
 
 _lib = None

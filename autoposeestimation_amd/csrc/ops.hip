@@ -1,0 +1,277 @@
+// HBM-bound glue kernels of the DenseFusion slice (NHWC fp32, 16-byte accesses along the channel run):
+//   max-pool 3x3/s2/p1          extractors.py:85,117
+//   adaptive average pool       pspnet.py:15 (nn.AdaptiveAvgPool2d(size), sizes 1,2,3,6)
+//   bilinear resize             pspnet.py:22 (F.upsample, align_corners=False) and :31 (nn.Upsample x2, align_corners=True)
+//   row gather                  network.py:100-102 (torch.gather of the embedding at `choose`)
+//   log-softmax over channels   pspnet.py:55 (nn.LogSoftmax, implicit dim=1)
+//   mean over points            network.py:51,65 (AvgPool1d(num_points))
+//   channel padding 3->4        (x[B,N,3] -> [B,N,4] so the first 1x1 conv can use 16-byte loads)
+//   head output layer           network.py:115-126 (conv4_{r,t,c} evaluated only for the selected object + sigmoid)
+// Each is one pass over its input (algorithmic bytes = bytes read + bytes written once); grids are sized to
+// >= 2048 workgroups-worth of work and grid-stride the rest.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline int grid_for(long work) { long g = (work + kThreads - 1) / kThreads; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+__global__ void maxpool3x3s2_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int C4,
+                                    int Ho, int Wo)
+{
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        long t = i / C4;
+        const int ox = t % Wo; t /= Wo;
+        const int oy = t % Ho;
+        const int b = t / Ho;
+        float4 m = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float4 v = x[((long)(b * H + iy) * W + ix) * C4 + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        y[i] = m;
+    }
+}
+
+// one workgroup per (b, oy, ox) bin; threads stride channels (float4) and loop over the bin's pixels
+__global__ void adaptive_avgpool_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W, int C4, int S)
+{
+    const int bin = blockIdx.x;
+    const int ox = bin % S, oy = (bin / S) % S, b = bin / (S * S);
+    const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
+    const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int iy = y0; iy < y1; ++iy)
+            for (int ix = x0; ix < x1; ++ix) {
+                const float4 v = x[((long)(b * H + iy) * W + ix) * C4 + c];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        // ATen divides the fp32 sum by the bin size
+        y[(long)bin * C4 + c] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    }
+}
+
+__device__ __forceinline__ float src_index(int dst, float scale, bool align_corners)
+{
+    if (align_corners) return scale * (float)dst;
+    const float s = scale * ((float)dst + 0.5f) - 0.5f;  // ATen area_pixel_compute_source_index
+    return s < 0.f ? 0.f : s;
+}
+
+__global__ void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4, int ldx4,
+                                int Ho, int Wo, int ldy4, int yoff4, float sh, float sw, int align_corners, int accumulate)
+{
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        long t = i / C4;
+        const int ox = t % Wo; t /= Wo;
+        const int oy = t % Ho;
+        const int b = t / Ho;
+        const float fy = src_index(oy, sh, align_corners), fx = src_index(ox, sw, align_corners);
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const int iy1 = iy0 + (iy0 < H - 1 ? 1 : 0), ix1 = ix0 + (ix0 < W - 1 ? 1 : 0);
+        const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0;
+        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float4 v00 = x4[((long)(b * H + iy0) * W + ix0) * ldx4 + c];
+        const float4 v01 = x4[((long)(b * H + iy0) * W + ix1) * ldx4 + c];
+        const float4 v10 = x4[((long)(b * H + iy1) * W + ix0) * ldx4 + c];
+        const float4 v11 = x4[((long)(b * H + iy1) * W + ix1) * ldx4 + c];
+        float4 o;
+        o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        const long yo = ((long)(b * Ho + oy) * Wo + ox) * ldy4 + yoff4 + c;
+        if (accumulate) {
+            const float4 p = y4[yo];
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        y4[yo] = o;
+    }
+}
+
+__global__ void gather_rows_kernel(const float4* __restrict__ x, const int64_t* __restrict__ index, float4* __restrict__ y,
+                                   int B, int rows_in, int n, int C4)
+{
+    const long total = (long)B * n * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        const long bn = i / C4;
+        const int b = bn / n;
+        long src = index[bn];
+        src = src < 0 ? 0 : (src >= rows_in ? rows_in - 1 : src);  // never read out of bounds on a bad index
+        y[i] = x[((long)b * rows_in + src) * C4 + c];
+    }
+}
+
+// log-softmax over C <= 64 channels of each row; one lane per row (rows are short: 32 channels on this path)
+__global__ void log_softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C)
+{
+    for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        const float* xr = x + r * C;
+        float m = xr[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, xr[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(xr[c] - m);
+        const float l = logf(s);
+        for (int c = 0; c < C; ++c) y[r * C + c] = (xr[c] - m) - l;
+    }
+}
+
+// mean over the n rows of each image: grid (C/64, B), block 256 = 4 row-groups x 64 channels
+__global__ void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int C)
+{
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float s = 0.f;
+    if (c < C)
+        for (int r = g; r < n; r += 4) s += x[((long)b * n + r) * C + c];
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < C) y[(long)b * C + c] = (((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x]) / (float)n;
+}
+
+__global__ void pad3to4_kernel(const float* __restrict__ x, float4* __restrict__ y, long rows)
+{
+    for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x)
+        y[r] = make_float4(x[r * 3], x[r * 3 + 1], x[r * 3 + 2], 0.f);
+}
+
+// out[b][n][j], j<8: 0..3 quaternion (W_r rows obj*4+j), 4..6 translation (W_t rows obj*3+j-4), 7 sigmoid(confidence)
+// h[b*n][ldh] holds the three 128-wide layer-3 activations at channel offsets off_r, off_t, off_c.
+__global__ void head_select_kernel(const float* __restrict__ h, int ldh, int off_r, int off_t, int off_c,
+                                   const float* __restrict__ wr, const float* __restrict__ br,
+                                   const float* __restrict__ wt, const float* __restrict__ bt,
+                                   const float* __restrict__ wc, const float* __restrict__ bc,
+                                   const int64_t* __restrict__ obj, float* __restrict__ out, int n, int K)
+{
+    extern __shared__ float wsel[];  // 8 rows x K
+    __shared__ float bsel[8];
+    const int b = blockIdx.y;
+    const int o = (int)obj[b];
+    for (int i = threadIdx.x; i < 8 * K; i += blockDim.x) {
+        const int j = i / K, k = i - j * K;
+        wsel[i] = j < 4 ? wr[(long)(o * 4 + j) * K + k] : j < 7 ? wt[(long)(o * 3 + j - 4) * K + k] : (wc ? wc[(long)o * K + k] : 0.f);
+    }
+    if (threadIdx.x < 8) {
+        const int j = threadIdx.x;
+        bsel[j] = j < 4 ? br[o * 4 + j] : j < 7 ? bt[o * 3 + j - 4] : (bc ? bc[o] : 0.f);
+    }
+    __syncthreads();
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * 8; t += gridDim.x * blockDim.x) {
+        const int j = t & 7, p = t >> 3;
+        const float* hp = h + ((long)b * n + p) * ldh + (j < 4 ? off_r : j < 7 ? off_t : off_c);
+        const float* w = wsel + j * K;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(hp[k], w[k], s);
+        s += bsel[j];
+        if (j == 7) s = wc ? 1.f / (1.f + expf(-s)) : 0.f;
+        out[((long)b * n + p) * 8 + j] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int ape_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream)
+{
+    if (!x || !y || B < 0 || H < 1 || W < 1 || C < 4 || C % 4) return APE_EINVAL;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)B * Ho * Wo * (C / 4);
+    if (total == 0) return APE_OK;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const float4*)x, (float4*)y, B, H, W, C / 4, Ho, Wo);
+    return ape::check_launch("ape_maxpool3x3s2_nhwc_f32");
+}
+
+extern "C" int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int S, void* stream)
+{
+    if (!x || !y || B < 0 || H < 1 || W < 1 || C < 4 || C % 4 || S < 1) return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(B * S * S), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const float4*)x, (float4*)y, H, W, C / 4, S);
+    return ape::check_launch("ape_adaptive_avgpool_nhwc_f32");
+}
+
+extern "C" int ape_bilinear_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
+                                     int yoff, int align_corners, int accumulate, void* stream)
+{
+    if (!x || !y || B < 0 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || C < 4 || C % 4 || ldx % 4 || ldy % 4 || yoff % 4 ||
+        C > ldx || yoff + C > ldy)
+        return APE_EINVAL;
+    float sh, sw;
+    if (align_corners) {
+        sh = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+        sw = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    } else {
+        sh = (float)H / (float)Ho;
+        sw = (float)W / (float)Wo;
+    }
+    const long total = (long)B * Ho * Wo * (C / 4);
+    if (total == 0) return APE_OK;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, x, y, B, H, W, C / 4,
+                       ldx / 4, Ho, Wo, ldy / 4, yoff / 4, sh, sw, align_corners, accumulate);
+    return ape::check_launch("ape_bilinear_nhwc_f32");
+}
+
+extern "C" int ape_gather_rows_f32(const float* x, const int64_t* index, float* y, int B, int rows_in, int n, int C, void* stream)
+{
+    if (!x || !index || !y || B < 0 || rows_in < 1 || n < 0 || C < 4 || C % 4) return APE_EINVAL;
+    const long total = (long)B * n * (C / 4);
+    if (total == 0) return APE_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)x,
+                       index, (float4*)y, B, rows_in, n, C / 4);
+    return ape::check_launch("ape_gather_rows_f32");
+}
+
+extern "C" int ape_log_softmax_rows_f32(const float* x, float* y, long rows, int C, void* stream)
+{
+    if (!x || !y || rows < 0 || C < 1) return APE_EINVAL;
+    if (rows == 0) return APE_OK;
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(grid_for(rows)), dim3(kThreads), 0, (hipStream_t)stream, x, y, rows, C);
+    return ape::check_launch("ape_log_softmax_rows_f32");
+}
+
+extern "C" int ape_mean_rows_f32(const float* x, float* y, int B, int n, int C, void* stream)
+{
+    if (!x || !y || B < 0 || n < 1 || C < 1) return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(ape::ceil_div(C, 64), B), dim3(256), 0, (hipStream_t)stream, x, y, n, C);
+    return ape::check_launch("ape_mean_rows_f32");
+}
+
+extern "C" int ape_pad3to4_f32(const float* x, float* y, long rows, void* stream)
+{
+    if (!x || !y || rows < 0) return APE_EINVAL;
+    if (rows == 0) return APE_OK;
+    hipLaunchKernelGGL(pad3to4_kernel, dim3(grid_for(rows)), dim3(kThreads), 0, (hipStream_t)stream, x, (float4*)y, rows);
+    return ape::check_launch("ape_pad3to4_f32");
+}
+
+extern "C" int ape_head_select_f32(const float* h, int ldh, int off_r, int off_t, int off_c, const float* wr, const float* br,
+                                   const float* wt, const float* bt, const float* wc, const float* bc, const int64_t* obj,
+                                   float* out, int B, int n, int K, void* stream)
+{
+    if (!h || !wr || !br || !wt || !bt || (wc && !bc) || !obj || !out || B < 0 || n < 0 || K < 1 || K > 1024) return APE_EINVAL;
+    if (B == 0 || n == 0) return APE_OK;
+    dim3 grid(ape::ceil_div((long)n * 8, kThreads), B);
+    hipLaunchKernelGGL(head_select_kernel, grid, dim3(kThreads), 8 * K * sizeof(float), (hipStream_t)stream, h, ldh, off_r,
+                       off_t, off_c, wr, br, wt, bt, wc, bc, obj, out, n, K);
+    return ape::check_launch("ape_head_select_f32");
+}

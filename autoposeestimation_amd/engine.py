@@ -1,0 +1,168 @@
+"""Thin host layer over the C ABI (include/ape_hip.h): weight repacking into the device layout and one Python
+function per kernel.  Tensors are torch CUDA(HIP) tensors used purely as device buffers; every function enqueues on
+torch's current stream and returns without synchronising.  No function here has a CPU path.
+
+Device layout (DESIGN.md "Data layout in HBM"): activations NHWC fp32 `[B,H,W,C]` (points are `[B,N,1,C]`),
+weights `[Cout][KH][KW][Cin4]` with Cin zero-padded to a multiple of 4.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID, ConvParams  # noqa: F401
+
+
+def _st():
+    return _lib.stream_ptr()
+
+
+def pack_conv_weight(w, device):
+    """[Cout,Cin,KH,KW] | [Cout,Cin,1] | [Cout,Cin]  ->  contiguous f32 [Cout,KH,KW,Cin4] on `device`."""
+    w = w.detach()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, :, None]
+    cout, cin, kh, kw = w.shape
+    cin4 = (cin + 3) // 4 * 4
+    out = torch.zeros(cout, kh, kw, cin4, dtype=torch.float32, device=device)
+    out[..., :cin] = w.to(device=device, dtype=torch.float32).permute(0, 2, 3, 1)
+    return out.contiguous()
+
+
+class Conv:
+    """One conv / 1x1 / Linear layer bound to ape_conv2d_nhwc_f32."""
+
+    def __init__(self, weight, bias=None, stride=1, pad=0, dil=1, act=ACT_NONE, alpha=0.0, device="cuda"):
+        self.w = pack_conv_weight(weight, device)
+        self.cout, self.kh, self.kw, self.cin = self.w.shape
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.stride, self.pad, self.dil, self.act, self.alpha = stride, pad, dil, act, float(alpha)
+
+    def out_hw(self, h, w):
+        ho = (h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1
+        wo = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
+        return ho, wo
+
+    def __call__(self, x, out=None, xoff=0, yoff=0, residual=None, roff=0, bias=None, bias_bstride=0, act=None):
+        """x[B,H,W,ldx] (reads channels xoff..xoff+cin) -> out[B,Ho,Wo,ldy] (writes yoff..yoff+cout)."""
+        b, h, w, ldx = x.shape
+        ho, wo = self.out_hw(h, w)
+        if out is None:
+            out = torch.empty(b, ho, wo, self.cout, dtype=torch.float32, device=x.device)
+        if tuple(out.shape[:3]) != (b, ho, wo):
+            raise ValueError("conv output buffer %s does not match %s" % (tuple(out.shape), (b, ho, wo)))
+        if residual is not None and tuple(residual.shape[:3]) != (b, ho, wo):
+            raise ValueError("residual shape mismatch")
+        bias = self.bias if bias is None else bias
+        p = ConvParams(B=b, H=h, W=w, Cin=self.cin, ldx=ldx, xoff=xoff, Ho=ho, Wo=wo, Cout=self.cout,
+                       ldy=out.shape[3], yoff=yoff, KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad,
+                       dil=self.dil, act=self.act if act is None else act, alpha=self.alpha,
+                       bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff)
+        rc = _lib.lib().ape_conv2d_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(self.w), _lib.dptr(bias),
+                                            _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p), _st())
+        _lib.check(rc, "ape_conv2d_nhwc_f32")
+        return out
+
+
+def maxpool3x3s2(x):
+    b, h, w, c = x.shape
+    y = torch.empty(b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ape_maxpool3x3s2_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(y), b, h, w, c, _st()),
+               "ape_maxpool3x3s2_nhwc_f32")
+    return y
+
+
+def adaptive_avgpool(x, s):
+    b, h, w, c = x.shape
+    y = torch.empty(b, s, s, c, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ape_adaptive_avgpool_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(y), b, h, w, c, s, _st()),
+               "ape_adaptive_avgpool_nhwc_f32")
+    return y
+
+
+def bilinear(x, ho, wo, align_corners, out=None, yoff=0, accumulate=False):
+    b, h, w, c = x.shape
+    if out is None:
+        out = torch.empty(b, ho, wo, c, dtype=torch.float32, device=x.device)
+    if tuple(out.shape[:3]) != (b, ho, wo):
+        raise ValueError("bilinear output buffer mismatch")
+    rc = _lib.lib().ape_bilinear_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(out, torch.float32), b, h, w, c, c, ho, wo,
+                                          out.shape[3], yoff, int(bool(align_corners)), int(bool(accumulate)), _st())
+    _lib.check(rc, "ape_bilinear_nhwc_f32")
+    return out
+
+
+def gather_rows(x, index):
+    """x[B,R,C], index[B,n] i64 -> [B,n,C]"""
+    b, r, c = x.shape
+    n = index.shape[1]
+    y = torch.empty(b, n, c, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().ape_gather_rows_f32(_lib.dptr(x, torch.float32), _lib.dptr(index, torch.int64), _lib.dptr(y), b, r, n, c, _st())
+    _lib.check(rc, "ape_gather_rows_f32")
+    return y
+
+
+def log_softmax_rows(x):
+    c = x.shape[-1]
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().ape_log_softmax_rows_f32(_lib.dptr(x, torch.float32), _lib.dptr(y), rows, c, _st()),
+               "ape_log_softmax_rows_f32")
+    return y
+
+
+def mean_rows(x):
+    """x[B,n,C] -> [B,C]"""
+    b, n, c = x.shape
+    y = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ape_mean_rows_f32(_lib.dptr(x, torch.float32), _lib.dptr(y), b, n, c, _st()), "ape_mean_rows_f32")
+    return y
+
+
+def pad3to4(x):
+    """x[...,3] -> [...,4]"""
+    rows = x.numel() // 3
+    y = torch.empty(*x.shape[:-1], 4, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ape_pad3to4_f32(_lib.dptr(x, torch.float32), _lib.dptr(y), rows, _st()), "ape_pad3to4_f32")
+    return y
+
+
+def head_select(h, off_r, off_t, off_c, wr, br, wt, bt, wc, bc, obj, b, n, k):
+    """h[B*n, ldh] -> out[B,n,8]"""
+    out = torch.empty(b, n, 8, dtype=torch.float32, device=h.device)
+    rc = _lib.lib().ape_head_select_f32(_lib.dptr(h, torch.float32), h.shape[-1], off_r, off_t, off_c, _lib.dptr(wr),
+                                        _lib.dptr(br), _lib.dptr(wt), _lib.dptr(bt), _lib.dptr(wc), _lib.dptr(bc),
+                                        _lib.dptr(obj, torch.int64), _lib.dptr(out), b, n, k, _st())
+    _lib.check(rc, "ape_head_select_f32")
+    return out
+
+
+def pose_select(heads, points4, want_new_points=True):
+    """heads[B,n,8], points4[B,n,4] -> pose[B,7] f64, which[B] i32, new_points4[B,n,4] | None"""
+    b, n, _ = heads.shape
+    pose = torch.empty(b, 7, dtype=torch.float64, device=heads.device)
+    which = torch.empty(b, dtype=torch.int32, device=heads.device)
+    newp = torch.empty(b, n, 4, dtype=torch.float32, device=heads.device) if want_new_points else None
+    rc = _lib.lib().ape_pose_select_f32(_lib.dptr(heads, torch.float32), _lib.dptr(points4, torch.float32), _lib.dptr(pose),
+                                        _lib.dptr(which), _lib.dptr(newp), b, n, _st())
+    _lib.check(rc, "ape_pose_select_f32")
+    return pose, which, newp
+
+
+def pose_compose(pose, ref_r, ref_t):
+    """in-place: pose[B,7] f64 <- pose o (ref_r[B,>=4], ref_t[B,>=3]) ; ref_* are (possibly strided) row views"""
+    b = pose.shape[0]
+    rc = _lib.lib().ape_pose_compose_f64(_lib.dptr(pose, torch.float64), ctypes.c_void_p(ref_r.data_ptr()), ref_r.stride(0),
+                                         ctypes.c_void_p(ref_t.data_ptr()), ref_t.stride(0), b, _st())
+    _lib.check(rc, "ape_pose_compose_f64")
+    return pose
+
+
+def pose_recentre(points4, pose):
+    b, n, _ = points4.shape
+    out = torch.empty_like(points4)
+    rc = _lib.lib().ape_pose_recentre_f32(_lib.dptr(points4, torch.float32), _lib.dptr(pose, torch.float64), _lib.dptr(out), b, n, _st())
+    _lib.check(rc, "ape_pose_recentre_f32")
+    return out

@@ -44,6 +44,67 @@ const char* ape_last_error(void);
 int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
                 int batch, int dim, int ref_nb, int query_nb, int k, void* stream);
 
+/* ---- dense contractions: conv2d / 1x1 / Linear, exact fp32 on the matrix cores ---------------------------
+ * One entry point replaces every torch.nn.Conv2d / Conv1d(k=1) / Linear forward on the path:
+ *   DenseFusion/lib/extractors.py:14-16,82-89,101-105 (ResNet convs), pspnet.py:12-17,30-33,53-55 (PSP, up-convs,
+ *   final 1x1), network.py:42-49,76-92,139-146,175-182 (PointNet / head 1x1 chains, refiner Linear stacks),
+ * with the following pointwise op fused: bias, residual add (extractors.py:40), ReLU / PReLU / sigmoid.
+ *
+ * Layouts: x[B][H][W][ldx] f32 (NHWC, the layer reads channels xoff .. xoff+Cin-1), w[Cout][KH][KW][Cin] f32,
+ * y[B][Ho][Wo][ldy] (writes channels yoff .. yoff+Cout-1), residual like y with (ldr, roff).
+ * bias: NULL, or bias[Cout] (bias_bstride = 0), or per-image bias[B][bias_bstride] (first Cout entries used).
+ * Constraints: Cin, ldx, xoff multiples of 4 (16-byte loads); Ho/Wo must equal the conv arithmetic result. */
+enum { APE_ACT_NONE = 0, APE_ACT_RELU = 1, APE_ACT_PRELU = 2, APE_ACT_SIGMOID = 3 };
+typedef struct ape_conv_params {
+    int32_t B, H, W, Cin, ldx, xoff;
+    int32_t Ho, Wo, Cout, ldy, yoff;
+    int32_t KH, KW, stride, pad, dil;
+    int32_t act;            /* APE_ACT_* */
+    float alpha;            /* PReLU slope (pspnet.py:33, single parameter) */
+    int32_t bias_bstride;
+    int32_t ldr, roff;
+} ape_conv_params;
+int ape_conv2d_nhwc_f32(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                        const ape_conv_params* params_host, void* stream);
+
+/* ---- HBM-bound glue of the PSPNet / PointNet graphs (NHWC f32, C multiple of 4) -----------------------------
+ * nn.MaxPool2d(3, 2, 1)                      DenseFusion/lib/extractors.py:85,117.   y[B][Ho][Wo][C], Ho=(H-1)/2+1 */
+int ape_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* nn.AdaptiveAvgPool2d((S,S))                DenseFusion/lib/pspnet.py:15.           y[B][S][S][C] */
+int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int S, void* stream);
+/* F.upsample(size=(Ho,Wo), 'bilinear') / nn.Upsample(x2, align_corners=True)   pspnet.py:22,31.
+ * Reads x[B][H][W][ldx] channels 0..C-1, writes y[B][Ho][Wo][ldy] channels yoff..yoff+C-1 (a slice of the PSP
+ * concat buffer, pspnet.py:22-23); accumulate != 0 adds into y instead of overwriting. */
+int ape_bilinear_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
+                          int yoff, int align_corners, int accumulate, void* stream);
+/* torch.gather(emb, 2, choose)               DenseFusion/lib/network.py:100-102.     y[b][i][:] = x[b][index[b][i]][:] */
+int ape_gather_rows_f32(const float* x, const int64_t* index, float* y, int B, int rows_in, int n, int C, void* stream);
+/* nn.LogSoftmax() over the channel run       DenseFusion/lib/pspnet.py:55.           rows x C, C contiguous */
+int ape_log_softmax_rows_f32(const float* x, float* y, long rows, int C, void* stream);
+/* nn.AvgPool1d(num_points)                   DenseFusion/lib/network.py:51,65,149,166.  x[B][n][C] -> y[B][C] */
+int ape_mean_rows_f32(const float* x, float* y, int B, int n, int C, void* stream);
+/* x[rows][3] -> y[rows][4] (w = 0): lets the first 1x1 conv (network.py:42,139) use 16-byte loads */
+int ape_pad3to4_f32(const float* x, float* y, long rows, void* stream);
+/* conv4_r / conv4_t / conv4_c + sigmoid + index_select(obj)   DenseFusion/lib/network.py:115-126 (and the refiner's
+ * conv3_r / conv3_t, :197-204, with wc = bc = NULL): only the selected object's 8 output rows are evaluated.
+ * h[B*n][ldh] holds the K-wide inputs of the three heads at channel offsets off_r/off_t/off_c; obj[B] i64;
+ * out[B][n][8] = (qw,qx,qy,qz, tx,ty,tz, sigmoid(c)). */
+int ape_head_select_f32(const float* h, int ldh, int off_r, int off_t, int off_c, const float* wr, const float* br,
+                        const float* wt, const float* bt, const float* wc, const float* bc, const int64_t* obj,
+                        float* out, int B, int n, int K, void* stream);
+
+/* ---- pose extraction / composition, device resident ----------------------------------------------------------
+ * my_estimator_prediction + get_new_points   DenseFusion/tools/utils.py:7-18,43-86.
+ * heads[B][n][8] (from ape_head_select_f32), points4[B][n][4] -> pose[B][7] f64 (qw,qx,qy,qz,tx,ty,tz),
+ * which[B] (arg-max confidence, may be NULL), new_points4[B][n][4] (may be NULL). */
+int ape_pose_select_f32(const float* heads, const float* points4, double* pose, int* which, float* new_points4,
+                        int B, int n, void* stream);
+/* my_refined_prediction                      DenseFusion/tools/utils.py:20-40 (+ transformations.py:1254-1278,1320-1363).
+ * pose[B][7] f64 is updated in place with the refiner residual ref_r[B][ldr>=4], ref_t[B][ldt>=3] (f32). */
+int ape_pose_compose_f64(double* pose, const float* ref_r, int ldr, const float* ref_t, int ldt, int B, void* stream);
+/* cloud re-centring of the iterative loop    DenseFusion/tools/eval_ycb.py:205-210. */
+int ape_pose_recentre_f32(const float* points4, const double* pose, float* new_points4, int B, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
