@@ -30,6 +30,12 @@ SIGNATURES = {
     "ape_pose_select_f32": [_P, _P, _P, _P, _P, _I, _I, _P],
     "ape_pose_compose_f64": [_P, _P, _I, _P, _I, _I, _P],
     "ape_pose_recentre_f32": [_P, _P, _P, _I, _I, _P],
+    "ape_seg_argmax_f32": [_P, _I, _I, _P, _P, _c.c_long, _I, _P],
+    "ape_seg_components_workspace_bytes": [_I, _I, _I, _I],
+    "ape_seg_components": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
+    "ape_choose_points": [_P, _P, _P, _I, _I, _I, _I, _c.c_uint, _P, _c.c_long, _P, _P, _P],
+    "ape_backproject_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
+    "ape_preprocess_u8_nhwc4": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 
 
@@ -41,7 +47,7 @@ class ConvParams(_c.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
-_RESTYPES = {"ape_last_error": _c.c_char_p}
+_RESTYPES = {"ape_last_error": _c.c_char_p, "ape_seg_components_workspace_bytes": _c.c_size_t}
 
 _lib = None
 

@@ -1,0 +1,441 @@
+// Segmentation post-processing and crop/point selection, device resident (HBM-bound integer/byte work).
+//
+// Reference (per frame, on the host with numpy + cv2): pipeline/utils.py:430-469 and its twin
+// label_generator/create_labels.py:127-147:
+//     softmax -> argmax -> np.unique counts -> per class with >100 px: 8-connectivity components ->
+//     component with the highest mean class probability (strict '>', first wins) -> mask {0,255};
+// then pipeline/utils.py:524-561: get_bbox (myDatasetAugmented/dataset.py:342-380), candidate pixels =
+// mask & depth != 0 inside the crop in raster order, N of them (random subset / wrap pad), back-projection
+// in float32, crop normalisation.
+//
+// Here the [C,480,640] probability tensor never leaves the GPU (the reference copies ~16 MB per frame to the host,
+// pipeline/utils.py:431-432).  One pass per stage over byte/int images:
+//   seg_argmax     logits -> label u8 + softmax(softmax(logits))[argmax] f32          (reads C*4 B, writes 5 B / px)
+//   ccl8_*         union-find labelling of ALL classes at once: pixels are linked iff they carry the same non-zero
+//                  class; root = smallest raster index of the component (raster-order numbering)
+//   seg_stats      per-root exact sums: probabilities are accumulated as 2^40 fixed point in u64 so the sum (and the
+//                  arg-max over component means) is independent of the atomic arrival order
+//   seg_pick_*     best component per (frame, class): max mean, ties -> smallest root (first in raster order)
+//   seg_mask       object map u8 (class id inside its best component, else 0) + tight bbox per (frame, class)
+//   seg_bbox       get_bbox arithmetic (x40 rounding, re-centring, shift into the image)
+//   choose_points  ordered stream compaction of (object map == cls) & (depth != 0) inside the crop, then N picks
+//   backproject    float32 pin-hole back-projection, bit-identical to the numpy arithmetic
+//   crop_normalize u8 RGB -> NHWC4 f32 (x[/255] - mean) / std
+#include "common.h"
+
+namespace {
+
+constexpr int kT = 256;
+inline int grid_for(long work) { long g = (work + kT - 1) / kT; return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g)); }
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void seg_argmax_kernel(const float* __restrict__ logits, int ld, int C, uint8_t* __restrict__ label,
+                                  float* __restrict__ score, long npix, int double_softmax)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const float* l = logits + p * ld;
+        float m = l[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c)
+            if (l[c] > m) { m = l[c]; am = c; }  // first maximum, like torch.argmax on the CPU
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+        float pm = 1.f / s;  // softmax(logits)[am]  (activation='softmax' inside predict, create_labels.py:23)
+        if (double_softmax) {
+            // F.softmax applied again on the probabilities (pipeline/utils.py:430): the maximum is p1[am]
+            float s2 = 0.f;
+            for (int c = 0; c < C; ++c) s2 += expf(expf(l[c] - m) / s - pm);
+            pm = 1.f / s2;
+        }
+        label[p] = (uint8_t)am;
+        score[p] = pm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// union-find on the pixel grid; every access to L during the merge is an agent-scope atomic (coherent across XCDs)
+__device__ __forceinline__ int ld_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ int uf_find(const int* L, int a)
+{
+    int p = ld_relaxed(&L[a]);
+    while (p != a) { a = p; p = ld_relaxed(&L[a]); }
+    return a;
+}
+
+__device__ void uf_union(int* L, int a, int b)
+{
+    bool done = false;
+    while (!done) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a < b) {
+            const int old = atomicMin(&L[b], a);
+            done = old == b;
+            b = old;
+        } else if (b < a) {
+            const int old = atomicMin(&L[a], b);
+            done = old == a;
+            a = old;
+        } else {
+            done = true;
+        }
+    }
+}
+
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ label, int* __restrict__ L, long npix)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x)
+        L[p] = label[p] ? (int)p : -1;
+}
+
+// L indices are global over the batch (frame b occupies [b*H*W, (b+1)*H*W)), so roots are unique batch-wide.
+__global__ void ccl_merge_kernel(const uint8_t* __restrict__ label, int* __restrict__ L, int H, int W, long npix)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const uint8_t c = label[p];
+        if (!c) continue;
+        const int x = p % W;
+        const int y = (p / W) % H;
+        if (x > 0 && label[p - 1] == c) uf_union(L, (int)p, (int)p - 1);
+        if (y > 0) {
+            if (label[p - W] == c) {
+                uf_union(L, (int)p, (int)(p - W));  // N present: NW and NE are already linked to N by their own W-links
+            } else {
+                if (x > 0 && label[p - W - 1] == c) uf_union(L, (int)p, (int)(p - W - 1));
+                if (x < W - 1 && label[p - W + 1] == c) uf_union(L, (int)p, (int)(p - W + 1));
+            }
+        }
+    }
+}
+
+__global__ void ccl_compress_kernel(int* __restrict__ L, long npix)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        int a = L[p];
+        if (a < 0) continue;
+        while (true) {
+            const int q = L[a];   // parents only ever point to smaller indices: chains end at the root
+            if (q == a) break;
+            a = q;
+        }
+        L[p] = a;   // benign race: other lanes may read either the old parent or the root, both lead to the root
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxCls = 64;
+
+__global__ void seg_stats_kernel(const uint8_t* __restrict__ label, const float* __restrict__ score, const int* __restrict__ L,
+                                 unsigned long long* __restrict__ sum, unsigned int* __restrict__ cnt,
+                                 unsigned int* __restrict__ hist, int HW, int C)
+{
+    __shared__ unsigned int lh[kMaxCls];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < kMaxCls; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    // whole waves walk 64 consecutive pixels; HW is a multiple of 64 for 480x640, the tail is handled by `in`
+    for (int q0 = blockIdx.x * blockDim.x; q0 < HW; q0 += gridDim.x * blockDim.x) {
+        const int q = q0 + threadIdx.x;
+        const bool in = q < HW;
+        const long p = (long)b * HW + q;
+        int root = -1;
+        unsigned long long fx = 0;
+        uint8_t c = 0;
+        if (in) {
+            c = label[p];
+            if (c) {
+                root = L[p];
+                fx = (unsigned long long)(score[p] * 1099511627776.0f);  // 2^40 fixed point, exact for p < 1
+            }
+        }
+        // wave-level aggregation: a wave is 64 consecutive pixels and mostly sits in ONE component
+        const int root0 = __shfl(root, 0);
+        if (__all(root == root0)) {
+            if (root0 >= 0) {
+                unsigned long long sacc = fx;
+                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&sum[root0], sacc);
+                    atomicAdd(&cnt[root0], 64u);
+                }
+            }
+        } else if (root >= 0) {
+            atomicAdd(&sum[root], fx);
+            atomicAdd(&cnt[root], 1u);
+        }
+        if (c) atomicAdd(&lh[c], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[(long)b * C + i], lh[i]);
+}
+
+__global__ void seg_small_init_kernel(unsigned int* hist, unsigned long long* best_key, int* best_root, int* tight, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    hist[i] = 0;
+    best_key[i] = 0;
+    best_root[i] = 0x7fffffff;
+    tight[i * 4 + 0] = 0x7fffffff; tight[i * 4 + 1] = -1; tight[i * 4 + 2] = 0x7fffffff; tight[i * 4 + 3] = -1;
+}
+
+__global__ void seg_pick_max_kernel(const uint8_t* __restrict__ label, const int* __restrict__ L,
+                                    const unsigned long long* __restrict__ sum, const unsigned int* __restrict__ cnt,
+                                    const unsigned int* __restrict__ hist, unsigned long long* __restrict__ best_key,
+                                    int HW, int C, int min_pixels, long npix)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        if (L[p] != (int)p) continue;
+        const int b = p / HW, c = label[p];
+        if (hist[(long)b * C + c] <= (unsigned)min_pixels) continue;   // counts[i] > 100 (pipeline/utils.py:445)
+        const double mean = (double)sum[p] / (double)cnt[p];
+        atomicMax(&best_key[(long)b * C + c], (unsigned long long)__double_as_longlong(mean));
+    }
+}
+
+__global__ void seg_pick_root_kernel(const uint8_t* __restrict__ label, const int* __restrict__ L,
+                                     const unsigned long long* __restrict__ sum, const unsigned int* __restrict__ cnt,
+                                     const unsigned int* __restrict__ hist, const unsigned long long* __restrict__ best_key,
+                                     int* __restrict__ best_root, int HW, int C, int min_pixels, long npix)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        if (L[p] != (int)p) continue;
+        const int b = p / HW, c = label[p];
+        if (hist[(long)b * C + c] <= (unsigned)min_pixels) continue;
+        const double mean = (double)sum[p] / (double)cnt[p];
+        if ((unsigned long long)__double_as_longlong(mean) == best_key[(long)b * C + c])
+            atomicMin(&best_root[(long)b * C + c], (int)p);   // ties: first component in raster order
+    }
+}
+
+// objmap[p] = class if p belongs to the best component of its class, else 0; tight bbox per (frame, class).
+// Only the ends of a component's row runs can move the extrema, so only those pixels issue atomics.
+__global__ void seg_mask_kernel(const uint8_t* __restrict__ label, const int* __restrict__ L, const int* __restrict__ best_root,
+                                uint8_t* __restrict__ objmap, int* __restrict__ tight, int H, int W, int C, long npix)
+{
+    const int HW = H * W;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const int c = label[p];
+        uint8_t o = 0;
+        if (c) {
+            const int b = p / HW;
+            if (L[p] == best_root[(long)b * C + c]) {
+                o = (uint8_t)c;
+                const int rem = p - (long)b * HW;
+                const int y = rem / W, x = rem - y * W;
+                int* t = tight + ((long)b * C + c) * 4;
+                if (x == 0 || label[p - 1] != c) { atomicMin(&t[2], x); atomicMin(&t[0], y); atomicMax(&t[1], y); }
+                if (x == W - 1 || label[p + 1] != c) atomicMax(&t[3], x);
+            }
+        }
+        objmap[p] = o;
+    }
+}
+
+__device__ __forceinline__ int up40(int v) { return v % 40 == 0 ? v : (v / 40 + 1) * 40; }
+
+// det[b][c] = (valid, rmin, rmax, cmin, cmax): dataset.py:342-380 on the tight extents
+__global__ void seg_bbox_kernel(const int* __restrict__ tight, const int* __restrict__ best_root, int* __restrict__ det,
+                                int n, int H, int W)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int* d = det + (long)i * 5;
+    if (best_root[i] == 0x7fffffff) { d[0] = 0; d[1] = d[2] = d[3] = d[4] = 0; return; }
+    int rmin = tight[i * 4 + 0], rmax = tight[i * 4 + 1] + 1, cmin = tight[i * 4 + 2], cmax = tight[i * 4 + 3] + 1;
+    const int r_b = up40(rmax - rmin), c_b = up40(cmax - cmin);
+    const int cr = (rmin + rmax) / 2, cc = (cmin + cmax) / 2;     // int((a+b)/2) of non-negative ints
+    rmin = cr - r_b / 2; rmax = cr + r_b / 2;
+    cmin = cc - c_b / 2; cmax = cc + c_b / 2;
+    if (rmin < 0) { rmax += -rmin; rmin = 0; }
+    if (cmin < 0) { cmax += -cmin; cmin = 0; }
+    if (rmax > H) { rmin -= rmax - H; rmax = H; }
+    if (cmax > W) { cmin -= cmax - W; cmax = W; }
+    d[0] = 1; d[1] = rmin; d[2] = rmax; d[3] = cmin; d[4] = cmax;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// objects[o] = (frame, cls, rmin, rmax, cmin, cmax).  One workgroup per object: ordered compaction, then N picks.
+__global__ __launch_bounds__(kT) void choose_points_kernel(const uint8_t* __restrict__ objmap, const uint16_t* __restrict__ depth,
+                                                           const int* __restrict__ objects, int H, int W, int N,
+                                                           unsigned int seed, int* __restrict__ cand, long cand_stride,
+                                                           int64_t* __restrict__ choose, int* __restrict__ n_cand)
+{
+    __shared__ int wsum[kT / 64];
+    __shared__ int running;
+    const int o = blockIdx.x;
+    const int* ob = objects + (long)o * 6;
+    const int b = ob[0], cls = ob[1], rmin = ob[2], rmax = ob[3], cmin = ob[4], cmax = ob[5];
+    const int Wc = cmax - cmin, total = (rmax - rmin) * Wc;
+    const uint8_t* om = objmap + (long)b * H * W;
+    const uint16_t* dp = depth + (long)b * H * W;
+    int* cd = cand + (long)o * cand_stride;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < total; base += kT) {
+        const int i = base + threadIdx.x;
+        bool v = false;
+        if (i < total) {
+            const int r = i / Wc + rmin, c = i % Wc + cmin;
+            v = om[r * W + c] == cls && dp[r * W + c] != 0;
+        }
+        const unsigned long long bal = __ballot(v);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (v) cd[off + before] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    const int n = running;
+    if (threadIdx.x == 0) n_cand[o] = n;
+    if (n == 0) return;
+    __threadfence_block();
+    if (n > N) {
+        // ordered subset with equal inclusion probability N/n (systematic sampling; the reference draws an unseeded
+        // np.random.shuffle of a 0/1 mask, pipeline/utils.py:533-537 -- parity tests inject `choose` instead)
+        unsigned int h = seed ^ (0x9E3779B9u * (unsigned)(o + 1));
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        const double u = (double)h / 4294967296.0;
+        for (int i = threadIdx.x; i < N; i += kT) {
+            long j = (long)(((double)i + u) * (double)n / (double)N);
+            j = j >= n ? n - 1 : j;
+            choose[(long)o * N + i] = cd[j];
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += kT) choose[(long)o * N + i] = cd[i % n];   // np.pad(..., 'wrap')
+    }
+}
+
+__global__ void backproject_kernel(const uint16_t* __restrict__ depth, const int* __restrict__ objects,
+                                   const int64_t* __restrict__ choose, float4* __restrict__ points, int H, int W, int N,
+                                   float fx, float fy, float ppx, float ppy, float depth_scale)
+{
+    const int o = blockIdx.y;
+    const int* ob = objects + (long)o * 6;
+    const int b = ob[0], rmin = ob[2], cmin = ob[4], Wc = ob[5] - ob[4];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int idx = (int)choose[(long)o * N + i];
+        const int r = idx / Wc + rmin, c = idx % Wc + cmin;
+        const float d = (float)depth[((long)b * H + r) * W + c];
+        const float pt2 = d * depth_scale;                       // pipeline/utils.py:549
+        const float pt0 = ((float)c - ppx) * pt2 / fx;           // :550  (ymap = column index)
+        const float pt1 = ((float)r - ppy) * pt2 / fy;           // :551  (xmap = row index)
+        points[(long)o * N + i] = make_float4(pt0, pt1, pt2, 0.f);
+    }
+}
+
+// rects[o] = (frame, rmin, cmin); output [n][Hc][Wc][4]
+__global__ void crop_normalize_kernel(const uint8_t* __restrict__ rgb, const int* __restrict__ rects, float4* __restrict__ out,
+                                      int H, int W, int Hc, int Wc, int div255, long total)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = i % Wc;
+        long t = i / Wc;
+        const int y = t % Hc;
+        const int o = t / Hc;
+        const int b = rects[o * 3], r = rects[o * 3 + 1] + y, c = rects[o * 3 + 2] + x;
+        const uint8_t* px = rgb + (((long)b * H + r) * W + c) * 3;
+        float v0 = (float)px[0], v1 = (float)px[1], v2 = (float)px[2];
+        if (div255) { v0 = v0 / 255.f; v1 = v1 / 255.f; v2 = v2 / 255.f; }   // torchvision ToTensor
+        out[i] = make_float4((v0 - 0.485f) / 0.229f, (v1 - 0.456f) / 0.224f, (v2 - 0.406f) / 0.225f, 0.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float* score, long npix,
+                                  int double_softmax, void* stream)
+{
+    if (!logits || !label || !score || C < 1 || C > kMaxCls || ld < C || npix < 0) return APE_EINVAL;
+    if (npix == 0) return APE_OK;
+    hipLaunchKernelGGL(seg_argmax_kernel, dim3(grid_for(npix)), dim3(kT), 0, (hipStream_t)stream, logits, ld, C, label, score,
+                       npix, double_softmax);
+    return ape::check_launch("ape_seg_argmax_f32");
+}
+
+extern "C" size_t ape_seg_components_workspace_bytes(int B, int H, int W, int C)
+{
+    const size_t npix = (size_t)B * H * W;
+    // sum u64[npix] | best_key u64[B*C] | L i32[npix] | cnt u32[npix] | hist u32[B*C] | best_root i32[B*C] | tight i32[B*C*4]
+    return npix * (8 + 4 + 4) + (size_t)B * C * (8 + 4 + 4 + 16) + 256;
+}
+
+/* label[B][H][W] u8, score[B][H][W] f32 -> objmap[B][H][W] u8, det[B][C][5] i32 (valid,rmin,rmax,cmin,cmax) */
+extern "C" int ape_seg_components(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
+                                  int C, int min_pixels, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!label || !score || !objmap || !det || !workspace || B < 0 || H < 1 || W < 1 || C < 1 || C > kMaxCls) return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    const long npix = (long)B * H * W;
+    if (npix >= (1L << 31) - 1) return APE_EINVAL;
+    if (workspace_bytes < ape_seg_components_workspace_bytes(B, H, W, C)) return APE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    unsigned long long* sum = (unsigned long long*)ws;            ws += npix * 8;
+    unsigned long long* best_key = (unsigned long long*)ws;       ws += (size_t)B * C * 8;
+    int* L = (int*)ws;                                            ws += npix * 4;
+    unsigned int* cnt = (unsigned int*)ws;                        ws += npix * 4;
+    unsigned int* hist = (unsigned int*)ws;                       ws += (size_t)B * C * 4;
+    int* best_root = (int*)ws;                                    ws += (size_t)B * C * 4;
+    int* tight = (int*)ws;
+    if (hipMemsetAsync(sum, 0, npix * 8, st) != hipSuccess || hipMemsetAsync(cnt, 0, npix * 4, st) != hipSuccess) {
+        ape::set_last_error("hipMemsetAsync");
+        return APE_ELAUNCH;
+    }
+    const int g = grid_for(npix);
+    const int BC = B * C;
+    hipLaunchKernelGGL(seg_small_init_kernel, dim3(ape::ceil_div(BC, kT)), dim3(kT), 0, st, hist, best_key, best_root, tight, BC);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(kT), 0, st, label, L, npix);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(kT), 0, st, label, L, H, W, npix);
+    hipLaunchKernelGGL(ccl_compress_kernel, dim3(g), dim3(kT), 0, st, L, npix);
+    int gx = ape::ceil_div((long)H * W, kT);
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(seg_stats_kernel, dim3(gx, B), dim3(kT), 0, st, label, score, L, sum, cnt, hist, H * W, C);
+    hipLaunchKernelGGL(seg_pick_max_kernel, dim3(g), dim3(kT), 0, st, label, L, sum, cnt, hist, best_key, H * W, C, min_pixels, npix);
+    hipLaunchKernelGGL(seg_pick_root_kernel, dim3(g), dim3(kT), 0, st, label, L, sum, cnt, hist, best_key, best_root, H * W, C,
+                       min_pixels, npix);
+    hipLaunchKernelGGL(seg_mask_kernel, dim3(g), dim3(kT), 0, st, label, L, best_root, objmap, tight, H, W, C, npix);
+    hipLaunchKernelGGL(seg_bbox_kernel, dim3(ape::ceil_div(BC, kT)), dim3(kT), 0, st, tight, best_root, det, BC, H, W);
+    return ape::check_launch("ape_seg_components");
+}
+
+/* objects[n][6] i32 = (frame, cls, rmin, rmax, cmin, cmax) -> choose[n][N] i64 (index inside the crop, row-major over Wc),
+ * n_cand[n] i32 (0 => the reference `continue`s, pipeline/utils.py:530-531).  cand: i32 scratch [n][cand_stride]. */
+extern "C" int ape_choose_points(const uint8_t* objmap, const uint16_t* depth, const int* objects, int n, int H, int W, int N,
+                                 unsigned int seed, int* cand, long cand_stride, int64_t* choose, int* n_cand, void* stream)
+{
+    if (!objmap || !depth || !objects || !cand || !choose || !n_cand || n < 0 || H < 1 || W < 1 || N < 1 || cand_stride < 1)
+        return APE_EINVAL;
+    if (n == 0) return APE_OK;
+    hipLaunchKernelGGL(choose_points_kernel, dim3(n), dim3(kT), 0, (hipStream_t)stream, objmap, depth, objects, H, W, N, seed,
+                       cand, cand_stride, choose, n_cand);
+    return ape::check_launch("ape_choose_points");
+}
+
+extern "C" int ape_backproject_f32(const uint16_t* depth, const int* objects, const int64_t* choose, float* points4, int n,
+                                   int H, int W, int N, float fx, float fy, float ppx, float ppy, float depth_scale, void* stream)
+{
+    if (!depth || !objects || !choose || !points4 || n < 0 || N < 1) return APE_EINVAL;
+    if (n == 0) return APE_OK;
+    hipLaunchKernelGGL(backproject_kernel, dim3(ape::ceil_div(N, kT), n), dim3(kT), 0, (hipStream_t)stream, depth, objects, choose,
+                       (float4*)points4, H, W, N, fx, fy, ppx, ppy, depth_scale);
+    return ape::check_launch("ape_backproject_f32");
+}
+
+extern "C" int ape_preprocess_u8_nhwc4(const uint8_t* rgb, const int* rects, float* out, int n, int H, int W, int Hc, int Wc,
+                                       int div255, void* stream)
+{
+    if (!rgb || !rects || !out || n < 0 || H < 1 || W < 1 || Hc < 1 || Wc < 1 || Hc > H || Wc > W) return APE_EINVAL;
+    const long total = (long)n * Hc * Wc;
+    if (total == 0) return APE_OK;
+    hipLaunchKernelGGL(crop_normalize_kernel, dim3(grid_for(total)), dim3(kT), 0, (hipStream_t)stream, rgb, rects, (float4*)out, H,
+                       W, Hc, Wc, div255, total);
+    return ape::check_launch("ape_preprocess_u8_nhwc4");
+}

@@ -166,3 +166,77 @@ def pose_recentre(points4, pose):
     rc = _lib.lib().ape_pose_recentre_f32(_lib.dptr(points4, torch.float32), _lib.dptr(pose, torch.float64), _lib.dptr(out), b, n, _st())
     _lib.check(rc, "ape_pose_recentre_f32")
     return out
+
+
+# ---- segmentation post-processing / selection --------------------------------------------------------------------
+def preprocess_u8(rgb, rects, hc, wc, div255):
+    """rgb[B,H,W,3] u8, rects[n,3] i32 (frame,row0,col0) -> [n,hc,wc,4] f32"""
+    b, h, w, _ = rgb.shape
+    n = rects.shape[0]
+    out = torch.empty(n, hc, wc, 4, dtype=torch.float32, device=rgb.device)
+    rc = _lib.lib().ape_preprocess_u8_nhwc4(_lib.dptr(rgb, torch.uint8), _lib.dptr(rects, torch.int32), _lib.dptr(out), n, h, w,
+                                            hc, wc, int(bool(div255)), _st())
+    _lib.check(rc, "ape_preprocess_u8_nhwc4")
+    return out
+
+
+def seg_argmax(logits, n_classes, double_softmax=True):
+    """logits[B,H,W,ld] -> label[B,H,W] u8, score[B,H,W] f32"""
+    b, h, w, ld = logits.shape
+    label = torch.empty(b, h, w, dtype=torch.uint8, device=logits.device)
+    score = torch.empty(b, h, w, dtype=torch.float32, device=logits.device)
+    rc = _lib.lib().ape_seg_argmax_f32(_lib.dptr(logits, torch.float32), ld, n_classes, _lib.dptr(label), _lib.dptr(score),
+                                       b * h * w, int(bool(double_softmax)), _st())
+    _lib.check(rc, "ape_seg_argmax_f32")
+    return label, score
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (str(device), "seg")
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def seg_components(label, score, n_classes, min_pixels=100):
+    """-> objmap[B,H,W] u8, det[B,C,5] i32 (valid,rmin,rmax,cmin,cmax)"""
+    b, h, w = label.shape
+    objmap = torch.empty_like(label)
+    det = torch.empty(b, n_classes, 5, dtype=torch.int32, device=label.device)
+    nbytes = _lib.lib().ape_seg_components_workspace_bytes(b, h, w, n_classes)
+    ws = _workspace(nbytes, label.device)
+    rc = _lib.lib().ape_seg_components(_lib.dptr(label, torch.uint8), _lib.dptr(score, torch.float32), _lib.dptr(objmap),
+                                       _lib.dptr(det), b, h, w, n_classes, min_pixels, _lib.dptr(ws), ws.numel(), _st())
+    _lib.check(rc, "ape_seg_components")
+    return objmap, det
+
+
+def choose_points(objmap, depth, objects, n_points, seed=0):
+    """objects[n,6] i32 (frame,cls,rmin,rmax,cmin,cmax) -> choose[n,N] i64, n_cand[n] i32"""
+    b, h, w = objmap.shape
+    n = objects.shape[0]
+    choose = torch.zeros(n, n_points, dtype=torch.int64, device=objmap.device)
+    n_cand = torch.zeros(n, dtype=torch.int32, device=objmap.device)
+    stride = h * w
+    cand = torch.empty(n, stride, dtype=torch.int32, device=objmap.device)
+    rc = _lib.lib().ape_choose_points(_lib.dptr(objmap, torch.uint8), _lib.dptr(depth, torch.uint16), _lib.dptr(objects, torch.int32),
+                                      n, h, w, n_points, seed & 0xFFFFFFFF, _lib.dptr(cand), stride, _lib.dptr(choose),
+                                      _lib.dptr(n_cand), _st())
+    _lib.check(rc, "ape_choose_points")
+    return choose, n_cand
+
+
+def backproject(depth, objects, choose, intr, depth_scale):
+    b, h, w = depth.shape
+    n, npts = choose.shape
+    pts = torch.empty(n, npts, 4, dtype=torch.float32, device=depth.device)
+    rc = _lib.lib().ape_backproject_f32(_lib.dptr(depth, torch.uint16), _lib.dptr(objects, torch.int32), _lib.dptr(choose, torch.int64),
+                                        _lib.dptr(pts), n, h, w, npts, float(intr["fx"]), float(intr["fy"]), float(intr["ppx"]),
+                                        float(intr["ppy"]), float(depth_scale), _st())
+    _lib.check(rc, "ape_backproject_f32")
+    return pts

@@ -1,0 +1,242 @@
+"""Drop-in for the live-prediction surface of pipeline/utils.py: `full_prediction` (reference :410-641) and
+`get_prediction_models` (:643-718), plus `FramePipeline`, the batched device-resident form the benchmark drives.
+
+Per frame the reference crosses host<->device ~8 times and loops in Python over classes / components / 307 200-element
+index maps.  Here a batch of B frames stays in HBM end to end:
+
+    u8 RGB + u16 depth  -> ToTensor/Normalize -> PSPNet segmentor -> softmax^2/argmax -> CCL + best component + bbox
+      --(ONE small D2H: det[B,C,5] int32, needed because crop shapes are data-dependent)-->
+    per (Hc,Wc) bucket:  choose/compaction -> back-projection -> crop normalise -> PoseNet -> pose select
+                         -> 2x PoseRefineNet -> float64 compose        ==> poses[n_obj,7] f64 on the device
+
+`refine_mode='live_compat'` reproduces the reference live loop literally (pipeline/utils.py:569-571: both refiner
+forwards see the SAME new_points and the residual is composed once); `'iterative'` is the upstream loop
+(DenseFusion/tools/eval_ycb.py:205-229).  Both run two real refiner forwards.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from autoposeestimation_amd import engine as E
+from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
+
+
+class FramePipeline:
+    def __init__(self, segmentor, estimator, refiner, class_names, num_points=1000, refine_mode="live_compat",
+                 min_pixels=100, iterations=2):
+        if refine_mode not in ("live_compat", "iterative"):
+            raise ValueError(refine_mode)
+        self.segmentor, self.estimator, self.refiner = segmentor, estimator, refiner
+        self.class_names = list(class_names)
+        self.n_cls = len(self.class_names) + 1          # + background (pipeline/utils.py:695)
+        self.num_points, self.refine_mode, self.min_pixels, self.iterations = num_points, refine_mode, min_pixels, iterations
+        self._full_rects = {}
+
+    # -- stage 1: segmentation + components, all on device ---------------------------------------------------------
+    def segment(self, rgb, inject_logits=None):
+        """rgb[B,H,W,3] u8 cuda -> objmap[B,H,W] u8, det[B,C,5] i32.  `inject_logits[B,H,W,C]` bypasses the CNN
+        (parity tests of the integer post-processing, SURVEY.md section 7 "Bit-exact masks")."""
+        b, h, w, _ = rgb.shape
+        if inject_logits is None:
+            key = (b, str(rgb.device))
+            rects = self._full_rects.get(key)
+            if rects is None:
+                rects = torch.zeros(b, 3, dtype=torch.int32)
+                rects[:, 0] = torch.arange(b, dtype=torch.int32)
+                rects = self._full_rects[key] = rects.to(rgb.device)
+            x4 = E.preprocess_u8(rgb, rects, h, w, div255=True)
+            logits = self.segmentor.logits_nhwc(x4)
+        else:
+            logits = inject_logits
+        label, score = E.seg_argmax(logits, self.n_cls, double_softmax=True)
+        return E.seg_components(label, score, self.n_cls, self.min_pixels)
+
+    # -- stage 2: pose for a list of detected objects --------------------------------------------------------------
+    def poses(self, rgb, depth, objmap, objects, meta, choose_override=None, seed=0):
+        """objects: list of (frame, cls, rmin, rmax, cmin, cmax).  Returns (pose[n,7] f64 cuda, n_cand[n] i32 cuda,
+        choose[n,N] i64 cuda) in the order of `objects`."""
+        n = len(objects)
+        dev = rgb.device
+        pose_all = torch.zeros(n, 7, dtype=torch.float64, device=dev)
+        ncand_all = torch.zeros(n, dtype=torch.int32, device=dev)
+        choose_all = torch.zeros(n, self.num_points, dtype=torch.int64, device=dev)
+        buckets = {}
+        for i, o in enumerate(objects):
+            buckets.setdefault((o[3] - o[2], o[5] - o[4]), []).append(i)
+        for (hc, wc), ids in buckets.items():
+            objs = torch.tensor([objects[i] for i in ids], dtype=torch.int32).to(dev)
+            ids_t = torch.tensor(ids, dtype=torch.int64).to(dev)
+            choose, n_cand = E.choose_points(objmap, depth, objs, self.num_points, seed)
+            if choose_override is not None:
+                for j, i in enumerate(ids):
+                    if choose_override.get(i) is not None:
+                        choose[j] = torch.as_tensor(choose_override[i], dtype=torch.int64).to(dev)
+            pts4 = E.backproject(depth, objs, choose, meta["intr"], meta["depth_scale"])
+            rects = objs[:, [0, 2, 4]].contiguous()
+            img4 = E.preprocess_u8(rgb, rects, hc, wc, div255=False)
+            obj_idx = (objs[:, 1].to(torch.int64) - 1).contiguous()         # class_names.index(cls) (pipeline/utils.py:561)
+            heads, emb = self.estimator.forward_batch(img4, pts4, choose, obj_idx)
+            if self.refine_mode == "live_compat":
+                pose, _, newp = E.pose_select(heads, pts4)
+                for _ in range(self.iterations):
+                    out = self.refiner.forward_batch(newp, emb, obj_idx)
+                E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+            else:
+                pose, _, _ = E.pose_select(heads, pts4, want_new_points=False)
+                for _ in range(self.iterations):
+                    out = self.refiner.forward_batch(E.pose_recentre(pts4, pose), emb, obj_idx)
+                    E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+            pose_all.index_copy_(0, ids_t, pose)
+            ncand_all.index_copy_(0, ids_t, n_cand)
+            choose_all.index_copy_(0, ids_t, choose)
+        return pose_all, ncand_all, choose_all
+
+    def run(self, rgb, depth, meta, inject_logits=None, choose_override=None, seed=0):
+        """Whole batch.  Returns dict(objects=[(frame,cls,rmin,rmax,cmin,cmax)], pose, n_cand, choose, objmap)."""
+        objmap, det = self.segment(rgb, inject_logits)
+        det_h = det.cpu().numpy()                       # the one host sync of the batch
+        objects = [(int(b), int(c), int(d[1]), int(d[2]), int(d[3]), int(d[4]))
+                   for b in range(det_h.shape[0]) for c, d in enumerate(det_h[b]) if c > 0 and d[0]]
+        if objects:
+            if choose_override is not None:             # keyed by (frame, cls) -> keyed by object position
+                choose_override = {i: choose_override.get((o[0], o[1])) for i, o in enumerate(objects)}
+            pose, n_cand, choose = self.poses(rgb, depth, objmap, objects, meta, choose_override, seed)
+        else:
+            pose = torch.zeros(0, 7, dtype=torch.float64, device=rgb.device)
+            n_cand = torch.zeros(0, dtype=torch.int32, device=rgb.device)
+            choose = torch.zeros(0, self.num_points, dtype=torch.int64, device=rgb.device)
+        return {"objects": objects, "pose": pose, "n_cand": n_cand, "choose": choose, "objmap": objmap}
+
+
+def _as_u8_frame(image):
+    arr = np.asarray(image)
+    if arr.ndim != 3 or arr.shape[2] < 3:
+        raise ValueError("image must be HxWx3 uint8")
+    return np.ascontiguousarray(arr[:, :, :3].astype(np.uint8))
+
+
+def full_prediction(image, depth, meta, segmentor, estimator, refiner, to_tensor, normalize, device, cuda, color_dict,
+                    class_names=None, point_clouds=None, plot=False, color_prediction=False, bbox=False, put_text=False,
+                    refine_mode="live_compat", choose_override=None):
+    """Reference signature (pipeline/utils.py:410-411) and output dict:
+        {'predictions': {cls_name: {'mask': u8[H,W] in {0,255}, 'position': f64[3] (m), 'rotation': f64[4] wxyz}},
+         'elapsed_times': {'segmentation', 'pose_estimation', 'total'}}
+    `to_tensor` / `normalize` are accepted for signature compatibility; the normalisation runs on the device.
+    `color_prediction` adds 'segmented_prediction' / 'pose_prediction' images (plain alpha blends; cv2 text/boxes are
+    skipped when OpenCV is absent).  Objects without a valid depth pixel are dropped like the reference (:530-531,623-635)."""
+    if not cuda or not torch.cuda.is_available():
+        raise RuntimeError("full_prediction needs the GPU: the MI355X path has no CPU fallback")
+    start_time = time.time()
+    rgb_np = _as_u8_frame(image)
+    depth_np = np.ascontiguousarray(np.asarray(depth))
+    if depth_np.dtype != np.uint16:
+        if (depth_np < 0).any() or (depth_np > 65535).any() or (depth_np != np.floor(depth_np)).any():
+            raise ValueError("depth must hold integer sensor units in 0..65535")
+        depth_np = depth_np.astype(np.uint16)
+    rgb = torch.from_numpy(rgb_np).to(device).unsqueeze(0)
+    dep = torch.from_numpy(depth_np).to(device).unsqueeze(0)
+    pipe = FramePipeline(segmentor, estimator, refiner, class_names, refine_mode=refine_mode)
+    objmap, det = pipe.segment(rgb)
+    det_h = det.cpu().numpy()
+    objmap_h = objmap[0].cpu().numpy()
+    output_dict = {"predictions": {}, "elapsed_times": {}}
+    objects = []
+    for c, d in enumerate(det_h[0]):
+        if c > 0 and d[0]:
+            name = class_names[c - 1]
+            output_dict["predictions"][name] = {"mask": np.where(objmap_h == c, 255, 0).astype(np.uint8)}
+            objects.append((0, c, int(d[1]), int(d[2]), int(d[3]), int(d[4])))
+    output_dict["elapsed_times"]["segmentation"] = time.time() - start_time
+    start_time_pose = time.time()
+    if objects:
+        ov = None
+        if choose_override is not None:
+            ov = {i: choose_override.get(class_names[o[1] - 1]) for i, o in enumerate(objects)}
+        pose, n_cand, _ = pipe.poses(rgb, dep, objmap, objects, meta, ov)
+        pose_h, n_cand_h = pose.cpu().numpy(), n_cand.cpu().numpy()
+        for i, o in enumerate(objects):
+            name = class_names[o[1] - 1]
+            if n_cand_h[i] == 0:
+                print('Deleting cls "{}"'.format(name))
+                del output_dict["predictions"][name]
+                continue
+            output_dict["predictions"][name]["position"] = pose_h[i, 4:7].copy()
+            output_dict["predictions"][name]["rotation"] = pose_h[i, 0:4].copy()
+    if color_prediction:
+        from autoposeestimation_amd.pc_reconstruction import open3d_utils as pc_utils
+        seg_img = rgb_np.astype(np.float64)
+        pose_img = rgb_np.astype(np.float64)
+        for name, pred in output_dict["predictions"].items():
+            colour = np.asarray(color_dict[name]["value"], dtype=np.float64)
+            m = pred["mask"] != 0
+            seg_img[m] = seg_img[m] * 0.7 + colour * 0.3
+            if point_clouds is not None:
+                from autoposeestimation_amd.DenseFusion.lib.transformations import quaternion_matrix
+                R = quaternion_matrix(pred["rotation"])[:3, :3]
+                cloud = np.dot(point_clouds[class_names.index(name)], R.T) + pred["position"]
+                pose_img = pc_utils.pointcloud2image(pose_img, cloud, 3, meta["intr"], color=list(colour))
+        output_dict["segmented_prediction"] = np.clip(seg_img, 0, 255).astype(np.uint8)
+        output_dict["pose_prediction"] = np.clip(pose_img, 0, 255).astype(np.uint8)
+    output_dict["elapsed_times"]["pose_estimation"] = time.time() - start_time_pose
+    output_dict["elapsed_times"]["total"] = time.time() - start_time
+    return output_dict
+
+
+class _ToTensor:
+    """torchvision.transforms.ToTensor stand-in returned by get_prediction_models (HWC u8 -> CHW float /255)."""
+
+    def __call__(self, pic):
+        arr = np.asarray(pic)
+        return torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).float().div(255)
+
+
+class _Normalize:
+    def __init__(self, mean, std):
+        self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+    def __call__(self, t):
+        return (t - self.mean.to(t.device)) / self.std.to(t.device)
+
+
+def read_xyz_cloud(path, to_meter=True):
+    """`<cls>.xyz` text parser (pipeline/utils.py:667-684): one bracketed, space-separated point per line, mm."""
+    pts = []
+    with open(path) as f:
+        for line in f:
+            vals = [float(v) for v in line.strip().strip("[]").split() if v]
+            if len(vals) >= 3:
+                pts.append(vals[:3])
+    arr = np.array(pts, dtype=np.float64)
+    return arr / 1000.0 if to_meter else arr
+
+
+def get_prediction_models(root, data_set_name, segmentor_name="PsPNet", encoder_name="resnet34"):
+    """Reference pipeline/utils.py:643-718: returns (segmentor, estimator, refiner, classes, to_tensor, normalize, cld,
+    device, cuda).  Weights are read from the same files (`pose_model.pth`, `pose_refine_model.pth`, and the segmentor
+    checkpoint `{name}_{encoder}.ckpt` with a 'state_dict' entry, label_generator/create_labels.py:29-35)."""
+    from autoposeestimation_amd.label_generator.create_labels import get_default_model
+    if not torch.cuda.is_available():
+        raise RuntimeError("get_prediction_models needs the GPU: the MI355X path has no CPU fallback")
+    device, cuda = torch.device("cuda:0"), True
+    classes, cld = [], {}
+    with open(os.path.join(root, "label_generator", "data_sets", "segmentation", data_set_name, "classes.txt")) as f:
+        for line in f:
+            name = line.strip()
+            if not name:
+                break
+            cld[len(classes)] = read_xyz_cloud(os.path.join(root, "pc_reconstruction", "data", name, "{}.xyz".format(name)))
+            classes.append(name)
+    to_tensor = _ToTensor()
+    normalize = _Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    segmentor = get_default_model(root, data_set_name, len(classes) + 1, name=segmentor_name, encoder_name=encoder_name)
+    segmentor.to(device).eval()
+    pose_path = os.path.join(root, "DenseFusion", "trained_models", data_set_name)
+    estimator = PoseNet(num_points=1000, num_obj=len(classes))
+    refiner = PoseRefineNet(num_points=1000, num_obj=len(classes))
+    estimator.load_state_dict(torch.load(os.path.join(pose_path, "pose_model.pth"), map_location="cpu"))
+    refiner.load_state_dict(torch.load(os.path.join(pose_path, "pose_refine_model.pth"), map_location="cpu"))
+    estimator.to(device).eval()
+    refiner.to(device).eval()
+    return segmentor, estimator, refiner, classes, to_tensor, normalize, cld, device, cuda

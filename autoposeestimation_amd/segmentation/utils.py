@@ -1,0 +1,71 @@
+"""Drop-in for the inference surface of segmentation/utils.py (reference :352-359): `nets`, `get_model`.
+
+The reference builds its segmentor from the third-party `segmentation_models_pytorch==0.1.3` (smp.Unet / PSPNet /
+Linknet), which is neither vendored in the reference tree nor installed here, so its arithmetic cannot be restated or
+pinned.  DECISION: `get_model('PsPNet', cfg)` returns the reference's OWN in-repo PSPNet
+(DenseFusion/lib/pspnet.py, BasicBlock encoder `cfg['encoder_name']` in {resnet18, resnet34}) executed by the gfx950
+kernels; `predict()` returns the first `classes` channels of its `final` 1x1 conv with the configured activation.
+smp-format Unet / LinkNet checkpoints cannot be honoured and raise NotImplementedError.
+
+Training-only symbols of the reference module (jaccard_loss, IoU, ConfusionMatrix, transforms, animate*) are outside the
+hot path and are not provided.
+"""
+import torch
+
+from autoposeestimation_amd import engine as E
+from autoposeestimation_amd.DenseFusion.lib.network import PSPNet, _need_cuda
+
+
+class PsPNetSegmentor(PSPNet):
+    """`model.predict(x[B,3,H,W]) -> [B,classes,H,W]` like smp's SegmentationModel.predict (eval + no_grad + activation)."""
+
+    def __init__(self, encoder_name="resnet18", encoder_weights=None, activation="softmax", in_channels=3, classes=2):
+        if in_channels != 3:
+            raise NotImplementedError("in_channels=3 only")
+        if encoder_weights is not None:
+            raise NotImplementedError("no pretrained encoder weights are available offline")
+        if not 1 <= classes <= 32:
+            raise ValueError("classes must be in 1..32 (the in-repo PSPNet's final conv has 32 channels, pspnet.py:54)")
+        if activation not in (None, "softmax", "softmax2d", "identity"):
+            raise NotImplementedError("activation %r" % (activation,))
+        super().__init__(backend=encoder_name)
+        self.classes, self.activation = classes, activation
+        self._final_cls = None
+
+    def _build_plan(self, sd, dev):
+        pl = super()._build_plan(sd, dev)
+        # only the first `classes` rows of the final 1x1 conv are ever needed
+        self._final_cls = E.Conv(sd["final.0.weight"][:self.classes], sd["final.0.bias"][:self.classes], device=dev)
+        return pl
+
+    def logits_nhwc(self, x4):
+        """x4[B,H,W,4] (ToTensor+Normalize'd RGB, zero 4th channel) -> logits[B,H,W,classes]"""
+        pl = self.plan()
+        return self._final_cls(pl.features(x4))
+
+    def predict(self, x):
+        _need_cuda(x, "input")
+        x4 = torch.zeros(x.shape[0], x.shape[2], x.shape[3], 4, dtype=torch.float32, device=x.device)
+        x4[..., :3] = x.permute(0, 2, 3, 1)
+        logits = self.logits_nhwc(x4).permute(0, 3, 1, 2).contiguous()
+        if self.activation in ("softmax", "softmax2d"):
+            return torch.softmax(logits, dim=1)
+        return logits
+
+
+def _unavailable(name):
+    def ctor(**cfg):
+        raise NotImplementedError(
+            "%s comes from segmentation_models_pytorch, which is not vendored in the reference and not installed; "
+            "use get_model('PsPNet', cfg) (in-repo PSPNet on gfx950)" % name)
+    return ctor
+
+
+nets = {"Unet": _unavailable("smp.Unet"), "PsPNet": PsPNetSegmentor, "LinkNet": _unavailable("smp.Linknet")}
+
+
+def get_model(name, segmentation_config):
+    """reference segmentation/utils.py:356-359"""
+    model = nets[name]
+    model = model(**segmentation_config)
+    return model

@@ -169,3 +169,18 @@ def model_cloud(cls, m=1000, seed=1234):
     """`m` model points uniform in a 0.1 m cube (metres), per class."""
     rng = np.random.default_rng([seed, int(cls)])
     return ((rng.random((m, 3), dtype=np.float32) - 0.5) * np.float32(0.1)).astype(np.float32)
+
+
+def fit_final_layer(feats, labels, n_out, margin=8.0, ridge=1e-2):
+    """Least-squares "training" of a segmentor's final 1x1 conv on frozen random features, so that synthetic frames
+    segment into their painted object with real logit margins (random weights alone give a random label map).
+    feats[P,64] float tensor (any device), labels[P] int64 in [0,n_out) -> (W[n_out,64], b[n_out]) float32 on CPU.
+    Targets: +margin for the pixel's class, -margin for every other class."""
+    f = feats.double()
+    p = f.shape[0]
+    a = torch.cat([f, torch.ones(p, 1, dtype=torch.float64, device=f.device)], 1)
+    t = torch.full((p, n_out), -float(margin), dtype=torch.float64, device=f.device)
+    t[torch.arange(p, device=f.device), labels.to(f.device)] = float(margin)
+    ata = a.t() @ a + ridge * p * torch.eye(a.shape[1], dtype=torch.float64, device=f.device)
+    sol = torch.linalg.solve(ata, a.t() @ t)          # [65, n_out]
+    return sol[:64].t().float().cpu().contiguous(), sol[64].float().cpu().contiguous()

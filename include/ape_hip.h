@@ -15,6 +15,7 @@
 #ifndef APE_HIP_H
 #define APE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -104,6 +105,33 @@ int ape_pose_select_f32(const float* heads, const float* points4, double* pose, 
 int ape_pose_compose_f64(double* pose, const float* ref_r, int ldr, const float* ref_t, int ldt, int B, void* stream);
 /* cloud re-centring of the iterative loop    DenseFusion/tools/eval_ycb.py:205-210. */
 int ape_pose_recentre_f32(const float* points4, const double* pose, float* new_points4, int B, int n, void* stream);
+
+/* ---- segmentation post-processing, crop / point selection (byte and index work, bit-exact) ----------------------
+ * softmax(+softmax) / argmax                 pipeline/utils.py:429-435 (predict's softmax activation, create_labels.py:23,
+ * then F.softmax again, then torch.argmax).  logits[npix][ld] f32 (first C channels) -> label[npix] u8,
+ * score[npix] f32 = probability of the arg-max class after one (double_softmax=0) or two softmaxes. */
+int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float* score, long npix,
+                       int double_softmax, void* stream);
+/* np.unique counts + cv2.connectedComponents(8) + best mean-probability component + mask + get_bbox
+ *   pipeline/utils.py:437-469, DenseFusion/datasets/myDatasetAugmented/dataset.py:338-380.
+ * label/score[B][H][W] -> objmap[B][H][W] u8 (class id inside the winning component of that class, else 0; the
+ * reference's per-class mask is (objmap == cls) * 255) and det[B][C][5] i32 = (valid, rmin, rmax, cmin, cmax).
+ * Classes with <= min_pixels pixels are skipped (reference: 100). */
+size_t ape_seg_components_workspace_bytes(int B, int H, int W, int C);
+int ape_seg_components(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
+                       int C, int min_pixels, void* workspace, size_t workspace_bytes, void* stream);
+/* choose = mask[rmin:rmax, cmin:cmax].flatten().nonzero(); > N -> ordered subset, <= N -> wrap pad
+ *   pipeline/utils.py:524-539.  objects[n][6] i32 = (frame, cls, rmin, rmax, cmin, cmax);
+ * choose[n][N] i64 indices inside the crop; n_cand[n] (0 => object dropped, :530-531); cand: scratch [n][cand_stride]. */
+int ape_choose_points(const uint8_t* objmap, const uint16_t* depth, const int* objects, int n, int H, int W, int N,
+                      unsigned int seed, int* cand, long cand_stride, int64_t* choose, int* n_cand, void* stream);
+/* float32 pin-hole back-projection          pipeline/utils.py:542-553.  points4[n][N][4] = (x, y, z, 0) */
+int ape_backproject_f32(const uint16_t* depth, const int* objects, const int64_t* choose, float* points4, int n,
+                        int H, int W, int N, float fx, float fy, float ppx, float ppy, float depth_scale, void* stream);
+/* ToTensor(/255)+Normalize (pipeline/utils.py:421-427, div255=1) or raw-scale crop normalisation (:559-560, div255=0):
+ * rgb[B][H][W][3] u8, rects[n][3] i32 = (frame, row0, col0) -> out[n][Hc][Wc][4] f32 (channel 3 = 0). */
+int ape_preprocess_u8_nhwc4(const uint8_t* rgb, const int* rects, float* out, int n, int H, int W, int Hc, int Wc,
+                            int div255, void* stream);
 
 #ifdef __cplusplus
 }

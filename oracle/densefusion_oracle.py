@@ -434,16 +434,20 @@ def segmentor_predict(seg_sd, x, classes, backend="resnet18"):
 
 
 def full_prediction(rgb, depth, meta, seg_sd, est_sd, ref_sd, class_names, num_points=1000,
-                    choose_masks=None, backend="resnet18", refine_mode="live_compat"):
+                    choose_masks=None, backend="resnet18", refine_mode="live_compat", choose_fn=None, inject_logits=None):
     """CPU restatement of pipeline/utils.py:410-641 without the drawing code.
 
     refine_mode 'live_compat' reproduces the reference's live loop literally (:569-571: two refiner
     forwards on the SAME new_points, one composition); 'iterative' follows DenseFusion/tools/eval_ycb.py:205-229.
-    `choose_masks[cls_name]` injects the random sub-selection (see select_choose)."""
+    `choose_masks[cls_name]` injects the random sub-selection (see select_choose); `choose_fn(name, nz, N)` may return the
+    chosen crop indices directly.  `inject_logits[1,C,H,W]` replaces the segmentor's raw logits."""
     n_cls = len(class_names)
     x = seg_input(rgb)
     with torch.no_grad():
-        pred = F.softmax(segmentor_predict(seg_sd, x, n_cls + 1, backend), dim=1)[0]
+        if inject_logits is None:
+            pred = F.softmax(segmentor_predict(seg_sd, x, n_cls + 1, backend), dim=1)[0]
+        else:
+            pred = F.softmax(F.softmax(inject_logits[:, :n_cls + 1], dim=1), dim=1)[0]
     masks = seg_postprocess(pred)
     out = {}
     for cls, mask in masks.items():
@@ -454,7 +458,10 @@ def full_prediction(rgb, depth, meta, seg_sd, est_sd, ref_sd, class_names, num_p
         nz = m[rmin:rmax, cmin:cmax].flatten().nonzero()[0]
         if len(nz) == 0:
             continue
-        choose = select_choose(nz, num_points, None if choose_masks is None else choose_masks.get(name))
+        if choose_fn is not None:
+            choose = np.asarray(choose_fn(name, nz, num_points))
+        else:
+            choose = select_choose(nz, num_points, None if choose_masks is None else choose_masks.get(name))
         pts = torch.from_numpy(backproject(depth, choose, rmin, rmax, cmin, cmax, meta)).unsqueeze(0)
         ch = torch.from_numpy(choose.astype(np.int64)).view(1, 1, -1)
         img = crop_image(rgb, rmin, rmax, cmin, cmax)

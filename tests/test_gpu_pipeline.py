@@ -1,0 +1,107 @@
+"""End-to-end parity of the live path (segmentor -> masks -> crop -> PoseNet -> 2x refiner -> pose) on synthetic 640x480
+RGB-D frames against the CPU oracle restatement of pipeline/utils.py:410-641.  Mask bit-exact, R/t within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from autoposeestimation_amd import synthetic as S
+from oracle import densefusion_oracle as O
+
+pytestmark = pytest.mark.gpu
+CLASSES = ["obj%02d" % i for i in range(12)]
+
+
+def _models(backend="resnet18"):
+    from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
+    from autoposeestimation_amd.segmentation.utils import get_model
+    seg = get_model("PsPNet", {"encoder_name": backend, "encoder_weights": None, "activation": "softmax",
+                               "in_channels": 3, "classes": 13})
+    seg_sd = S.pspnet_state_dict(backend, seed=5)
+    seg.load_state_dict(seg_sd)
+    est = PoseNet(1000, 12)
+    est_sd = S.posenet_state_dict(12, 0)
+    est.load_state_dict(est_sd)
+    ref = PoseRefineNet(1000, 12)
+    ref_sd = S.refiner_state_dict(12, 0)
+    ref.load_state_dict(ref_sd)
+    return seg.cuda().eval(), est.cuda().eval(), ref.cuda().eval(), seg_sd, est_sd, ref_sd
+
+
+def _fit_segmentor(seg, seg_sd, frames):
+    """"train" the final 1x1 conv by least squares on the HIP features of the given frames (see synthetic.fit_final_layer)"""
+    from autoposeestimation_amd import engine as E
+    feats, labels = [], []
+    for rgb, _, label in frames:
+        x4 = E.preprocess_u8(torch.from_numpy(rgb[None]).cuda(), torch.zeros(1, 3, dtype=torch.int32).cuda(), 480, 640, True)
+        f = seg.plan().features(x4)[0].reshape(-1, 64)
+        lab = torch.from_numpy(label.reshape(-1).astype(np.int64))
+        rng = np.random.default_rng(0)
+        fg = np.nonzero(label.reshape(-1))[0]
+        bg = rng.choice(np.nonzero(label.reshape(-1) == 0)[0], size=len(fg), replace=False)
+        sel = torch.from_numpy(np.concatenate([fg, bg]))
+        feats.append(f[sel.cuda()])
+        labels.append(lab[sel])
+    w, b = S.fit_final_layer(torch.cat(feats), torch.cat(labels), 13)
+    seg_sd = dict(seg_sd)
+    fw, fb = seg_sd["final.0.weight"].clone(), seg_sd["final.0.bias"].clone()
+    fw[:13, :, 0, 0], fb[:13] = w, b
+    seg_sd["final.0.weight"], seg_sd["final.0.bias"] = fw, fb
+    seg.load_state_dict(seg_sd)
+    return seg.cuda().eval(), seg_sd
+
+
+@pytest.mark.parametrize("refine_mode", ["live_compat", "iterative"])
+def test_full_prediction_vs_oracle(refine_mode):
+    from autoposeestimation_amd.pipeline.utils import full_prediction
+    seg, est, ref, seg_sd, est_sd, ref_sd = _models()
+    frames = [S.synthetic_frame(100 + i, cls=c, box=bx, size=sz) for i, (c, bx, sz) in
+              enumerate([(4, (150, 250), (150, 150)), (9, (40, 60), (70, 110))])]
+    seg, seg_sd = _fit_segmentor(seg, seg_sd, frames)
+    meta = S.REALSENSE_META
+    for rgb, depth, label in frames:
+        chosen = {}
+
+        def choose_fn(name, nz, n):
+            rng = np.random.default_rng(len(nz))
+            ch = np.sort(rng.choice(nz, size=n, replace=False)) if len(nz) > n else np.pad(nz, (0, n - len(nz)), "wrap")
+            chosen[name] = ch
+            return ch
+
+        want = O.full_prediction(rgb, depth, meta, seg_sd, est_sd, ref_sd, CLASSES, choose_fn=choose_fn, refine_mode=refine_mode)
+        got = full_prediction(rgb, depth, meta, seg, est, ref, None, None, torch.device("cuda:0"), True, {},
+                              class_names=CLASSES, refine_mode=refine_mode, choose_override=chosen)
+        assert set(got["predictions"]) == set(want) and len(want) >= 1
+        assert set(got["elapsed_times"]) == {"segmentation", "pose_estimation", "total"}
+        for name, w in want.items():
+            g = got["predictions"][name]
+            diff = int((g["mask"] != w["mask"]).sum())
+            assert diff == 0, "mask differs in %d pixels" % diff
+            assert g["mask"].dtype == np.uint8 and set(np.unique(g["mask"])) <= {0, 255}
+            q = g["rotation"] if np.dot(g["rotation"], w["rotation"]) >= 0 else -g["rotation"]
+            assert np.abs(q - w["rotation"]).max() <= 1e-4, (name, np.abs(q - w["rotation"]).max())
+            assert np.abs(g["position"] - w["position"]).max() <= 1e-4, (name, np.abs(g["position"] - w["position"]).max())
+
+
+def test_batched_pipeline_equals_single_frames():
+    """FramePipeline over B frames (mixed crop sizes -> two buckets) == per-frame full_prediction."""
+    from autoposeestimation_amd.pipeline.utils import FramePipeline, full_prediction
+    seg, est, ref, seg_sd, _, _ = _models()
+    spec = [(1, (150, 250), (150, 150)), (2, (200, 100), (150, 150)), (3, (40, 60), (70, 110)), (5, (300, 400), (150, 150))]
+    frames = [S.synthetic_frame(200 + i, cls=c, box=bx, size=sz) for i, (c, bx, sz) in enumerate(spec)]
+    seg, _ = _fit_segmentor(seg, seg_sd, frames)
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    pipe = FramePipeline(seg, est, ref, CLASSES)
+    out = pipe.run(rgb, depth, S.REALSENSE_META, seed=3)
+    assert len(out["objects"]) >= len(frames)
+    choose = out["choose"].cpu().numpy()
+    pose = out["pose"].cpu().numpy()
+    for i, o in enumerate(out["objects"]):
+        b, cls = o[0], o[1]
+        single = full_prediction(frames[b][0], frames[b][1], S.REALSENSE_META, seg, est, ref, None, None,
+                                 torch.device("cuda:0"), True, {}, class_names=CLASSES,
+                                 choose_override={CLASSES[cls - 1]: choose[i]})
+        p = single["predictions"][CLASSES[cls - 1]]
+        np.testing.assert_allclose(pose[i, :4], p["rotation"], atol=1e-6)
+        np.testing.assert_allclose(pose[i, 4:], p["position"], atol=1e-6)
+        assert np.array_equal((out["objmap"][b].cpu().numpy() == cls), p["mask"] == 255)

@@ -1,0 +1,35 @@
+"""Quick device timing of PoseNet+2xRefiner on B crops (development aid, not the bench contract)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from autoposeestimation_amd import synthetic as S, engine as E
+from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+HC = int(sys.argv[2]) if len(sys.argv) > 2 else 160
+N = 1000
+est = PoseNet(N, 12); est.load_state_dict(S.posenet_state_dict(12, 0)); est = est.cuda().eval()
+ref = PoseRefineNet(N, 12); ref.load_state_dict(S.refiner_state_dict(12, 0)); ref = ref.cuda().eval()
+torch.manual_seed(0)
+img4 = torch.rand(B, HC, HC, 4, device="cuda") * 1000; img4[..., 3] = 0
+pts4 = torch.rand(B, N, 4, device="cuda"); pts4[..., 3] = 0
+choose = torch.stack([torch.randperm(HC * HC, device="cuda")[:N] for _ in range(B)])
+obj = torch.randint(0, 12, (B,), device="cuda")
+
+def step():
+    heads, emb = est.forward_batch(img4, pts4, choose, obj)
+    pose, _, newp = E.pose_select(heads, pts4)
+    for _ in range(2):
+        out = ref.forward_batch(newp, emb, obj)
+    E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+    return pose
+
+for _ in range(3): step()
+torch.cuda.synchronize()
+K = 10
+t = time.time()
+for _ in range(K): step()
+torch.cuda.synchronize()
+dt = (time.time() - t) / K
+flop = B * (0.8957e6 * HC * HC + 7.959e9 + 2 * 1.4814e9)
+print("B=%d crop=%d  %.2f ms/step  %.1f crops/s  %.1f TFLOP/s (reference-algorithm FLOPs)" % (B, HC, dt * 1e3, B / dt, flop / dt / 1e12))
