@@ -17,6 +17,26 @@ def _st():
     return _lib.stream_ptr()
 
 
+class LaunchProfile:
+    """Optional per-launch HIP-event timing of the conv kernels on torch's current stream (bench.py's roofline leg).
+    Events are recorded on the very stream the kernel is enqueued on; durations are read after the final sync."""
+
+    def __init__(self):
+        self.records = []       # (kernel variant, algorithmic flop, start event, end event)
+
+    def summary(self):
+        out = {}
+        for name, flop, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flop"] += flop
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILE = None   # set to a LaunchProfile() to time conv launches
+
+
 def pack_conv_weight(w, device):
     """[Cout,Cin,KH,KW] | [Cout,Cin,1] | [Cout,Cin]  ->  contiguous f32 [Cout,KH,KW,Cin4] on `device`."""
     w = w.detach()
@@ -37,6 +57,8 @@ class Conv:
     def __init__(self, weight, bias=None, stride=1, pad=0, dil=1, act=ACT_NONE, alpha=0.0, device="cuda"):
         self.w = pack_conv_weight(weight, device)
         self.cout, self.kh, self.kw, self.cin = self.w.shape
+        self.cin_real = weight.shape[1]
+        self.variant = "conv_f32_kernel<%s>" % ("128,2,2" if self.cout > 64 else "64,4,1" if self.cout > 32 else "32,4,1")
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.stride, self.pad, self.dil, self.act, self.alpha = stride, pad, dil, act, float(alpha)
 
@@ -60,9 +82,16 @@ class Conv:
                        ldy=out.shape[3], yoff=yoff, KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad,
                        dil=self.dil, act=self.act if act is None else act, alpha=self.alpha,
                        bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff)
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = _lib.lib().ape_conv2d_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(self.w), _lib.dptr(bias),
                                             _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p), _st())
         _lib.check(rc, "ape_conv2d_nhwc_f32")
+        if prof is not None:
+            e1.record()
+            prof.records.append((self.variant, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
 
 

@@ -78,10 +78,12 @@ def _fill(spec, seed, prefix="", overrides=None):
     return sd
 
 
-def pspnet_state_dict(backend="resnet18", seed=0, prefix="", n_classes=21):
-    # the stem sees raw 0-255-scale pixels: bring them to O(1) like a trained first layer would
+def pspnet_state_dict(backend="resnet18", seed=0, prefix="", n_classes=21, stem_gain=1.0 / 256.0):
+    """stem_gain: the PoseNet crop encoder sees raw 0-255-scale pixels (pipeline/utils.py:559-560), so its stem is scaled
+    by 1/256 to bring them to O(1) like a trained first layer would; a SEGMENTOR sees ToTensor'd [0,1] pixels
+    (pipeline/utils.py:421-424) -> use stem_gain=1.0 there."""
     spec = pspnet_spec(backend, n_classes)
-    over = {"feats.conv1.weight": 1.0 / 256.0, "final.0.weight": 0.35}
+    over = {"feats.conv1.weight": stem_gain, "final.0.weight": 0.35}
     # residual branches at half gain so 8..16 un-normalised blocks do not blow the variance up
     over.update({k: 0.5 for k, _ in spec if k.startswith("feats.layer") and k.endswith("conv2.weight")})
     return _fill(spec, seed, prefix, over)

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- RGB-D frames/s through seg + DenseFusion + 2 refine iterations on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the whole live path (FramePipeline.run: u8 RGB + u16 depth resident in HBM -> PSPNet-resnet18
+segmentation at 480x640 -> masks / CCL / bbox -> 160x160 crop -> PoseNet(N=1000) -> 2x PoseRefineNet -> float64 pose)
+over one batch of synthetic frames (BASELINE config 3: batch=64 640x480 frames per GPU).  Frames shard across ranks
+(weak scaling, no data-path collective); each step ends with the single RCCL all_gather of the poses (config 4).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from autoposeestimation_amd import engine as E  # noqa: E402
+from autoposeestimation_amd import synthetic as S  # noqa: E402
+
+CLASSES = ["obj%02d" % i for i in range(12)]
+H, W, N_POINTS = 480, 640, 1000
+# algorithmic work per frame: PSPNet-r18 segmentation 275.15 GF + crop encoder 22.95 + PointNet/heads 7.96 + 2 x 1.48
+GFLOP_PER_FRAME = 309.0
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def make_frames(batch, rank):
+    frames = []
+    for i in range(batch):
+        fid = rank * 100003 + i
+        rng = np.random.default_rng(fid)
+        box = (int(rng.integers(10, 480 - 160)), int(rng.integers(10, 640 - 160)))
+        frames.append(S.synthetic_frame(fid, cls=1 + (i % 12), box=box, size=(150, 150)))
+    return frames
+
+
+def build_models(device, frames_for_fit):
+    from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
+    from autoposeestimation_amd.segmentation.utils import get_model
+    seg = get_model("PsPNet", {"encoder_name": "resnet18", "encoder_weights": None, "activation": "softmax",
+                               "in_channels": 3, "classes": 13})
+    seg_sd = S.pspnet_state_dict("resnet18", seed=5, stem_gain=1.0)
+    seg.load_state_dict(seg_sd)
+    seg = seg.to(device).eval()
+    # "train" the final 1x1 conv by least squares on frozen random features so the painted objects are segmented
+    feats, labels = [], []
+    rects = torch.zeros(1, 3, dtype=torch.int32, device=device)
+    for rgb, _, label in frames_for_fit:
+        x4 = E.preprocess_u8(torch.from_numpy(rgb[None]).to(device), rects, H, W, True)
+        f = seg.plan().features(x4)[0].reshape(-1, 64)
+        flat = label.reshape(-1)
+        fg = np.nonzero(flat)[0]
+        bg = np.random.default_rng(0).choice(np.nonzero(flat == 0)[0], size=len(fg), replace=False)
+        sel = torch.from_numpy(np.concatenate([fg, bg]))
+        feats.append(f[sel.to(device)])
+        labels.append(torch.from_numpy(flat.astype(np.int64))[sel])
+    w, b = S.fit_final_layer(torch.cat(feats), torch.cat(labels), 13)
+    fw, fb = seg_sd["final.0.weight"].clone(), seg_sd["final.0.bias"].clone()
+    fw[:13, :, 0, 0], fb[:13] = w, b
+    seg_sd["final.0.weight"], seg_sd["final.0.bias"] = fw, fb
+    seg.load_state_dict(seg_sd)
+    seg = seg.to(device).eval()
+    est = PoseNet(N_POINTS, 12)
+    est_sd = S.posenet_state_dict(12, 0)
+    est.load_state_dict(est_sd)
+    ref = PoseRefineNet(N_POINTS, 12)
+    ref_sd = S.refiner_state_dict(12, 0)
+    ref.load_state_dict(ref_sd)
+    return seg, est.to(device).eval(), ref.to(device).eval(), seg_sd, est_sd, ref_sd
+
+
+def cpu_baseline(frames, seg_sd, est_sd, ref_sd, n_frames=3):
+    """The oracle (CPU restatement of pipeline/utils.py:410-641, validated against reference goldens) timed on the host
+    cores on a bounded sample of the SAME frames.  Reported baseline only -- never part of `value`."""
+    from oracle import densefusion_oracle as O
+
+    def choose_fn(name, nz, n):
+        return nz[(np.arange(n) * len(nz)) // n] if len(nz) > n else np.pad(nz, (0, n - len(nz)), "wrap")
+
+    O.full_prediction(*frames[0][:2], S.REALSENSE_META, seg_sd, est_sd, ref_sd, CLASSES, choose_fn=choose_fn)  # warm
+    t = time.time()
+    found = 0
+    for rgb, depth, _ in frames[:n_frames]:
+        found += len(O.full_prediction(rgb, depth, S.REALSENSE_META, seg_sd, est_sd, ref_sd, CLASSES, choose_fn=choose_fn))
+    dt = time.time() - t
+    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the benchmark's 640x480 frames (%d objects found), oracle/densefusion_oracle.full_prediction, "
+                      "torch CPU fp32, %d threads" % (n_frames, found, torch.get_num_threads())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from autoposeestimation_amd.pipeline.utils import FramePipeline
+    frames = make_frames(args.batch, rank)
+    fit_frames = [S.synthetic_frame(900 + c, cls=c, box=(100 + 20 * c, 60 + 40 * c), size=(150, 150)) for c in range(1, 13)]
+    seg, est, ref, seg_sd, est_sd, ref_sd = build_models(device, fit_frames)
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device)        # inputs resident in HBM
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device)
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat")
+    gathered = [torch.empty(args.batch, 1, 8, dtype=torch.float32, device=device) for _ in range(world)] if dist else None
+
+    def step(i):
+        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+        poses = torch.zeros(args.batch, 1, 8, dtype=torch.float32, device=device)
+        if out["objects"]:
+            fr = torch.tensor([o[0] for o in out["objects"]], device=device)
+            cl = torch.tensor([float(o[1]) for o in out["objects"]], device=device)
+            poses[fr, 0, 0] = cl
+            poses[fr, 0, 1:] = out["pose"].float()
+        if dist:
+            dist.all_gather(gathered, poses)     # the single RCCL collective of the path: (cls, q, t) per frame
+        return out
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    n_found = len(out["objects"]) if args.warmup else -1
+    fence()
+    prof = E.PROFILE = E.LaunchProfile()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    E.PROFILE = None
+    n_found = len(out["objects"])
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    if rank == 0:
+        summ = prof.summary()
+        dom = max(summ, key=lambda k: summ[k]["ms"]) if summ else None
+        roofline = None
+        if dom:
+            d = summ[dom]
+            ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                        "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3),
+                        "share_of_step_time": round(d["ms"] * 1e-3 / dt, 3)}
+        total_frames = args.batch * world * args.steps
+        line = {
+            "metric": "RGB-D frames/sec (seg+DenseFusion+2-refine), 640x480 N=1000",
+            "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: end-to-end PSPNet-resnet18 segmentation -> mask/CCL/bbox -> 160x160 crop -> "
+                                   "PoseNet(N=1000) -> 2x PoseRefineNet, batch=%d 640x480 frames per GPU" % args.batch,
+                       "frames_per_gpu_per_step": args.batch, "objects_found_last_step": n_found,
+                       "gflop_per_frame_algorithmic": GFLOP_PER_FRAME, "parallelism": "frames sharded x%d, 1 all_gather of poses/step" % world},
+            "achieved_tflops_algorithmic": round(total_frames * GFLOP_PER_FRAME / dt / 1e3, 2),
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(frames, seg_sd, est_sd, ref_sd)
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@ def _models(backend="resnet18"):
     from autoposeestimation_amd.segmentation.utils import get_model
     seg = get_model("PsPNet", {"encoder_name": backend, "encoder_weights": None, "activation": "softmax",
                                "in_channels": 3, "classes": 13})
-    seg_sd = S.pspnet_state_dict(backend, seed=5)
+    seg_sd = S.pspnet_state_dict(backend, seed=5, stem_gain=1.0)
     seg.load_state_dict(seg_sd)
     est = PoseNet(1000, 12)
     est_sd = S.posenet_state_dict(12, 0)
