@@ -1,0 +1,44 @@
+"""Summarise a rocprofv3 --kernel-trace CSV of `bench.py --steps K --warmup W`: per-kernel totals over the whole process
+and over the TIMED REGION only (the last K/(K+W) of the pipeline's launches -- set-up launches, e.g. the segmentor
+last-layer fit, come first and are dropped), so the average launch duration can be compared with bench.py's live figure.
+
+    python tools/prof_summary.py gpurun_out/prof_bench/*/*_kernel_trace.csv --steps 3 --warmup 1 > profiles/rNN_....json
+"""
+import argparse
+import collections
+import csv
+import json
+
+ap = argparse.ArgumentParser()
+ap.add_argument("trace")
+ap.add_argument("--steps", type=int, required=True)
+ap.add_argument("--warmup", type=int, required=True)
+a = ap.parse_args()
+assert a.warmup >= 1, "needs at least one warm-up step to locate the start of the timed region"
+rows = list(csv.DictReader(open(a.trace)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# Step structure: every step launches seg_argmax_kernel exactly once (after its segmentation CNN) and ends with
+# pose_compose_kernel launches.  The timed region starts after the last pose_compose of warm-up step W.
+argmax = [i for i, r in enumerate(rows) if "seg_argmax_kernel" in r["Kernel_Name"]]
+assert len(argmax) == a.steps + a.warmup, (len(argmax), a.steps, a.warmup)
+last_compose = max(i for i, r in enumerate(rows[:argmax[a.warmup]]) if "pose_compose_kernel" in r["Kernel_Name"])
+t0 = int(rows[last_compose]["End_Timestamp"])
+by = collections.defaultdict(list)
+timed = collections.defaultdict(list)
+for r in rows:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    by[r["Kernel_Name"]].append(d)
+    if int(r["Start_Timestamp"]) >= t0:
+        timed[r["Kernel_Name"]].append(d)
+out = {}
+tot = sum(sum(v) for v in by.values())
+ttot = sum(sum(v) for v in timed.values())
+for name, d in sorted(by.items(), key=lambda kv: -sum(timed.get(kv[0], [0]))):
+    t = timed.get(name, [])
+    short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:80]
+    out[short] = {"process": {"launches": len(d), "total_ms": round(sum(d) / 1e3, 3), "avg_us": round(sum(d) / len(d), 2),
+                              "share": round(sum(d) / tot, 4)},
+                  "timed_region": {"launches": len(t), "total_ms": round(sum(t) / 1e3, 3),
+                                   "avg_us": round(sum(t) / len(t), 2) if t else None,
+                                   "share": round(sum(t) / ttot, 4) if t else 0.0}}
+print(json.dumps(out, indent=1))
