@@ -48,6 +48,15 @@ class _HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._plan = None
+        self.precision = "f32"
+
+    def set_precision(self, precision):
+        """Operand precision of this network's dense contractions: 'f32' | 'bf16x3' | 'bf16' (see engine.PRECISIONS)."""
+        if precision not in E.PRECISIONS:
+            raise ValueError(precision)
+        self.precision = precision
+        self._plan = None
+        return self
 
     def _apply(self, fn, *a, **k):
         self._plan = None
@@ -78,9 +87,10 @@ def _pspnet_param_shapes(backend, n_classes):
 
 
 class _PSPPlan:
-    def __init__(self, sd, prefix, backend, dev):
+    def __init__(self, sd, prefix, backend, dev, precision="f32"):
         g = lambda k: sd[prefix + k]  # noqa: E731
-        self.stem = E.Conv(g("feats.conv1.weight"), None, 2, 3, 1, E.ACT_RELU, device=dev)
+        _Conv = lambda *a, **k: E.Conv(*a, precision=precision, **k)  # noqa: E731
+        self.stem = _Conv(g("feats.conv1.weight"), None, 2, 3, 1, E.ACT_RELU, device=dev)
         self.blocks = []
         inplanes = 64
         for li, (planes, nblk, stride, dil) in enumerate(zip((64, 128, 256, 512), _BLOCKS[backend], (1, 2, 1, 1), (1, 1, 2, 4)), 1):
@@ -89,20 +99,20 @@ class _PSPPlan:
                 s = stride if first else 1
                 d = 1 if first else dil      # extractors.py:107 does not forward `dilation` to the first block
                 p = f"feats.layer{li}.{b}."
-                c1 = E.Conv(g(p + "conv1.weight"), None, s, d, d, E.ACT_RELU, device=dev)
-                c2 = E.Conv(g(p + "conv2.weight"), None, 1, d, d, E.ACT_RELU, device=dev)   # relu after the residual add
+                c1 = _Conv(g(p + "conv1.weight"), None, s, d, d, E.ACT_RELU, device=dev)
+                c2 = _Conv(g(p + "conv2.weight"), None, 1, d, d, E.ACT_RELU, device=dev)   # relu after the residual add
                 down = None
                 if first and (stride != 1 or inplanes != planes):
-                    down = E.Conv(g(p + "downsample.0.weight"), None, s, 0, 1, E.ACT_NONE, device=dev)
+                    down = _Conv(g(p + "downsample.0.weight"), None, s, 0, 1, E.ACT_NONE, device=dev)
                 self.blocks.append((c1, c2, down))
             inplanes = planes
         wb = g("psp.bottleneck.weight")           # [1024, 2560, 1, 1] = [prior_1 | prior_2 | prior_3 | prior_6 | feats]
-        self.stage = [E.Conv(g(f"psp.stages.{i}.1.weight"), None, device=dev) for i in range(4)]
-        self.bott_prior = [E.Conv(wb[:, i * 512:(i + 1) * 512], None, device=dev) for i in range(4)]
-        self.bott_feats = E.Conv(wb[:, 2048:2560], g("psp.bottleneck.bias"), act=E.ACT_RELU, device=dev)
-        self.up = [E.Conv(g(f"{n}.conv.1.weight"), g(f"{n}.conv.1.bias"), 1, 1, 1, E.ACT_PRELU,
+        self.stage = [_Conv(g(f"psp.stages.{i}.1.weight"), None, device=dev) for i in range(4)]
+        self.bott_prior = [_Conv(wb[:, i * 512:(i + 1) * 512], None, device=dev) for i in range(4)]
+        self.bott_feats = _Conv(wb[:, 2048:2560], g("psp.bottleneck.bias"), act=E.ACT_RELU, device=dev)
+        self.up = [_Conv(g(f"{n}.conv.1.weight"), g(f"{n}.conv.1.bias"), 1, 1, 1, E.ACT_PRELU,
                           alpha=float(g(f"{n}.conv.2.weight").reshape(-1)[0]), device=dev) for n in ("up_1", "up_2", "up_3")]
-        self.final = E.Conv(g("final.0.weight"), g("final.0.bias"), device=dev)
+        self.final = _Conv(g("final.0.weight"), g("final.0.bias"), device=dev)
 
     def features(self, x, taps=None):
         """x[B,H,W,4] (RGB + zero pad) -> up_3 activation [B,H,W,64]"""
@@ -139,7 +149,7 @@ class PSPNet(_HipModule):
             _register(self, key, torch.zeros(shape))
 
     def _build_plan(self, sd, dev):
-        return _PSPPlan(sd, "", self.backend, dev)
+        return _PSPPlan(sd, "", self.backend, dev, self.precision)
 
     def forward_nhwc(self, x4, logits_only=False):
         """x4[B,H,W,4] -> [B,H,W,32] log-softmax (or raw logits)"""
@@ -161,14 +171,15 @@ class _FeatPlan:
     """PoseNetFeat / PoseRefineNetFeat (network.py:39-68, 136-168) writing straight into the concatenated buffer
     pf[B*N, 384] = [conv1(x) 64 | e_conv1(emb) 64 | conv2 128 | e_conv2 128]."""
 
-    def __init__(self, sd, dev, refine):
+    def __init__(self, sd, dev, refine, precision="f32"):
         g = lambda k: (sd[f"feat.{k}.weight"], sd[f"feat.{k}.bias"])  # noqa: E731
-        self.conv1 = E.Conv(*g("conv1"), act=E.ACT_RELU, device=dev)
-        self.e_conv1 = E.Conv(*g("e_conv1"), act=E.ACT_RELU, device=dev)
-        self.conv2 = E.Conv(*g("conv2"), act=E.ACT_RELU, device=dev)
-        self.e_conv2 = E.Conv(*g("e_conv2"), act=E.ACT_RELU, device=dev)
-        self.conv5 = E.Conv(*g("conv5"), act=E.ACT_RELU, device=dev)
-        self.conv6 = E.Conv(*g("conv6"), act=E.ACT_RELU, device=dev)
+        kw = dict(act=E.ACT_RELU, device=dev, precision=precision)
+        self.conv1 = E.Conv(*g("conv1"), **kw)
+        self.e_conv1 = E.Conv(*g("e_conv1"), **kw)
+        self.conv2 = E.Conv(*g("conv2"), **kw)
+        self.e_conv2 = E.Conv(*g("e_conv2"), **kw)
+        self.conv5 = E.Conv(*g("conv5"), **kw)
+        self.conv6 = E.Conv(*g("conv6"), **kw)
         self.refine = refine
 
     def __call__(self, x4, emb):
@@ -198,14 +209,15 @@ class PoseNet(_HipModule):
 
     def _build_plan(self, sd, dev):
         pl = type("Plan", (), {})()
-        pl.cnn = _PSPPlan(sd, "cnn.model.module.", "resnet18", dev)
-        pl.feat = _FeatPlan(sd, dev, refine=False)
+        pr = self.precision
+        pl.cnn = _PSPPlan(sd, "cnn.model.module.", "resnet18", dev, pr)
+        pl.feat = _FeatPlan(sd, dev, refine=False, precision=pr)
         w1 = torch.cat([sd[f"conv1_{h}.weight"] for h in "rtc"], 0)[:, :, 0]      # [1920, 1408]
         b1 = torch.cat([sd[f"conv1_{h}.bias"] for h in "rtc"], 0)
-        pl.l1_point = E.Conv(w1[:, :384], None, act=E.ACT_RELU, device=dev)           # per-point part
-        pl.l1_global = E.Conv(w1[:, 384:], b1, act=E.ACT_NONE, device=dev)            # per-crop bias from ap_x
-        pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev) for h in "rtc"]
-        pl.l3 = [E.Conv(sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"], act=E.ACT_RELU, device=dev) for h in "rtc"]
+        pl.l1_point = E.Conv(w1[:, :384], None, act=E.ACT_RELU, device=dev, precision=pr)           # per-point part
+        pl.l1_global = E.Conv(w1[:, 384:], b1, act=E.ACT_NONE, device=dev, precision=pr)            # per-crop bias from ap_x
+        pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev, precision=pr) for h in "rtc"]
+        pl.l3 = [E.Conv(sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"], act=E.ACT_RELU, device=dev, precision=pr) for h in "rtc"]
         pl.l4 = [t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).contiguous()
                  for h in "rtc" for t in (sd[f"conv4_{h}.weight"], sd[f"conv4_{h}.bias"])]
         return pl
@@ -263,10 +275,11 @@ class PoseRefineNet(_HipModule):
 
     def _build_plan(self, sd, dev):
         pl = type("Plan", (), {})()
-        pl.feat = _FeatPlan(sd, dev, refine=True)
+        pr = self.precision
+        pl.feat = _FeatPlan(sd, dev, refine=True, precision=pr)
         pl.l1 = E.Conv(torch.cat([sd["conv1_r.weight"], sd["conv1_t.weight"]], 0),
-                       torch.cat([sd["conv1_r.bias"], sd["conv1_t.bias"]], 0), act=E.ACT_RELU, device=dev)   # 1024 -> 512|512
-        pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev) for h in "rt"]
+                       torch.cat([sd["conv1_r.bias"], sd["conv1_t.bias"]], 0), act=E.ACT_RELU, device=dev, precision=pr)   # 1024 -> 512|512
+        pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev, precision=pr) for h in "rt"]
         pl.l3 = [t.detach().to(dev, torch.float32).contiguous()
                  for h in "rt" for t in (sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"])]
         return pl

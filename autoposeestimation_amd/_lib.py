@@ -19,6 +19,9 @@ SIGNATURES = {
     "ape_last_error": [],
     "ape_knn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ape_conv2d_nhwc_f32": [_P, _P, _P, _P, _P, _P, _P],
+    "ape_packed_weights_bf16_elems": [_I, _I],
+    "ape_pack_weights_bf16": [_P, _P, _I, _I, _P],
+    "ape_conv2d_nhwc_bf16": [_P, _P, _P, _P, _P, _P, _I, _P],
     "ape_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
     "ape_adaptive_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ape_bilinear_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -47,7 +50,8 @@ class ConvParams(_c.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
-_RESTYPES = {"ape_last_error": _c.c_char_p, "ape_seg_components_workspace_bytes": _c.c_size_t}
+_RESTYPES = {"ape_last_error": _c.c_char_p, "ape_seg_components_workspace_bytes": _c.c_size_t,
+             "ape_packed_weights_bf16_elems": _c.c_long}
 
 _lib = None
 

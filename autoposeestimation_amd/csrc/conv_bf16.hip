@@ -1,0 +1,318 @@
+// Implicit-GEMM convolution / 1x1 / Linear on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate),
+// same GEMM view, NHWC fp32 activations in HBM, fused epilogue and XCD-aware tile map as conv_f32.hip, with the operands
+// handed to the MFMA as bf16 in one of two ways:
+//
+//   NSPLIT = 3  "split-bf16": x = x_hi + x_lo with x_hi = bf16(x), x_lo = bf16(x - x_hi) (16 significand bits), and
+//               acc += a_lo*b_hi + a_hi*b_lo + a_hi*b_hi   -- 3 MFMAs per product, relative error ~2^-16 per product
+//               instead of 2^-8; measured end-to-end pose error vs the fp32 reference ~1e-5 (tolerance 1e-4), at an
+//               effective dense peak of 2.5 PF / 3 = 833 TFLOP/s versus 157 TFLOP/s for the exact-fp32 MFMA.
+//   NSPLIT = 1  plain bf16 operands (segmentation only: its consumer is an arg-max).
+//
+// Activations stay fp32 in HBM (the pooling / resize / gather kernels are shared with the fp32 path); the A tile is split
+// into hi/lo planes on the fly while it is staged  HBM -> registers -> LDS  (3 VALU ops per element, hidden under the
+// 24 MFMAs of a k-tile).  Weights are split once at load time (ape_pack_weights_bf16) into two bf16 planes [Cout][Kp].
+//
+// LDS: four bf16 tiles (A_hi, A_lo, B_hi, B_lo), K-contiguous rows of 32 elements padded to 40 (80 B = 5 x 16-B slots, odd
+// => the 16 rows of a ds_read_b128 lane group hit 16 distinct bank slots); one ds_read_b128 is exactly one MFMA fragment
+// (lane l: row l&31, k = 8*(l>>5) + 0..7 of the 16-deep k-step).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LD = BK + 8;  // bf16 elements per LDS row (80 B)
+constexpr int NT = 256;
+
+struct ConvArgsB {
+    const float* x;
+    const __bf16* w;   // plane 0 (hi) at w, plane 1 (lo) at w + plane_stride
+    const float* bias;
+    const float* res;
+    float* y;
+    ape_conv_params p;
+    int M, K, Kp, m_tiles, n_tiles;
+    long plane_stride;
+};
+
+__device__ __forceinline__ float activate(float v, int act, float alpha)
+{
+    switch (act) {
+        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
+        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo)
+{
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+template <int NSPLIT, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
+{
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int NPL = NSPLIT == 3 ? 2 : 1;           // operand planes (hi [, lo])
+    constexpr int A_ROWS = BM / 64;                    // rows per thread (tid>>2 covers 64 rows)
+    constexpr int B_ITEMS = BN * 4 / NT;               // 16-B chunks per thread per plane (2 / 1)
+    static_assert(B_ITEMS >= 1, "BN");
+
+    __shared__ __attribute__((aligned(16))) __bf16 As[NPL][BM * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[NPL][BN * LD];
+
+    const ape_conv_params& p = a.p;
+    const int nwg = a.m_tiles * a.n_tiles;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const int n_tile = logical % a.n_tiles;
+    const int m_tile = logical / a.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int k8 = tid & 3;      // which 8-element chunk of the 32-deep k-tile
+    const int srow = tid >> 2;   // 0..63
+    const int HoWo = p.Ho * p.Wo;
+    int a_base[A_ROWS], a_iy0[A_ROWS], a_ix0[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int m = m0 + srow + 64 * i;
+        if (m < a.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_base[i] = b * p.H;
+        } else {
+            a_iy0[i] = -(1 << 28);
+            a_ix0[i] = 0;
+            a_base[i] = 0;
+        }
+    }
+
+    float4 areg[A_ROWS][2];
+    uint4 breg[NPL][B_ITEMS];
+    // Fast path (every layer but the 4-channel stem / xyz inputs): Cin is a multiple of BK, so a whole k-tile lies inside
+    // ONE filter tap and (ky, kx, ci0) advance incrementally in scalar registers -- no per-lane integer division.
+    const bool tap_uniform = (p.Cin % BK) == 0;
+    int t_ci0 = 0, t_kx = 0, t_ky = 0;      // tap state of the NEXT tile to load (wave-uniform)
+    auto load_tiles = [&](int kt) {
+        if (tap_uniform) {
+            const int dy = t_ky * p.dil, dx = t_kx * p.dil;
+            const bool kin = kt * BK < a.K;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+                const bool ok = kin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = (unsigned)(((a_base[i] + iy) * p.W + ix) * p.ldx + p.xoff + t_ci0 + k8 * 8);
+                const float4* src = reinterpret_cast<const float4*>(a.x + off);
+                areg[i][0] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                areg[i][1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            t_ci0 += BK;
+            if (t_ci0 >= p.Cin) { t_ci0 = 0; if (++t_kx == p.KW) { t_kx = 0; ++t_ky; } }
+        } else {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {   // the two float4 halves of the 8-element chunk may sit in different taps (Cin = 4)
+                const int k = kt * BK + k8 * 8 + hf * 4;
+                const bool kin = k < a.K;
+                const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                const int dy = ky * p.dil, dx = kx * p.dil;
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) {
+                    const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+                    const bool ok = kin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    const unsigned off = (unsigned)(((a_base[i] + iy) * p.W + ix) * p.ldx + p.xoff + ci);
+                    areg[i][hf] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        const int kb = kt * BK + k8 * 8;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < B_ITEMS; ++i) {
+                const int n = n0 + srow + 64 * i;
+                const bool ok = n < p.Cout && kb < a.Kp;
+                breg[pl][i] = ok ? *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + (unsigned)(n * a.Kp + kb))
+                                 : make_uint4(0u, 0u, 0u, 0u);
+            }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            bf16x4 h0, l0, h1, l1;
+            split4(areg[i][0], h0, l0);
+            split4(areg[i][1], h1, l1);
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[e] = h0[e]; hi[4 + e] = h1[e]; lo[e] = l0[e]; lo[4 + e] = l1[e]; }
+            *reinterpret_cast<bf16x8*>(&As[0][(srow + 64 * i) * LD + k8 * 8]) = hi;
+            if (NPL == 2) *reinterpret_cast<bf16x8*>(&As[NPL - 1][(srow + 64 * i) * LD + k8 * 8]) = lo;
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < B_ITEMS; ++i)
+                *reinterpret_cast<uint4*>(&Bs[pl][(srow + 64 * i) * LD + k8 * 8]) = breg[pl][i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (a.K + BK - 1) / BK;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int a_off = (wm * (BM / WM) + frow) * LD + 8 * fh;
+    const int b_off = (wn * (BN / WN) + frow) * LD + 8 * fh;
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][a_off + i * 32 * LD + s * 16]);
+                if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][a_off + i * 32 * LD + s * 16]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][b_off + j * 32 * LD + s * 16]);
+                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][b_off + j * 32 * LD + s * 16]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NPL == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + frow;
+        if (n >= p.Cout) continue;
+        const float bshared = (a.bias && p.bias_bstride == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int m = m0 + wm * (BM / WM) + i * 32 + row;
+                if (m >= a.M) continue;
+                float v = acc[i][j][e] + bshared;
+                if (a.bias && p.bias_bstride != 0) v += a.bias[(size_t)(m / HoWo) * p.bias_bstride + n];
+                if (a.res) v += a.res[(size_t)m * p.ldr + p.roff + n];
+                a.y[(size_t)m * p.ldy + p.yoff + n] = activate(v, p.act, p.alpha);
+            }
+        }
+    }
+}
+
+template <int NSPLIT, int BN, int WM, int WN>
+void launch(const ConvArgsB& a, hipStream_t st)
+{
+    hipLaunchKernelGGL((conv_bf16_kernel<NSPLIT, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles), dim3(NT), 0, st, a);
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int K, int Kp)
+{
+    const long total = (long)cout * Kp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % Kp;
+        const long n = i / Kp;
+        const float v = k < K ? w[n * K + k] : 0.f;
+        const __bf16 hi = (__bf16)v;
+        out[i] = hi;
+        out[total + i] = (__bf16)(v - (float)hi);
+    }
+}
+
+}  // namespace
+
+extern "C" long ape_packed_weights_bf16_elems(int cout, int K)
+{
+    const long Kp = (K + 7) / 8 * 8;
+    return 2L * cout * Kp;
+}
+
+/* w[cout][K] f32 -> out: bf16 hi plane [cout][Kp] followed by lo plane [cout][Kp], Kp = K rounded up to 8, zero padded */
+extern "C" int ape_pack_weights_bf16(const float* w, void* out, int cout, int K, void* stream)
+{
+    if (!w || !out || cout < 1 || K < 1) return APE_EINVAL;
+    const int Kp = (K + 7) / 8 * 8;
+    const long total = (long)cout * Kp;
+    long g = (total + 255) / 256;
+    g = g > 4096 ? 4096 : g;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, cout, K, Kp);
+    return ape::check_launch("ape_pack_weights_bf16");
+}
+
+extern "C" int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                                    const ape_conv_params* params, int nsplit, void* stream)
+{
+    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3)) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (p.B < 0 || p.H < 1 || p.W < 1 || p.Cin < 4 || p.Cout < 1 || p.KH < 1 || p.KW < 1 || p.stride < 1 || p.dil < 1 ||
+        p.pad < 0 || p.Ho < 1 || p.Wo < 1)
+        return APE_EINVAL;
+    if (p.Cin % 4 || p.ldx % 4 || p.xoff % 4 || p.xoff + p.Cin > p.ldx || p.yoff + p.Cout > p.ldy) return APE_EINVAL;
+    if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return APE_EINVAL;
+    const int ho = (p.H + 2 * p.pad - p.dil * (p.KH - 1) - 1) / p.stride + 1;
+    const int wo = (p.W + 2 * p.pad - p.dil * (p.KW - 1) - 1) / p.stride + 1;
+    if (ho != p.Ho || wo != p.Wo) return APE_EINVAL;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    if (M == 0) return APE_OK;
+    // the kernel addresses x and w with 32-bit ELEMENT offsets
+    if (M > (1L << 30) || (long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * ((p.KH * p.KW * p.Cin + 7) / 8 * 8) >= (1L << 31))
+        return APE_EINVAL;
+
+    ConvArgsB a;
+    a.x = x; a.w = (const __bf16*)w_packed; a.bias = bias; a.res = residual; a.y = y; a.p = p;
+    a.M = (int)M;
+    a.K = p.KH * p.KW * p.Cin;
+    a.Kp = (a.K + 7) / 8 * 8;
+    a.plane_stride = (long)p.Cout * a.Kp;
+    a.m_tiles = ape::ceil_div(M, BM);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.Cout > 64) {
+        a.n_tiles = ape::ceil_div(p.Cout, 128);
+        if (nsplit == 3) launch<3, 128, 2, 2>(a, st); else launch<1, 128, 2, 2>(a, st);
+    } else {
+        a.n_tiles = 1;
+        if (nsplit == 3) launch<3, 64, 4, 1>(a, st); else launch<1, 64, 4, 1>(a, st);
+    }
+    return ape::check_launch("ape_conv2d_nhwc_bf16");
+}

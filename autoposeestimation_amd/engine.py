@@ -36,6 +36,12 @@ class LaunchProfile:
 
 PROFILE = None   # set to a LaunchProfile() to time conv launches
 
+# operand precision of the dense contractions (accumulation is always fp32):
+#   "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                 157 TFLOP/s peak
+#   "bf16x3" split-bf16, 3 products per term, ~2^-16 operand error      833 TFLOP/s effective peak
+#   "bf16"   plain bf16 operands (2^-8)                                 2.5 PFLOP/s peak
+PRECISIONS = ("f32", "bf16x3", "bf16")
+
 
 def pack_conv_weight(w, device):
     """[Cout,Cin,KH,KW] | [Cout,Cin,1] | [Cout,Cin]  ->  contiguous f32 [Cout,KH,KW,Cin4] on `device`."""
@@ -54,11 +60,23 @@ def pack_conv_weight(w, device):
 class Conv:
     """One conv / 1x1 / Linear layer bound to ape_conv2d_nhwc_f32."""
 
-    def __init__(self, weight, bias=None, stride=1, pad=0, dil=1, act=ACT_NONE, alpha=0.0, device="cuda"):
+    def __init__(self, weight, bias=None, stride=1, pad=0, dil=1, act=ACT_NONE, alpha=0.0, device="cuda", precision="f32"):
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
         self.w = pack_conv_weight(weight, device)
         self.cout, self.kh, self.kw, self.cin = self.w.shape
         self.cin_real = weight.shape[1]
-        self.variant = "conv_f32_kernel<%s>" % ("128,2,2" if self.cout > 64 else "64,4,1" if self.cout > 32 else "32,4,1")
+        self.precision = precision
+        self.nsplit = {"f32": 0, "bf16x3": 3, "bf16": 1}[precision]
+        if self.nsplit:
+            k = self.kh * self.kw * self.cin
+            n = _lib.lib().ape_packed_weights_bf16_elems(self.cout, k)
+            self.wp = torch.empty(n, dtype=torch.bfloat16, device=device)
+            _lib.check(_lib.lib().ape_pack_weights_bf16(_lib.dptr(self.w), _lib.dptr(self.wp), self.cout, k, _st()),
+                       "ape_pack_weights_bf16")
+            self.variant = "conv_bf16_kernel<%d,%s>" % (self.nsplit, "128,2,2" if self.cout > 64 else "64,4,1")
+        else:
+            self.variant = "conv_f32_kernel<%s>" % ("128,2,2" if self.cout > 64 else "64,4,1" if self.cout > 32 else "32,4,1")
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.stride, self.pad, self.dil, self.act, self.alpha = stride, pad, dil, act, float(alpha)
 
@@ -86,9 +104,15 @@ class Conv:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = _lib.lib().ape_conv2d_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(self.w), _lib.dptr(bias),
-                                            _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p), _st())
-        _lib.check(rc, "ape_conv2d_nhwc_f32")
+        if self.nsplit:
+            rc = _lib.lib().ape_conv2d_nhwc_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
+                                                 _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
+                                                 self.nsplit, _st())
+            _lib.check(rc, "ape_conv2d_nhwc_bf16")
+        else:
+            rc = _lib.lib().ape_conv2d_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(self.w), _lib.dptr(bias),
+                                                _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p), _st())
+            _lib.check(rc, "ape_conv2d_nhwc_f32")
         if prof is not None:
             e1.record()
             prof.records.append((self.variant, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))

@@ -35,7 +35,8 @@ class PsPNetSegmentor(PSPNet):
     def _build_plan(self, sd, dev):
         pl = super()._build_plan(sd, dev)
         # only the first `classes` rows of the final 1x1 conv are ever needed
-        self._final_cls = E.Conv(sd["final.0.weight"][:self.classes], sd["final.0.bias"][:self.classes], device=dev)
+        self._final_cls = E.Conv(sd["final.0.weight"][:self.classes], sd["final.0.bias"][:self.classes], device=dev,
+                                 precision=self.precision)
         return pl
 
     def logits_nhwc(self, x4):

@@ -29,6 +29,7 @@ H, W, N_POINTS = 480, 640, 1000
 # algorithmic work per frame: PSPNet-r18 segmentation 275.15 GF + crop encoder 22.95 + PointNet/heads 7.96 + 2 x 1.48
 GFLOP_PER_FRAME = 309.0
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA, dense"
 
 
 def make_frames(batch, rank):
@@ -102,6 +103,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seg-precision", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--pose-precision", default="f32", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -127,6 +130,9 @@ def main():
     seg, est, ref, seg_sd, est_sd, ref_sd = build_models(device, fit_frames)
     rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device)        # inputs resident in HBM
     depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device)
+    seg.set_precision(args.seg_precision)
+    est.set_precision(args.pose_precision)
+    ref.set_precision(args.pose_precision)
     pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat")
     from autoposeestimation_amd.sharding import gather_results
 
@@ -180,8 +186,11 @@ def main():
         if dom:
             d = summ[dom]
             ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            # algorithmic flop (2*M*N*K of the convolution) against the peak of the instruction the kernel issues; a
+            # split-bf16 kernel issues 3 bf16 MFMAs per algorithmic product, so its ceiling is the bf16 peak / 3
+            peak = PEAK_F32_MFMA_TFLOPS if "f32" in dom else PEAK_BF16_MFMA_TFLOPS / (3.0 if "<3," in dom else 1.0)
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3),
                         "share_of_step_time": round(d["ms"] * 1e-3 / dt, 3)}
@@ -190,7 +199,9 @@ def main():
             "metric": "RGB-D frames/sec (seg+DenseFusion+2-refine), 640x480 N=1000",
             "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "seg:%s pose:%s (fp32 accumulate, fp32 activations)" % (args.seg_precision, args.pose_precision),
+            "data": "synthetic",
             "config": {"workload": "configs[2]: end-to-end PSPNet-resnet18 segmentation -> mask/CCL/bbox -> 160x160 crop -> "
                                    "PoseNet(N=1000) -> 2x PoseRefineNet, batch=%d 640x480 frames per GPU" % args.batch,
                        "frames_per_gpu_per_step": args.batch, "objects_found_last_step": n_found,

@@ -68,6 +68,16 @@ typedef struct ape_conv_params {
 int ape_conv2d_nhwc_f32(const float* x, const float* w, const float* bias, const float* residual, float* y,
                         const ape_conv_params* params_host, void* stream);
 
+/* ---- the same contraction on the bf16 matrix cores (fp32 accumulate, fp32 activations in HBM) ------------------
+ * nsplit = 3: split-bf16 operands (x = hi + lo, three MFMA products per term, ~2^-16 relative operand error);
+ * nsplit = 1: plain bf16 operands.  Same params / fused epilogue / layouts as ape_conv2d_nhwc_f32, except that the
+ * weights are the packed planes produced by ape_pack_weights_bf16 from w[Cout][KH*KW*Cin] f32:
+ * hi plane [Cout][Kp] bf16 then lo plane [Cout][Kp], Kp = K rounded up to 8 (ape_packed_weights_bf16_elems elements). */
+long ape_packed_weights_bf16_elems(int cout, int K);
+int ape_pack_weights_bf16(const float* w, void* out, int cout, int K, void* stream);
+int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                         const ape_conv_params* params_host, int nsplit, void* stream);
+
 /* ---- HBM-bound glue of the PSPNet / PointNet graphs (NHWC f32, C multiple of 4) -----------------------------
  * nn.MaxPool2d(3, 2, 1)                      DenseFusion/lib/extractors.py:85,117.   y[B][Ho][Wo][C], Ho=(H-1)/2+1 */
 int ape_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);

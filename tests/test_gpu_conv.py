@@ -1,0 +1,80 @@
+"""Numerics of the implicit-GEMM conv kernels (exact-fp32 MFMA, split-bf16 x3, plain bf16) against a plain PyTorch fp32
+CPU reference of the same op (F.conv2d + bias + residual + activation), across the geometries the PSPNet / PointNet
+graphs use plus ragged edge cases.  Tolerances are relative to the output's max magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-6, "bf16x3": 5e-5, "bf16": 2e-2}
+
+CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 40, 40, 3, 64, 7, 2, 3, 1),      # stem (Cin padded to 4, K = 196: k-tail)
+    (2, 20, 20, 64, 64, 3, 1, 1, 1),
+    (1, 21, 19, 64, 128, 3, 2, 1, 1),    # odd sizes, stride 2
+    (1, 20, 20, 128, 256, 3, 1, 2, 2),   # dilation 2
+    (1, 12, 12, 256, 512, 3, 1, 4, 4),   # dilation 4
+    (1, 9, 11, 64, 128, 1, 2, 0, 1),     # 1x1 stride-2 downsample
+    (3, 5, 5, 512, 1024, 1, 1, 0, 1),
+    (1, 1000, 1, 32, 64, 1, 1, 0, 1),    # PointNet 1x1
+    (2, 333, 1, 384, 1920, 1, 1, 0, 1),  # ragged M, Cout not a tile multiple
+    (1, 17, 23, 64, 33, 3, 1, 1, 1),     # Cout = 33
+    (1, 8, 8, 8, 13, 1, 1, 0, 1),        # tiny Cout (segmentor final conv)
+    (5, 1, 1, 1024, 512, 1, 1, 0, 1),    # Linear on B rows
+]
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_matches_torch(case, precision):
+    from autoposeestimation_amd import engine as E
+    b, h, w, cin, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(b, cin, h, w, generator=g) * 3
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    want = F.conv2d(x, wt, bias, stride, pad, dil)
+    res = torch.randn(want.shape, generator=g)
+    want = F.relu(want + res)
+    conv = E.Conv(wt, bias, stride, pad, dil, E.ACT_RELU, device="cuda", precision=precision)
+    cin4 = (cin + 3) // 4 * 4
+    x4 = torch.zeros(b, h, w, cin4, device="cuda")
+    x4[..., :cin] = x.permute(0, 2, 3, 1).cuda()
+    got = conv(x4, residual=res.permute(0, 2, 3, 1).contiguous().cuda()).permute(0, 3, 1, 2).cpu()
+    err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+    assert err <= TOL[precision], (case, precision, err)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_conv_channel_slices_per_image_bias_prelu(precision):
+    """(ld, offset) slices on input/output/residual, per-image bias, PReLU and sigmoid epilogues."""
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(3)
+    b, n = 3, 130
+    buf = torch.randn(b, n, 1, 96, generator=g)
+    wt = torch.randn(40, 32, generator=g) / 6
+    bias_img = torch.randn(b, 48, generator=g)            # bias_bstride = 48 > Cout
+    res = torch.randn(b, n, 1, 64, generator=g)
+    want = torch.einsum("bnc,oc->bno", buf[:, :, 0, 32:64], wt) + bias_img[:, None, :40] + res[:, :, 0, 8:48]
+    want = torch.where(want > 0, want, 0.1 * want)
+    out = torch.full((b, n, 1, 80), 7.0, device="cuda")
+    conv = E.Conv(wt, None, act=E.ACT_PRELU, alpha=0.1, device="cuda", precision=precision)
+    conv(buf.cuda(), out=out, xoff=32, yoff=16, residual=res.cuda(), roff=8, bias=bias_img.cuda(), bias_bstride=48)
+    got = out.cpu()
+    assert torch.all(got[..., :16] == 7.0) and torch.all(got[..., 56:] == 7.0)          # untouched outside the slice
+    err = (got[:, :, 0, 16:56] - want).abs().max().item() / want.abs().max().item()
+    assert err <= TOL[precision]
+    sig = E.Conv(wt, None, act=E.ACT_SIGMOID, device="cuda", precision=precision)(buf.cuda(), xoff=32).cpu()
+    want_s = torch.sigmoid(torch.einsum("bnc,oc->bno", buf[:, :, 0, 32:64], wt))
+    assert (sig[:, :, 0] - want_s).abs().max().item() <= max(TOL[precision], 2e-6) * 4
+
+
+def test_conv_rejects_bad_geometry():
+    from autoposeestimation_amd import engine as E
+    from autoposeestimation_amd._lib import ApeError
+    conv = E.Conv(torch.randn(8, 6, 3, 3), None, 1, 1, 1, device="cuda")
+    with pytest.raises(ApeError):
+        conv(torch.zeros(1, 8, 8, 6, device="cuda"))         # ld not a multiple of 4
+    with pytest.raises(ValueError):
+        conv(torch.zeros(1, 8, 8, 8, device="cuda"), out=torch.zeros(1, 7, 8, 8, device="cuda"))

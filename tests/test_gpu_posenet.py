@@ -136,3 +136,31 @@ def test_cpu_tensors_are_refused():
     ref.load_state_dict(S.refiner_state_dict(12, 0))
     with pytest.raises(RuntimeError):
         ref(torch.zeros(1, 1000, 3), torch.zeros(1, 32, 1000), torch.zeros(1, 1, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("precision", ["bf16x3"])
+@pytest.mark.parametrize("case", CASES)
+def test_split_bf16_pose_within_tolerance(case, precision):
+    """The fast path (split-bf16 operands on the bf16 matrix cores) must still give R,t within 1e-4 of the reference."""
+    from autoposeestimation_amd import engine as E
+    g = golden(case)
+    if float(g["c_margin"]) <= 1e-4:
+        pytest.skip("arg-max margin of this golden is below the operand error; winner not comparable")
+    n, num_obj, obj = int(g["n"]), int(g["num_obj"]), int(g["obj"])
+    est, refiner = _models(num_obj, n)
+    est.set_precision(precision)
+    refiner.set_precision(precision)
+    img = torch.from_numpy(g["img"]).unsqueeze(0).cuda()
+    pts = torch.from_numpy(g["points"]).unsqueeze(0).cuda()
+    ch = torch.from_numpy(g["choose"]).view(1, 1, -1).cuda()
+    idx = torch.tensor([[obj]]).cuda()
+    pr, pt, pc, emb = est(img, pts, ch, idx)
+    assert int(pc.view(-1).argmax()) == int(np.argmax(g["pred_c"].reshape(-1)))
+    np.testing.assert_allclose(pc.cpu().numpy(), g["pred_c"], atol=1e-4)
+    pts4 = E.pad3to4(pts)
+    pose, _, newp = E.pose_select(torch.cat([pr, pt, pc], 2).contiguous(), pts4)
+    for _ in range(2):
+        out = refiner.forward_batch(newp, emb.transpose(1, 2).contiguous(), idx.view(1))
+    E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+    np.testing.assert_allclose(pose[0, :4].cpu().numpy(), g["fin_r"], atol=1e-4)
+    np.testing.assert_allclose(pose[0, 4:].cpu().numpy(), g["fin_t"], atol=1e-4)

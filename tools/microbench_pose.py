@@ -8,8 +8,9 @@ from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNe
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 HC = int(sys.argv[2]) if len(sys.argv) > 2 else 160
 N = 1000
-est = PoseNet(N, 12); est.load_state_dict(S.posenet_state_dict(12, 0)); est = est.cuda().eval()
-ref = PoseRefineNet(N, 12); ref.load_state_dict(S.refiner_state_dict(12, 0)); ref = ref.cuda().eval()
+PREC = sys.argv[3] if len(sys.argv) > 3 else "f32"
+est = PoseNet(N, 12); est.load_state_dict(S.posenet_state_dict(12, 0)); est = est.cuda().eval().set_precision(PREC)
+ref = PoseRefineNet(N, 12); ref.load_state_dict(S.refiner_state_dict(12, 0)); ref = ref.cuda().eval().set_precision(PREC)
 torch.manual_seed(0)
 img4 = torch.rand(B, HC, HC, 4, device="cuda") * 1000; img4[..., 3] = 0
 pts4 = torch.rand(B, N, 4, device="cuda"); pts4[..., 3] = 0
@@ -32,4 +33,4 @@ for _ in range(K): step()
 torch.cuda.synchronize()
 dt = (time.time() - t) / K
 flop = B * (0.8957e6 * HC * HC + 7.959e9 + 2 * 1.4814e9)
-print("B=%d crop=%d  %.2f ms/step  %.1f crops/s  %.1f TFLOP/s (reference-algorithm FLOPs)" % (B, HC, dt * 1e3, B / dt, flop / dt / 1e12))
+print(PREC, "B=%d crop=%d  %.2f ms/step  %.1f crops/s  %.1f TFLOP/s (reference-algorithm FLOPs)" % (B, HC, dt * 1e3, B / dt, flop / dt / 1e12))
