@@ -12,7 +12,7 @@
 // into hi/lo planes on the fly while it is staged  HBM -> registers -> LDS  (3 VALU ops per element, hidden under the
 // 24 MFMAs of a k-tile).  Weights are split once at load time (ape_pack_weights_bf16) into two bf16 planes [Cout][Kp].
 //
-// LDS: four bf16 tiles (A_hi, A_lo, B_hi, B_lo), K-contiguous rows of 32 elements padded to 40 (80 B = 5 x 16-B slots, odd
+// LDS: four bf16 tiles (A_hi, A_lo, B_hi, B_lo), K-contiguous rows of 64 elements padded to 72 (144 B = 9 x 16-B slots, odd
 // => the 16 rows of a ds_read_b128 lane group hit 16 distinct bank slots); one ds_read_b128 is exactly one MFMA fragment
 // (lane l: row l&31, k = 8*(l>>5) + 0..7 of the 16-deep k-step).
 #include "common.h"
@@ -24,8 +24,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LD = BK + 8;  // bf16 elements per LDS row (80 B)
+constexpr int BK = 64;
+constexpr int LD = BK + 8;  // bf16 elements per LDS row (144 B = 9 x 16-B slots, odd)
 constexpr int NT = 256;
 
 struct ConvArgsB {
@@ -62,8 +62,10 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;           // operand planes (hi [, lo])
-    constexpr int A_ROWS = BM / 64;                    // rows per thread (tid>>2 covers 64 rows)
-    constexpr int B_ITEMS = BN * 4 / NT;               // 16-B chunks per thread per plane (2 / 1)
+    constexpr int CPR = BK / 8;                        // 16-B (8 x bf16) chunks per tile row
+    constexpr int RPP = NT / CPR;                      // rows covered per pass of the 256 threads (32)
+    constexpr int A_ROWS = BM / RPP;                   // rows per thread
+    constexpr int B_ITEMS = BN / RPP;                  // 16-B chunks per thread per plane
     static_assert(B_ITEMS >= 1, "BN");
 
     __shared__ __attribute__((aligned(16))) __bf16 As[NPL][BM * LD];
@@ -82,13 +84,13 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int k8 = tid & 3;      // which 8-element chunk of the 32-deep k-tile
-    const int srow = tid >> 2;   // 0..63
+    const int k8 = tid % CPR;    // which 8-element chunk of the k-tile
+    const int srow = tid / CPR;  // 0..RPP-1
     const int HoWo = p.Ho * p.Wo;
     int a_base[A_ROWS], a_iy0[A_ROWS], a_ix0[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const int m = m0 + srow + 64 * i;
+        const int m = m0 + srow + RPP * i;
         if (m < a.M) {
             const int b = m / HoWo, rem = m - b * HoWo;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -109,9 +111,11 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
     const bool tap_uniform = (p.Cin % BK) == 0;
     int t_ci0 = 0, t_kx = 0, t_ky = 0;      // tap state of the NEXT tile to load (wave-uniform)
     auto load_tiles = [&](int kt) {
+        int t_kb = 0;
         if (tap_uniform) {
             const int dy = t_ky * p.dil, dx = t_kx * p.dil;
             const bool kin = kt * BK < a.K;
+            t_kb = (t_ky * p.KW + t_kx) * p.Cin + t_ci0;      // column of w[Cout][KH][KW][Cin] for this (tap, chunk)
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
@@ -121,8 +125,10 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
                 areg[i][0] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
                 areg[i][1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            t_ci0 += BK;
-            if (t_ci0 >= p.Cin) { t_ci0 = 0; if (++t_kx == p.KW) { t_kx = 0; ++t_ky; } }
+            // K order = channel chunk OUTER, filter tap INNER: the KH*KW consecutive k-tiles of one 32-channel chunk re-read
+            // the same 128-B lines of x shifted by one pixel / one image row, so they hit L1/L2 instead of the fabric
+            // (tap-outer order re-streams the whole Cin run of every pixel KH*KW times, 32..288 k-tiles apart).
+            if (++t_kx == p.KW) { t_kx = 0; if (++t_ky == p.KH) { t_ky = 0; t_ci0 += BK; } }
         } else {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {   // the two float4 halves of the 8-element chunk may sit in different taps (Cin = 4)
@@ -140,12 +146,12 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
                 }
             }
         }
-        const int kb = kt * BK + k8 * 8;
+        const int kb = (tap_uniform ? t_kb : kt * BK) + k8 * 8;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < B_ITEMS; ++i) {
-                const int n = n0 + srow + 64 * i;
+                const int n = n0 + srow + RPP * i;
                 const bool ok = n < p.Cout && kb < a.Kp;
                 breg[pl][i] = ok ? *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + (unsigned)(n * a.Kp + kb))
                                  : make_uint4(0u, 0u, 0u, 0u);
@@ -160,14 +166,14 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
             bf16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { hi[e] = h0[e]; hi[4 + e] = h1[e]; lo[e] = l0[e]; lo[4 + e] = l1[e]; }
-            *reinterpret_cast<bf16x8*>(&As[0][(srow + 64 * i) * LD + k8 * 8]) = hi;
-            if (NPL == 2) *reinterpret_cast<bf16x8*>(&As[NPL - 1][(srow + 64 * i) * LD + k8 * 8]) = lo;
+            *reinterpret_cast<bf16x8*>(&As[0][(srow + RPP * i) * LD + k8 * 8]) = hi;
+            if (NPL == 2) *reinterpret_cast<bf16x8*>(&As[NPL - 1][(srow + RPP * i) * LD + k8 * 8]) = lo;
         }
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < B_ITEMS; ++i)
-                *reinterpret_cast<uint4*>(&Bs[pl][(srow + 64 * i) * LD + k8 * 8]) = breg[pl][i];
+                *reinterpret_cast<uint4*>(&Bs[pl][(srow + RPP * i) * LD + k8 * 8]) = breg[pl][i];
     };
 
     f32x16 acc[TM][TN];
