@@ -33,6 +33,9 @@ SIGNATURES = {
     "ape_pose_select_f32": [_P, _P, _P, _P, _P, _I, _I, _P],
     "ape_pose_compose_f64": [_P, _P, _I, _P, _I, _I, _P],
     "ape_pose_recentre_f32": [_P, _P, _P, _I, _I, _P],
+    "ape_adds_dis_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "ape_adds_select_f32": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P],
+    "ape_recentre_qt_f32": [_P, _P, _P, _I, _P],
     "ape_seg_argmax_f32": [_P, _I, _I, _P, _P, _c.c_long, _I, _P],
     "ape_seg_components_workspace_bytes": [_I, _I, _I, _I],
     "ape_seg_components": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],

@@ -293,3 +293,38 @@ def backproject(depth, objects, choose, intr, depth_scale):
                                         float(intr["ppy"]), float(depth_scale), _st())
     _lib.check(rc, "ape_backproject_f32")
     return pts
+
+
+# ---- ADD / ADD-S ------------------------------------------------------------------------------------------------------
+def adds_dis(pred_r, pred_t, points, model, target, symmetric, want_pred=False, want_std=True):
+    """pred_r[N,4], pred_t[N,3], points[N,3]|None, model[M,3], target[M,3] -> dis[N], std[N]|None, pred[N,M,3]|None"""
+    n, m = pred_r.shape[0], model.shape[0]
+    dev = pred_r.device
+    dis = torch.empty(n, dtype=torch.float32, device=dev)
+    std = torch.empty(n, dtype=torch.float32, device=dev) if want_std else None
+    pred = torch.empty(n, m, 3, dtype=torch.float32, device=dev) if want_pred else None
+    rc = _lib.lib().ape_adds_dis_f32(_lib.dptr(pred_r, torch.float32), _lib.dptr(pred_t, torch.float32), _lib.dptr(points),
+                                     _lib.dptr(model, torch.float32), _lib.dptr(target, torch.float32), n, m,
+                                     int(bool(symmetric)), _lib.dptr(pred), _lib.dptr(dis), _lib.dptr(std), _st())
+    _lib.check(rc, "ape_adds_dis_f32")
+    return dis, std, pred
+
+
+def adds_select(dis, std, pred_c, pred_r, pred_t, points, w):
+    """-> out9 (loss, dis[which], q[4], t[3]) f32 on device, which i32[1]"""
+    out = torch.empty(9, dtype=torch.float32, device=dis.device)
+    which = torch.empty(1, dtype=torch.int32, device=dis.device)
+    rc = _lib.lib().ape_adds_select_f32(_lib.dptr(dis), _lib.dptr(std), _lib.dptr(pred_c, torch.float32), _lib.dptr(pred_r),
+                                        _lib.dptr(pred_t), _lib.dptr(points), dis.shape[0], float(w), _lib.dptr(out),
+                                        _lib.dptr(which), _st())
+    _lib.check(rc, "ape_adds_select_f32")
+    return out, which
+
+
+def recentre_qt(pts, qt7):
+    """pts[n,3], qt7 (device f32 [7]: unnormalised quaternion + translation) -> (pts - t) . R(q)"""
+    out = torch.empty_like(pts)
+    rc = _lib.lib().ape_recentre_qt_f32(_lib.dptr(pts, torch.float32), _lib.dptr(qt7, torch.float32), _lib.dptr(out),
+                                        pts.shape[0], _st())
+    _lib.check(rc, "ape_recentre_qt_f32")
+    return out

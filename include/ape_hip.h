@@ -116,6 +116,23 @@ int ape_pose_compose_f64(double* pose, const float* ref_r, int ldr, const float*
 /* cloud re-centring of the iterative loop    DenseFusion/tools/eval_ycb.py:205-210. */
 int ape_pose_recentre_f32(const float* points4, const double* pose, float* new_points4, int B, int n, void* stream);
 
+/* ---- ADD / ADD-S and the DenseFusion loss forward -------------------------------------------------------------
+ * loss_calculation               DenseFusion/lib/loss.py:12-73, lib/loss_refiner.py:12-64, tools/eval_linemod.py:118-130.
+ * pred[n][m] = R(pred_r[n]/|pred_r[n]|) . model[m] + pred_t[n] (+ points[n] when points != NULL, loss.py:38);
+ * dis[n] = mean_m |pred[n][m] - target[m']|, m' = m, or for symmetric objects the nearest target with the k-NN
+ * kernel's float32 arithmetic and lowest-index tie rule (loss.py:42-47); stdv[n] = unbiased std of those norms (may be
+ * NULL); pred_out[N][M][3] is written only when non-NULL.  pred_r[N][4], pred_t[N][3], points[N][3], model/target[M][3]. */
+int ape_adds_dis_f32(const float* pred_r, const float* pred_t, const float* points, const float* model,
+                     const float* target, int N, int M, int symmetric, float* pred_out, float* dis, float* stdv,
+                     void* stream);
+/* loss = mean((dis + 2 std) c - w log c), which = argmax c (first), out9 = (loss, dis[which], pred_r[which][0..3],
+ * pred_t[which] + points[which])   loss.py:50-59 */
+int ape_adds_select_f32(const float* dis, const float* stdv, const float* pred_c, const float* pred_r,
+                        const float* pred_t, const float* points, int N, float w, float* out9, int* which,
+                        void* stream);
+/* out[i] = (pts[i] - t) . ori_base(q/|q|), qt7 = (q[4], t[3]) on the device   loss.py:61-69, loss_refiner.py:51-60 */
+int ape_recentre_qt_f32(const float* pts, const float* qt7, float* out, int n, void* stream);
+
 /* ---- segmentation post-processing, crop / point selection (byte and index work, bit-exact) ----------------------
  * softmax(+softmax) / argmax                 pipeline/utils.py:429-435 (predict's softmax activation, create_labels.py:23,
  * then F.softmax again, then torch.argmax).  logits[npix][ld] f32 (first C channels) -> label[npix] u8,
