@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libape_hip.so")
 
 _c = ctypes
-_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+_P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
 
 # symbol -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/ape_hip.h one to one
 SIGNATURES = {
@@ -42,6 +42,18 @@ SIGNATURES = {
     "ape_choose_points": [_P, _P, _P, _I, _I, _I, _I, _c.c_uint, _P, _c.c_long, _P, _P, _P],
     "ape_backproject_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
     "ape_preprocess_u8_nhwc4": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "ape_pc_workspace_bytes": [_I],
+    "ape_surface_points_f64": [_P, _P, _I, _I, _D, _D, _D, _D, _P, _P, _P, _P, _c.c_size_t, _P],
+    "ape_transform_points_f64": [_P, _P, _I, _P, _P],
+    "ape_voxel_down_sample_f64": [_P, _I, _D, _P, _P, _P, _c.c_size_t, _P],
+    "ape_grid_build_f64": [_P, _I, _D, _P, _P, _P, _P, _P, _c.c_size_t, _P],
+    "ape_grid_radius_count_f64": [_P, _P, _P, _P, _I, _D, _P, _I, _D, _P, _P],
+    "ape_grid_nn1_f64": [_P, _P, _P, _P, _I, _D, _P, _I, _D, _P, _P, _P],
+    "ape_grid_normals_f64": [_P, _P, _P, _P, _I, _D, _P, _I, _D, _I, _P, _P],
+    "ape_knn_mean_dist_f64": [_P, _I, _I, _P, _P],
+    "ape_icp_sums_f64": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _c.c_size_t, _P],
+    "ape_mahalanobis_f64": [_P, _I, _P, _P, _P],
+    "ape_select_points_f64": [_P, _P, _I, _P, _P, _P, _P, _c.c_size_t, _P],
 }
 
 
@@ -54,7 +66,7 @@ class ConvParams(_c.Structure):
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 _RESTYPES = {"ape_last_error": _c.c_char_p, "ape_seg_components_workspace_bytes": _c.c_size_t,
-             "ape_packed_weights_bf16_elems": _c.c_long}
+             "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t}
 
 _lib = None
 

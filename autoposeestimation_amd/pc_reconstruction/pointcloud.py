@@ -1,0 +1,370 @@
+"""Device-resident stand-in for the slice of open3d 0.9 the pose-label path uses ("pc_reconstruction.
+open3d_utils": duck-typed PointCloud surface + registration_icp), backed by the float64 kernels of
+csrc/pointcloud.hip.  open3d is a third-party dependency absent from the reference tree, so its exact arithmetic is
+UNPINNED; semantics follow open3d 0.9's documented behaviour and are checked against a
+scipy/numpy restatement (oracle/pointcloud_oracle.py) plus recover-a-known-transform self-consistency tests.
+
+Points live on the GPU as a contiguous float64 [n,3] tensor; `np.array(pcd.points)` / `np.asarray(pcd.points)` copies to
+the host like open3d's Vector3dVector does; assigning `pcd.points = array` uploads.  No CPU fallback."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from autoposeestimation_amd import _lib
+
+_D = torch.float64
+
+
+def _st():
+    return _lib.stream_ptr()
+
+
+def _ws(n, device):
+    nbytes = _lib.lib().ape_pc_workspace_bytes(int(max(n, 1)))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def _host16(T):
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(16))
+    return T, T.ctypes.data_as(ctypes.c_void_p)
+
+
+class _Points:
+    """What `pcd.points` returns: converts to numpy on demand, keeps the device tensor for kernels."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.t.cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.t.shape[0]
+
+
+class PointCloud:
+    def __init__(self, points=None, device="cuda"):
+        self.device = torch.device(device)
+        self._p = torch.zeros(0, 3, dtype=_D, device=self.device)
+        self._n = None   # normals
+        if points is not None:
+            self.points = points
+
+    # -- open3d attribute surface ----------------------------------------------------------------------------------
+    @property
+    def points(self):
+        return _Points(self._p)
+
+    @points.setter
+    def points(self, value):
+        if isinstance(value, _Points):
+            value = value.t
+        if torch.is_tensor(value):
+            t = value.to(device=self.device, dtype=_D)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(value, dtype=np.float64))).to(self.device)
+        self._p = t.reshape(-1, 3).contiguous()
+        self._n = None
+
+    @property
+    def normals(self):
+        return None if self._n is None else _Points(self._n)
+
+    def has_normals(self):
+        return self._n is not None
+
+    def __len__(self):
+        return self._p.shape[0]
+
+    def clone(self):
+        c = PointCloud(device=self.device)
+        c._p = self._p.clone()
+        c._n = None if self._n is None else self._n.clone()
+        return c
+
+    __deepcopy__ = lambda self, memo: self.clone()   # noqa: E731  (copy.deepcopy(target), open3d_utils.py:72)
+
+    # -- moments ---------------------------------------------------------------------------------------------------
+    def _moments(self):
+        n = len(self)
+        out = torch.empty(9, dtype=_D, device=self.device)
+        ws = torch.empty(512 * 29 * 8, dtype=torch.uint8, device=self.device)
+        rc = _lib.lib().ape_icp_sums_f64(2, _lib.dptr(self._p, _D), None, None, None, None, n, _lib.dptr(out), _lib.dptr(ws),
+                                         ws.numel(), _st())
+        _lib.check(rc, "ape_icp_sums_f64")
+        m = out.cpu().numpy()
+        mean = m[:3] / n
+        s2 = np.array([[m[3], m[4], m[5]], [m[4], m[6], m[7]], [m[5], m[7], m[8]]]) / n
+        return mean, s2 - np.outer(mean, mean)      # open3d ComputeMeanAndCovariance: population covariance
+
+    def get_center(self):
+        if len(self) == 0:
+            return np.zeros(3)
+        return self._moments()[0]
+
+    def compute_mahalanobis_distance(self):
+        n = len(self)
+        if n == 0:
+            return np.zeros(0)
+        mean, cov = self._moments()
+        mc = np.ascontiguousarray(np.concatenate([mean, np.linalg.inv(cov).reshape(9)]))
+        out = torch.empty(n, dtype=_D, device=self.device)
+        rc = _lib.lib().ape_mahalanobis_f64(_lib.dptr(self._p, _D), n, mc.ctypes.data_as(ctypes.c_void_p), _lib.dptr(out), _st())
+        _lib.check(rc, "ape_mahalanobis_f64")
+        return out.cpu().numpy()
+
+    # -- rigid motions (in place, return self like open3d) ------------------------------------------------------------
+    def transform(self, T):
+        if len(self):
+            T, ptr = _host16(T)
+            rc = _lib.lib().ape_transform_points_f64(_lib.dptr(self._p, _D), _lib.dptr(self._n), len(self), ptr, _st())
+            _lib.check(rc, "ape_transform_points_f64")
+        return self
+
+    def translate(self, translation, relative=True):
+        T = np.eye(4)
+        t = np.asarray(translation, dtype=np.float64)
+        T[:3, 3] = t if relative else t - self.get_center()
+        return self.transform(T)
+
+    def rotate(self, R, center=True):
+        T = np.eye(4)
+        T[:3, :3] = np.asarray(R, dtype=np.float64)
+        if center:
+            c = self.get_center()
+            T[:3, 3] = c - T[:3, :3] @ c
+        return self.transform(T)
+
+    # -- filters ---------------------------------------------------------------------------------------------------
+    def voxel_down_sample(self, voxel_size):
+        n = len(self)
+        out = PointCloud(device=self.device)
+        if n == 0:
+            return out
+        buf = torch.empty(n, 3, dtype=_D, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = _ws(n, self.device)
+        rc = _lib.lib().ape_voxel_down_sample_f64(_lib.dptr(self._p, _D), n, float(voxel_size), _lib.dptr(buf), _lib.dptr(cnt),
+                                                  _lib.dptr(ws), ws.numel(), _st())
+        _lib.check(rc, "ape_voxel_down_sample_f64")
+        out._p = buf[:int(cnt.item())].contiguous()
+        return out
+
+    def _grid(self, cell):
+        n = len(self)
+        g = {"sorted": torch.empty(n, 3, dtype=_D, device=self.device),
+             "keys": torch.empty(n, dtype=torch.int64, device=self.device),
+             "order": torch.empty(n, dtype=torch.int32, device=self.device),
+             "origin": torch.empty(3, dtype=_D, device=self.device), "n": n, "cell": float(cell)}
+        ws = _ws(n, self.device)
+        rc = _lib.lib().ape_grid_build_f64(_lib.dptr(self._p, _D), n, float(cell), _lib.dptr(g["sorted"]), _lib.dptr(g["keys"]),
+                                           _lib.dptr(g["order"]), _lib.dptr(g["origin"]), _lib.dptr(ws), ws.numel(), _st())
+        _lib.check(rc, "ape_grid_build_f64")
+        return g
+
+    @staticmethod
+    def _gargs(g):
+        return (_lib.dptr(g["sorted"]), _lib.dptr(g["keys"]), _lib.dptr(g["order"]), _lib.dptr(g["origin"]), g["n"], g["cell"])
+
+    def _select(self, keep):
+        n = len(self)
+        out = PointCloud(device=self.device)
+        buf = torch.empty(n, 3, dtype=_D, device=self.device)
+        sel = torch.empty(n, dtype=torch.int32, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ws = _ws(n, self.device)
+        rc = _lib.lib().ape_select_points_f64(_lib.dptr(self._p, _D), _lib.dptr(keep, torch.uint8), n, _lib.dptr(buf), _lib.dptr(sel),
+                                              _lib.dptr(cnt), _lib.dptr(ws), ws.numel(), _st())
+        _lib.check(rc, "ape_select_points_f64")
+        k = int(cnt.item())
+        out._p = buf[:k].contiguous()
+        return out, sel[:k].cpu().numpy().tolist()
+
+    def remove_radius_outlier(self, nb_points, radius):
+        """keeps points with MORE than nb_points neighbours (self included) at distance < radius; -> (cloud, kept indices)"""
+        n = len(self)
+        if n == 0:
+            return PointCloud(device=self.device), []
+        g = self._grid(radius)
+        count = torch.empty(n, dtype=torch.int32, device=self.device)
+        rc = _lib.lib().ape_grid_radius_count_f64(*self._gargs(g), _lib.dptr(self._p, _D), n, float(radius), _lib.dptr(count), _st())
+        _lib.check(rc, "ape_grid_radius_count_f64")
+        return self._select((count > int(nb_points)).to(torch.uint8))
+
+    def remove_statistical_outlier(self, nb_neighbors, std_ratio):
+        """open3d 0.9 RemoveStatisticalOutliers: mean distance to the nb_neighbors nearest (self included) must be
+        < cloud mean + std_ratio * sample std; -> (cloud, kept indices)"""
+        n = len(self)
+        if n == 0:
+            return PointCloud(device=self.device), []
+        mean = torch.empty(n, dtype=_D, device=self.device)
+        rc = _lib.lib().ape_knn_mean_dist_f64(_lib.dptr(self._p, _D), n, int(min(nb_neighbors, n)), _lib.dptr(mean), _st())
+        _lib.check(rc, "ape_knn_mean_dist_f64")
+        m = mean.cpu().numpy()
+        valid = m >= 0
+        cloud_mean = m[valid].sum() / max(int(valid.sum()), 1)
+        std = math.sqrt(((m[valid] - cloud_mean) ** 2).sum() / max(int(valid.sum()) - 1, 1))
+        thr = cloud_mean + float(std_ratio) * std
+        keep = torch.from_numpy(((m > 0) & (m < thr)).astype(np.uint8)).to(self.device)
+        return self._select(keep)
+
+    def estimate_normals(self, search_param=None, radius=None, max_nn=30):
+        """KDTreeSearchParamHybrid(radius, max_nn) semantics (open3d_utils.py:25-27)"""
+        if search_param is not None:
+            radius, max_nn = search_param.radius, search_param.max_nn
+        n = len(self)
+        if n == 0:
+            return self
+        g = self._grid(radius)
+        self._n = torch.empty(n, 3, dtype=_D, device=self.device)
+        rc = _lib.lib().ape_grid_normals_f64(*self._gargs(g), _lib.dptr(self._p, _D), n, float(radius), int(max_nn), _lib.dptr(self._n), _st())
+        _lib.check(rc, "ape_grid_normals_f64")
+        return self
+
+
+class KDTreeSearchParamHybrid:
+    def __init__(self, radius, max_nn):
+        self.radius, self.max_nn = radius, max_nn
+
+
+class ICPConvergenceCriteria:
+    def __init__(self, relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30):
+        self.relative_fitness, self.relative_rmse, self.max_iteration = relative_fitness, relative_rmse, max_iteration
+
+
+class TransformationEstimationPointToPoint:
+    kind = 0
+
+    def __init__(self, with_scaling=False):
+        if with_scaling:
+            raise NotImplementedError("with_scaling")
+
+
+class TransformationEstimationPointToPlane:
+    kind = 1
+
+
+class RegistrationResult:
+    def __init__(self, transformation, fitness, inlier_rmse, n_corr):
+        self.transformation, self.fitness, self.inlier_rmse, self.correspondence_count = transformation, fitness, inlier_rmse, n_corr
+
+    def __repr__(self):
+        return "RegistrationResult(fitness=%.6f, inlier_rmse=%.6f, correspondences=%d)" % (self.fitness, self.inlier_rmse,
+                                                                                           self.correspondence_count)
+
+
+def _umeyama(s):
+    """Eigen::umeyama(src, dst, with_scaling=false) from the one-pass sums s[17]."""
+    n = s[0]
+    mu_s, mu_t = s[2:5] / n, s[5:8] / n
+    cov = s[8:17].reshape(3, 3).T / n - np.outer(mu_t, mu_s)        # (1/n) sum (t - mu_t)(s - mu_s)^T
+    U, d, Vt = np.linalg.svd(cov)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = mu_t - R @ mu_s
+    return T
+
+
+def _vec6_to_mat4(x):
+    """open3d TransformVector6dToMatrix4d: R = Rz(x[2]) Ry(x[1]) Rx(x[0]), t = x[3:6]"""
+    cx, sx, cy, sy, cz, sz = math.cos(x[0]), math.sin(x[0]), math.cos(x[1]), math.sin(x[1]), math.cos(x[2]), math.sin(x[2])
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = x[3:6]
+    return T
+
+
+def _point_to_plane(s):
+    JTJ = np.zeros((6, 6))
+    k = 2
+    for a in range(6):
+        for b in range(a, 6):
+            JTJ[a, b] = JTJ[b, a] = s[k]
+            k += 1
+    JTr = s[23:29]
+    try:
+        x = np.linalg.solve(JTJ, -JTr)
+    except np.linalg.LinAlgError:
+        return np.eye(4)
+    return _vec6_to_mat4(x)
+
+
+def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None):
+    """open3d 0.9 registration::RegistrationICP (call sites open3d_utils.py:56-58,98-117).  The source cloud is NOT
+    modified (open3d works on a transformed copy).  One small D2H per iteration (the 17/29 reduced doubles) drives the
+    host-side 3x3 SVD / 6x6 solve and the convergence test."""
+    estimation_method = estimation_method or TransformationEstimationPointToPoint()
+    criteria = criteria or ICPConvergenceCriteria()
+    T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
+    ns, nt = len(source), len(target)
+    if ns == 0 or nt == 0:
+        return RegistrationResult(T, 0.0, 0.0, 0)
+    if estimation_method.kind == 1 and not target.has_normals():
+        raise RuntimeError("TransformationEstimationPointToPlane requires target normals")
+    dev = source.device
+    pcd = source.clone().transform(T)
+    grid = target._grid(max_correspondence_distance)
+    corr = torch.empty(ns, dtype=torch.int32, device=dev)
+    d2 = torch.empty(ns, dtype=_D, device=dev)
+    sums = torch.empty(29, dtype=_D, device=dev)
+    ws = torch.empty(512 * 29 * 8, dtype=torch.uint8, device=dev)
+    L = _lib.lib()
+
+    def evaluate():
+        _lib.check(L.ape_grid_nn1_f64(*PointCloud._gargs(grid), _lib.dptr(pcd._p, _D), ns, float(max_correspondence_distance),
+                                      _lib.dptr(corr), _lib.dptr(d2), _st()), "ape_grid_nn1_f64")
+        _lib.check(L.ape_icp_sums_f64(estimation_method.kind, _lib.dptr(pcd._p, _D), _lib.dptr(target._p, _D), _lib.dptr(target._n),
+                                      _lib.dptr(corr), _lib.dptr(d2), ns, _lib.dptr(sums), _lib.dptr(ws), ws.numel(), _st()),
+                   "ape_icp_sums_f64")
+        s = sums.cpu().numpy()
+        n_corr = int(round(s[0]))
+        fitness = n_corr / ns
+        rmse = math.sqrt(s[1] / n_corr) if n_corr else 0.0
+        return s, n_corr, fitness, rmse
+
+    s, n_corr, fitness, rmse = evaluate()
+    for _ in range(criteria.max_iteration):
+        if n_corr < (3 if estimation_method.kind == 0 else 6):
+            break
+        update = _umeyama(s) if estimation_method.kind == 0 else _point_to_plane(s)
+        T = update @ T
+        pcd.transform(update)
+        prev_f, prev_r = fitness, rmse
+        s, n_corr, fitness, rmse = evaluate()
+        if abs(prev_f - fitness) < criteria.relative_fitness and abs(prev_r - rmse) < criteria.relative_rmse:
+            break
+    return RegistrationResult(T, fitness, rmse, n_corr)
+
+
+def surface_points(label, depth, intr, robot2cam, device="cuda"):
+    """label u8[H,W], depth (integer sensor units) [H,W] -> PointCloud of the valid pixels in the robot frame (mm)."""
+    dev = torch.device(device)
+    lab = torch.as_tensor(np.ascontiguousarray(np.asarray(label, dtype=np.uint8))).to(dev)
+    d = np.asarray(depth)
+    if d.dtype != np.uint16:
+        if (d < 0).any() or (d > 65535).any() or (d != np.floor(d)).any():
+            raise ValueError("depth must hold integer sensor units in 0..65535")
+        d = d.astype(np.uint16)
+    dep = torch.from_numpy(np.ascontiguousarray(d)).to(dev)
+    h, w = lab.shape
+    buf = torch.empty(h * w, 3, dtype=_D, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _ws(h * w, dev)
+    T, ptr = _host16(robot2cam)
+    rc = _lib.lib().ape_surface_points_f64(_lib.dptr(lab, torch.uint8), _lib.dptr(dep, torch.uint16), h, w, float(intr.get("fx")),
+                                           float(intr.get("fy")), float(intr.get("ppx")), float(intr.get("ppy")), ptr, _lib.dptr(buf),
+                                           _lib.dptr(cnt), _lib.dptr(ws), ws.numel(), _st())
+    _lib.check(rc, "ape_surface_points_f64")
+    out = PointCloud(device=dev)
+    out._p = buf[:int(cnt.item())].contiguous()
+    return out

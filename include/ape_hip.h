@@ -160,6 +160,46 @@ int ape_backproject_f32(const uint16_t* depth, const int* objects, const int64_t
 int ape_preprocess_u8_nhwc4(const uint8_t* rgb, const int* rects, float* out, int n, int H, int W, int Hc, int Wc,
                             int div255, void* stream);
 
+/* ---- pose-label path: point clouds in float64 (pc_reconstruction/open3d_utils.py, open3d 0.9 semantics) -------
+ * Workspace for any of the calls below on clouds of up to n points (H*W for ape_surface_points_f64). */
+size_t ape_pc_workspace_bytes(int n);
+/* get_surface's pixel loop        pc_reconstruction/open3d_utils.py:171-192: pixels with label != 0 and depth != 0, in raster
+ * order, back-projected (mm, no depth scale) and moved to the robot frame by T (row-major 4x4, HOST pointer).
+ * points[H*W][3] capacity, *n_out (device int). */
+int ape_surface_points_f64(const uint8_t* label, const uint16_t* depth, int H, int W, double fx, double fy, double ppx,
+                           double ppy, const double* T16_host, double* points, int* n_out, void* ws, size_t ws_bytes,
+                           void* stream);
+/* PointCloud.transform            in place; normals (may be NULL) get the rotation part */
+int ape_transform_points_f64(double* pts, double* normals_or_null, int n, const double* T16_host, void* stream);
+/* PointCloud.voxel_down_sample    open3d_utils.py:21,198,157: per-voxel mean, output ordered by voxel key */
+int ape_voxel_down_sample_f64(const double* pts, int n, double voxel, double* out, int* n_out, void* ws, size_t ws_bytes,
+                              void* stream);
+/* Uniform search grid over a cloud (cell >= every radius later asked of it): caller-owned sorted[n][3], keys[n],
+ * order[n], origin3[3].  Replaces open3d's KDTreeFlann for the bounded-radius searches of the path. */
+int ape_grid_build_f64(const double* pts, int n, double cell, double* sorted, unsigned long long* keys, unsigned* order,
+                       double* origin3, void* ws, size_t ws_bytes, void* stream);
+/* remove_radius_outlier's neighbour count (d < radius, self included)   open3d_utils.py:203 */
+int ape_grid_radius_count_f64(const double* sorted, const unsigned long long* keys, const unsigned* order, const double* origin3,
+                              int n, double cell, const double* q, int nq, double radius, int* count, void* stream);
+/* registration_icp's correspondence search: nearest target point within max_dist, idx = -1 if none   :98-117 */
+int ape_grid_nn1_f64(const double* sorted, const unsigned long long* keys, const unsigned* order, const double* origin3,
+                     int n, double cell, const double* q, int nq, double max_dist, int* idx, double* dist2, void* stream);
+/* estimate_normals(KDTreeSearchParamHybrid(radius, max_nn))   open3d_utils.py:25-27; normals oriented towards +z */
+int ape_grid_normals_f64(const double* sorted, const unsigned long long* keys, const unsigned* order, const double* origin3,
+                         int n, double cell, const double* q, int nq, double radius, int max_nn, double* normals, void* stream);
+/* remove_statistical_outlier's per-point mean distance to its k nearest neighbours (self included)   :208-211 */
+int ape_knn_mean_dist_f64(const double* pts, int n, int k, double* mean, void* stream);
+/* One-pass ICP reductions (bitwise reproducible).  kind 0: point-to-point (Umeyama) out[17] = count, sum d^2, sum s[3],
+ * sum t[3], sum s_a t_b[9];  kind 1: point-to-plane out[29] = count, sum d^2, upper triangle of J^T J[21], J^T r[6];
+ * kind 2: moments of src, out[9] = sum p[3], sum p_a p_b upper triangle[6] (get_center / compute_mahalanobis_distance). */
+int ape_icp_sums_f64(int kind, const double* src, const double* tgt, const double* tgt_normals, const int* corr,
+                     const double* dist2, int n, double* out, void* ws, size_t ws_bytes, void* stream);
+/* compute_mahalanobis_distance    mean_cinv12_host = (mean[3], inverse covariance[9]) */
+int ape_mahalanobis_f64(const double* pts, int n, const double* mean_cinv12_host, double* out, void* stream);
+/* ordered row selection (outlier filters): out = pts[keep != 0], sel_idx = kept indices, *n_out on the device */
+int ape_select_points_f64(const double* pts, const uint8_t* keep, int n, double* out, int* sel_idx, int* n_out, void* ws,
+                          size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
