@@ -1,8 +1,12 @@
-"""Drop-in surface of pc_reconstruction/open3d_utils.py.  Round 1 provides the numpy-only helpers that the live path
-touches (`points2pixel` :233-243, `pixels2points` :215-231, `pointcloud2image` :246-270, `get_my_source_center` :273-292)
-vectorised on the host -- they are visualisation / bookkeeping, not the hot path.  The open3d-backed functions
-(get_surface, preprocess_point_cloud, icp_regression, align_point_clouds) are the ICP row of SURVEY.md 8a (a15-a17) and
-land with the HIP ICP kernels."""
+"""Drop-in surface of pc_reconstruction/open3d_utils.py.
+
+Host numpy helpers the live path touches (visualisation / bookkeeping): `points2pixel` :233-243, `pixels2points`
+:215-231, `pointcloud2image` :246-270, `get_my_source_center` :273-292.
+The open3d-backed half -- `get_surface` :171-213, `preprocess_point_cloud` :19-33, `icp_regression` :63-122,
+`refine_registration` :51-59, `align_point_clouds` :125-168 -- runs on the gfx950 float64 point-cloud kernels through
+`pc_reconstruction.pointcloud.PointCloud` (open3d itself is a third-party dependency absent from the reference tree:
+parity UNPINNED, semantics restated from open3d 0.9).  `fuse_views` is the array-level core of
+create_pointcloud.load_point_cloud :276-312 (its PNG/JSON directory walking is SURVEY.md 8f "next")."""
 import numpy as np
 
 
