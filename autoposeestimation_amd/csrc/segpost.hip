@@ -348,6 +348,38 @@ __global__ void crop_normalize_kernel(const uint8_t* __restrict__ rgb, const int
     }
 }
 
+// trust checks of the pose-label relabelling (label_generator/create_labels.py:166-196): per frame six counts of
+// (condition, pred set / unset) pairs: cond 0 = background-subtraction label != 0, cond 1 = depth inside the +-gate and != 0,
+// cond 2 = centre window [cut0, H-cut0) x [cut1, W-cut1).  counts[b][6] = (c0&p, c0&!p, c1&p, c1&!p, c2&p, c2&!p).
+__global__ __launch_bounds__(kT) void label_trust_kernel(const uint8_t* __restrict__ objmap, int cls, const uint8_t* __restrict__ bs_label,
+                                                         const uint16_t* __restrict__ depth, const float* __restrict__ gate /*[B][2] min,max*/,
+                                                         int H, int W, int cut0, int cut1, unsigned int* __restrict__ counts)
+{
+    __shared__ unsigned int lc[6];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 6) lc[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int c[6] = {0, 0, 0, 0, 0, 0};
+    const float dmin = gate[b * 2], dmax = gate[b * 2 + 1];
+    const int HW = H * W;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < HW; q += gridDim.x * blockDim.x) {
+        const long p = (long)b * HW + q;
+        const int pr = objmap[p] == cls ? 0 : 1;
+        const int y = q / W, x = q - y * W;
+        const float d = (float)depth[p];
+        if (bs_label && bs_label[p] != 0) c[0 + pr]++;
+        if (d != 0.f && !(d > dmax) && !(d < dmin)) c[2 + pr]++;       // depth[depth > max] = 0; depth[depth < min] = 0 (:111-112)
+        if (y >= cut0 && y < H - cut0 && x >= cut1 && x < W - cut1) c[4 + pr]++;
+    }
+    for (int i = 0; i < 6; ++i) {
+        unsigned int v = c[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&lc[i], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && lc[threadIdx.x]) atomicAdd(&counts[b * 6 + threadIdx.x], lc[threadIdx.x]);
+}
+
 }  // namespace
 
 extern "C" int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float* score, long npix,
@@ -438,4 +470,18 @@ extern "C" int ape_preprocess_u8_nhwc4(const uint8_t* rgb, const int* rects, flo
     hipLaunchKernelGGL(crop_normalize_kernel, dim3(grid_for(total)), dim3(kT), 0, (hipStream_t)stream, rgb, rects, (float4*)out, H,
                        W, Hc, Wc, div255, total);
     return ape::check_launch("ape_preprocess_u8_nhwc4");
+}
+
+/* counts[B][6] u32 must be zeroed by the caller (hipMemsetAsync / torch.zeros); see label_trust_kernel. */
+extern "C" int ape_label_trust_counts(const uint8_t* objmap, int cls, const uint8_t* bs_label_or_null, const uint16_t* depth,
+                                      const float* gate_min_max, int B, int H, int W, int cut0, int cut1, unsigned int* counts,
+                                      void* stream)
+{
+    if (!objmap || !depth || !gate_min_max || !counts || B < 0 || H < 1 || W < 1 || cls < 1 || cls > 255) return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    int gx = ape::ceil_div((long)H * W, kT);
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(label_trust_kernel, dim3(gx, B), dim3(kT), 0, (hipStream_t)stream, objmap, cls, bs_label_or_null, depth,
+                       gate_min_max, H, W, cut0, cut1, counts);
+    return ape::check_launch("ape_label_trust_counts");
 }

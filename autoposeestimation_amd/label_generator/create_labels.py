@@ -23,3 +23,99 @@ def get_default_model(root, ds_name, n_classes, name="PsPNet", encoder_name="res
                         map_location=torch.device("cpu"))
         model.load_state_dict(cp["state_dict"])
     return model
+
+
+# ---- "Create Pose labels": the per-frame relabelling and the pose-label maths (reference :96-214, :395-429) -------------
+import math  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+from autoposeestimation_amd import _lib  # noqa: E402
+from autoposeestimation_amd import engine as E  # noqa: E402
+
+
+def relabel_frames(model, rgb, depth, robot2cam, reference_point, class_id, bs_labels=None, is_extra=False):
+    """Device form of the seg-relabel loop body (reference :101-205) for a batch of frames of ONE object class.
+
+    rgb[B,H,W,3] u8 cuda, depth[B,H,W] u16 cuda, robot2cam[B,4,4] (robot2endEff_tf . hand_eye_calibration, :104-106),
+    reference_point[3] mm, class_id 0-based, bs_labels[B,H,W] u8 cuda = the background-subtraction `.pred.label.png`
+    (None for the 'extra' directories).  Returns (labels[B,H,W] u8 {0,255} cuda, save[B] bool, stats dict): frame i's
+    `.new_pred.label.png` is labels[i] when save[i], otherwise the reference deletes stale outputs (:206-214)."""
+    b, h, w, _ = rgb.shape
+    dev = rgb.device
+    target = class_id + 1
+    n_cls = model.classes
+    rects = torch.zeros(b, 3, dtype=torch.int32)
+    rects[:, 0] = torch.arange(b, dtype=torch.int32)
+    x4 = E.preprocess_u8(rgb, rects.to(dev), h, w, div255=True)
+    label, score = E.seg_argmax(model.logits_nhwc(x4), n_cls, double_softmax=True)      # predict's softmax + F.softmax (:121-122)
+    label = torch.where(label == target, label, torch.zeros_like(label))                # pred_arg[pred_arg != class_id+1] = 0 (:128)
+    objmap, _ = E.seg_components(label, score, n_cls, min_pixels=0)                      # best mean-probability component (:131-141)
+    pos = np.asarray(robot2cam, dtype=np.float64).reshape(b, 4, 4)[:, :3, 3]
+    dist = np.linalg.norm(np.asarray(reference_point, dtype=np.float64)[None] - pos, axis=1)
+    gate = torch.from_numpy(np.stack([dist - 150, dist + 150], 1).astype(np.float32)).to(dev)   # :107-109
+    counts = torch.zeros(b, 6, dtype=torch.int32, device=dev)
+    rc = _lib.lib().ape_label_trust_counts(_lib.dptr(objmap, torch.uint8), target, _lib.dptr(bs_labels), _lib.dptr(depth, torch.uint16),
+                                           _lib.dptr(gate), b, h, w, 30, 50, _lib.dptr(counts), _lib.stream_ptr())
+    _lib.check(rc, "ape_label_trust_counts")
+    c = counts.cpu().numpy()
+    labels = torch.where(objmap == target, torch.full_like(objmap, 255), torch.zeros_like(objmap))
+    save = np.zeros(b, bool)
+    stats = {"bs_copied": 0, "no_depth_overlap": 0, "not_in_center": 0}
+    for i in range(b):
+        if not is_extra and bs_labels is not None and not (c[i, 0] > 0 and c[i, 1] > 0):      # len(np.unique(pred[bs != 0])) <= 1 (:169)
+            labels[i] = bs_labels[i]
+            save[i] = True
+            stats["bs_copied"] += 1
+            continue
+        if not (c[i, 2] > 0 and c[i, 3] > 0):                                                   # :182-185
+            stats["no_depth_overlap"] += 1
+            continue
+        if c[i, 4] > 0 and c[i, 5] > 0:                                                         # :187-193
+            save[i] = True
+        else:
+            stats["not_in_center"] += 1
+    return labels, save, stats
+
+
+_EPS4 = np.finfo(float).eps * 4.0
+
+
+def mat2euler(M):
+    """transforms3d.euler.mat2euler(M) with its default axes='sxyz' (reference :343,368; UNPINNED third-party maths)."""
+    M = np.asarray(M, dtype=np.float64)[:3, :3]
+    cy = math.sqrt(M[0, 0] * M[0, 0] + M[1, 0] * M[1, 0])
+    if cy > _EPS4:
+        return math.atan2(M[2, 1], M[2, 2]), math.atan2(-M[2, 0], cy), math.atan2(M[1, 0], M[0, 0])
+    return math.atan2(-M[1, 2], M[1, 1]), math.atan2(-M[2, 0], cy), 0.0
+
+
+def euler2mat(ai, aj, ak):
+    """transforms3d.euler.euler2mat(ai, aj, ak) with axes='sxyz': R = Rz(ak) Ry(aj) Rx(ai)"""
+    ci, si, cj, sj, ck, sk = math.cos(ai), math.sin(ai), math.cos(aj), math.sin(aj), math.cos(ak), math.sin(ak)
+    return np.array([[cj * ck, sj * si * ck - ci * sk, sj * ci * ck + si * sk],
+                     [cj * sk, sj * si * sk + ci * ck, sj * ci * sk - si * ck],
+                     [-sj, cj * si, cj * ci]])
+
+
+def constrain_rotation(pc_rotation, init_tf):
+    """reference :366-377: fold the ICP correction into the requested object rotation and keep only the Euler axes that
+    were requested non-zero."""
+    old = np.rad2deg(mat2euler(pc_rotation))
+    new = np.dot(np.asarray(pc_rotation, float), np.asarray(init_tf, float)[:3, :3])
+    euler = np.array(mat2euler(new))
+    euler[old == 0.0] = 0.0
+    return euler2mat(*euler)
+
+
+def pose_label(meta, pc_position, pc_rotation, object_name):
+    """reference :395-429: cam2object = inv(hand_eye) . inv(robot2endEff) . [pc_rotation | pc_position] -> label dict"""
+    hand_eye = np.array(meta.get("hand_eye_calibration"), dtype=np.float64).reshape(4, 4)
+    robot2end = np.array(meta.get("robot2endEff_tf"), dtype=np.float64).reshape(4, 4)
+    robot2object = np.identity(4)
+    robot2object[:3, :3] = pc_rotation
+    robot2object[:3, 3] = pc_position
+    cam2robot = np.dot(np.linalg.inv(hand_eye), np.linalg.inv(robot2end))
+    cam2object = np.dot(cam2robot, robot2object)
+    return {"position": list(cam2object[:3, 3]), "rotation": list(cam2object[:3, :3].flatten()), "cls_name": object_name,
+            "cam2robot": list(cam2robot.flatten()), "robot2object": list(robot2object.flatten())}

@@ -147,6 +147,12 @@ int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float
 size_t ape_seg_components_workspace_bytes(int B, int H, int W, int C);
 int ape_seg_components(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
                        int C, int min_pixels, void* workspace, size_t workspace_bytes, void* stream);
+/* trust checks of the relabelling loop   label_generator/create_labels.py:166-196.  objmap from ape_seg_components
+ * (min_pixels = 0), cls = target class; counts[B][6] u32 (zeroed by the caller) = (bs&pred, bs&!pred, depth&pred,
+ * depth&!pred, centre&pred, centre&!pred) with the depth gate [min,max] per frame (:106-112) and the 30/50 px centre window. */
+int ape_label_trust_counts(const uint8_t* objmap, int cls, const uint8_t* bs_label_or_null, const uint16_t* depth,
+                           const float* gate_min_max, int B, int H, int W, int cut0, int cut1, unsigned int* counts,
+                           void* stream);
 /* choose = mask[rmin:rmax, cmin:cmax].flatten().nonzero(); > N -> ordered subset, <= N -> wrap pad
  *   pipeline/utils.py:524-539.  objects[n][6] i32 = (frame, cls, rmin, rmax, cmin, cmax);
  * choose[n][N] i64 indices inside the crop; n_cand[n] (0 => object dropped, :530-531); cand: scratch [n][cand_stride]. */

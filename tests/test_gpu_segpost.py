@@ -127,3 +127,50 @@ def test_empty_depth_object_is_dropped():
     objs = torch.tensor([(0, 1) + O.get_bbox(label == 1, H, W)], dtype=torch.int32).cuda()
     choose, n_cand = E.choose_points(torch.from_numpy(label[None]).cuda(), torch.from_numpy(depth[None]).cuda(), objs, 1000)
     assert int(n_cand[0]) == 0 and not choose.any()
+
+
+def test_relabel_trust_checks_vs_numpy():
+    """create_labels.py:101-205 on the device: target-class component + the three trust checks, against numpy."""
+    from autoposeestimation_amd import engine as E
+    from autoposeestimation_amd.label_generator.create_labels import relabel_frames
+
+    class _FakeSeg:             # injects logits so the comparison is integer-exact
+        classes = 13
+
+        def __init__(self, logits):
+            self.l = logits
+
+        def logits_nhwc(self, x4):
+            return self.l
+
+    B = 4
+    logits = torch.stack([_blob_logits(50 + i, 13) for i in range(B)])
+    rng = np.random.default_rng(3)
+    depth = rng.integers(300, 1100, (B, H, W)).astype(np.uint16)
+    depth[rng.random((B, H, W)) < 0.05] = 0
+    depth[2] = 2000                                   # outside the gate everywhere -> "no depth overlap"
+    bs = np.zeros((B, H, W), np.uint8)
+    bs[0, 100:200, 100:300] = 255
+    bs[1, 0:5, 0:5] = 255
+    r2c = np.tile(np.eye(4), (B, 1, 1))
+    r2c[:, :3, 3] = [0, 0, 700]
+    ref = np.array([0.0, 0.0, 0.0])
+    for cls in (0, 2):
+        labels, save, stats = relabel_frames(_FakeSeg(logits.permute(0, 2, 3, 1).contiguous().cuda()),
+                                             torch.zeros(B, H, W, 3, dtype=torch.uint8).cuda(), torch.from_numpy(depth).cuda(), r2c,
+                                             ref, cls, torch.from_numpy(bs).cuda())
+        labels = labels.cpu().numpy()
+        for i in range(B):
+            pred = F.softmax(F.softmax(logits[i], 0), 0)
+            want = O.seg_postprocess(pred, min_pixels=-1).get(cls + 1, np.zeros((H, W), np.uint8))
+            d = depth[i].astype(np.float64)
+            d[d > 850] = 0
+            d[d < 550] = 0
+            if len(np.unique(want[bs[i] != 0])) <= 1:
+                exp_save, exp = True, bs[i]
+            elif len(np.unique(want[d != 0])) <= 1:
+                exp_save, exp = False, want
+            else:
+                exp_save, exp = len(np.unique(want[30:H - 30, 50:W - 50])) > 1, want
+            assert bool(save[i]) == exp_save, (cls, i)
+            assert np.array_equal(labels[i], exp), (cls, i)
