@@ -1,0 +1,94 @@
+"""Array-level drop-in for pc_reconstruction/create_pointcloud.py: `get_view_distribution` (reference :46-174) and the
+fusion / alignment / export tail of `load_point_cloud` (:181-378).  The reference walks directories of PNG/JSON samples;
+that on-disk format is SURVEY.md 8f "next", so the entry points here take the decoded arrays.  Per-view geometry runs on
+the GPU (open3d_utils.get_surface / icp_regression); view selection over <= ~200 camera positions is host numpy."""
+import numpy as np
+
+from autoposeestimation_amd.pc_reconstruction import open3d_utils as utils
+from autoposeestimation_amd.pc_reconstruction import pointcloud as pc
+
+
+def _voxel_mean_host(points, voxel):
+    origin = points.min(0) - voxel * 0.5
+    idx = np.floor((points - origin) / voxel).astype(np.int64)
+    key = (idx[:, 0] << 42) | (idx[:, 1] << 21) | idx[:, 2]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+    ends = np.r_[starts[1:], len(ks)]
+    return np.array([points[order[a:b]].mean(0) for a, b in zip(starts, ends)])
+
+
+def get_view_distribution(cam_positions, n_viewpoints, rng=None):
+    """reference :46-174 on the camera positions robot2Cam[:3,3] of a directory's samples: thin them with a voxel grid
+    whose size is searched in 1 mm steps until exactly `n_viewpoints` voxels remain (random subset when it overshoots),
+    snap each voxel centroid to its nearest real view, then order the views greedily by nearest neighbour starting from
+    the one closest to the robot origin.  Returns indices into `cam_positions`."""
+    points = np.asarray(cam_positions, dtype=np.float64)
+    n = len(points)
+    if n_viewpoints > n:
+        raise ValueError("more viewpoints requested than samples")
+    rng = rng or np.random.default_rng()
+    d = np.linalg.norm(points[:, None] - points[None], axis=2)
+    np.fill_diagonal(d, np.inf)
+    voxel_size = float(int(d.min()))                           # int(np.linalg.norm(...)) of the closest pair (:84-95)
+    if voxel_size == 0:
+        voxel_size = 1.0                                        # a zero voxel is meaningless (the reference would divide by it)
+    while True:
+        down = _voxel_mean_host(points, voxel_size)
+        if len(down) == n_viewpoints:
+            selected = down
+            break
+        if len(down) < n_viewpoints:
+            voxel_size -= 1
+            down = _voxel_mean_host(points, max(voxel_size, 1e-9))
+            selected = down[rng.choice(len(down), replace=False, size=n_viewpoints)]
+            break
+        voxel_size += 1
+    selection = np.array([int(np.argmin(np.linalg.norm(points - p, axis=1))) for p in selected])
+    pts = points[selection]
+    order = [int(np.argmin(np.linalg.norm(pts, axis=1)))]
+    while len(order) != n_viewpoints:
+        dist = np.linalg.norm(pts - pts[order[-1]], axis=1)
+        dist[order] = np.inf
+        order.append(int(np.argmin(dist)))
+    return selection[order]
+
+
+def fuse_direction(views, intr, point_cloud_tf=None, **kw):
+    """One (object, rotation-directory) chain (reference :227-325): sequential registration of the selected views, then the
+    directory's known object rotation applied about the cloud centre (:320)."""
+    cloud, tfs = utils.fuse_views(views, intr, **kw)
+    if cloud is not None and point_cloud_tf is not None:
+        cloud.rotate(R=np.asarray(point_cloud_tf, dtype=np.float64)[:3, :3], center=True)
+    return cloud, tfs
+
+
+def finish_object(point_clouds, min_friends=20, min_dist=5, nb_neighbors=20, voxel_size=2, voxel_size_out=5, threshold=10):
+    """reference :331-376: align the per-directory clouds, then derive the three exported clouds: `<obj>_out` (robot
+    frame), `<obj>` (centred, voxel_size_out) and the >= 1000-point `<obj>.xyz` model cloud used by DenseFusion (voxel grown
+    in 0.1 steps until fewer than 1000 points would remain).  Returns (out, centred_down, xyz ndarray)."""
+    out = utils.align_point_clouds(point_clouds, min_friends=min_friends, min_dist=min_dist, nb_neighbors=nb_neighbors,
+                                   voxel_size=voxel_size, threshold=threshold)
+    down = out.voxel_down_sample(voxel_size=voxel_size_out)
+    down.translate(translation=-utils.get_my_source_center(down))
+    big = out.clone()
+    big.translate(translation=-utils.get_my_source_center(big))
+    v = voxel_size
+    while True:
+        v += 0.1
+        if len(big.voxel_down_sample(voxel_size=v)) < 1000:
+            big = big.voxel_down_sample(voxel_size=v - 0.1)
+            break
+    return out, down, np.array(big.points)
+
+
+def write_xyz(path, points):
+    """`<obj>.xyz` exactly as the reference writes it (:373-376): one numpy-repr'd point per line, parsed back by
+    pipeline/utils.py:667-684 (read_xyz_cloud)."""
+    with open(path, "w") as f:
+        for item in np.asarray(points):
+            f.write("%s\n" % item)
+
+
+__all__ = ["get_view_distribution", "fuse_direction", "finish_object", "write_xyz", "pc"]

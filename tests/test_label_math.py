@@ -37,3 +37,26 @@ def test_pose_label_composition():
     np.testing.assert_allclose(np.array(lab["rotation"]).reshape(3, 3), want[:3, :3], atol=1e-10)
     np.testing.assert_allclose(lab["position"], want[:3, 3], atol=1e-8)
     assert lab["cls_name"] == "obj" and len(lab["cam2robot"]) == 16 and len(lab["robot2object"]) == 16
+
+
+def test_view_distribution_selects_ordered_distinct_views():
+    from autoposeestimation_amd.pc_reconstruction.create_pointcloud import get_view_distribution
+    rng = np.random.default_rng(2)
+    th = rng.uniform(0, 2 * np.pi, 164)
+    ph = rng.uniform(0.2, 1.2, 164)
+    cams = np.stack([600 * np.cos(th) * np.sin(ph), 600 * np.sin(th) * np.sin(ph) - 600, 600 * np.cos(ph) + 100], 1)
+    sel = get_view_distribution(cams, 30, np.random.default_rng(0))
+    assert len(sel) == 30 and len(set(sel.tolist())) >= 28          # snapping may map two centroids to one view
+    assert sel[0] == sel[np.argmin(np.linalg.norm(cams[sel], axis=1))]
+    hop = np.linalg.norm(np.diff(cams[sel], axis=0), axis=1)          # greedy nearest-neighbour tour: mostly short hops
+    assert np.median(hop) < np.median(np.linalg.norm(cams[sel][:, None] - cams[sel][None], axis=2))
+
+
+def test_xyz_roundtrip(tmp_path):
+    from autoposeestimation_amd.pc_reconstruction.create_pointcloud import write_xyz
+    from autoposeestimation_amd.pipeline.utils import read_xyz_cloud
+    pts = np.random.default_rng(0).uniform(-50, 50, (20, 3))
+    p = tmp_path / "obj.xyz"
+    write_xyz(p, pts)
+    np.testing.assert_allclose(read_xyz_cloud(str(p), to_meter=False), pts, rtol=1e-7)
+    np.testing.assert_allclose(read_xyz_cloud(str(p)), pts / 1000, rtol=1e-7)
