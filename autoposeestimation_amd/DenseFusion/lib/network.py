@@ -11,6 +11,8 @@ Differences from the reference that do not change results beyond fp32 rounding:
     1024-vector broadcast of network.py:67-68 becomes a per-crop bias instead of a materialised 1408 x N tensor;
   * the PSP bottleneck (pspnet.py:22-24) is evaluated as  W_f . feats + sum_s up(W_s . prior_s)  (1x1 conv and bilinear
     resize commute), so the 2560-channel concat is never built;
+  * up_1 / up_2 (bilinear x2 then 3x3 conv, pspnet.py:27-37) mix channels at LOW resolution (1x1 conv to 9*Cout channels) and
+    then resize + shift + sum the nine taps (engine.UpConv): conv and resize are linear, so the order is free;
   * the heads evaluate only the selected object's output rows (network.py:119-126 computes all, then index_selects);
   * the 32-channel log-softmax embedding is evaluated only at the `choose`d pixels (network.py:100-102 gathers them
     from the full map);  `PSPNet.forward` still returns the full map;
@@ -110,8 +112,12 @@ class _PSPPlan:
         self.stage = [_Conv(g(f"psp.stages.{i}.1.weight"), None, device=dev) for i in range(4)]
         self.bott_prior = [_Conv(wb[:, i * 512:(i + 1) * 512], None, device=dev) for i in range(4)]
         self.bott_feats = _Conv(wb[:, 2048:2560], g("psp.bottleneck.bias"), act=E.ACT_RELU, device=dev)
-        self.up = [_Conv(g(f"{n}.conv.1.weight"), g(f"{n}.conv.1.bias"), 1, 1, 1, E.ACT_PRELU,
-                          alpha=float(g(f"{n}.conv.2.weight").reshape(-1)[0]), device=dev) for n in ("up_1", "up_2", "up_3")]
+        # up_1 / up_2: channel mixing at low resolution + tap gather (4x fewer flops, no upsampled tensor); up_3 (64 -> 64 at
+        # full resolution) would write a 9 x 64-channel half-resolution tensor larger than what it saves, so it stays direct
+        self.up = [E.UpConv(g(f"{n}.conv.1.weight"), g(f"{n}.conv.1.bias"), float(g(f"{n}.conv.2.weight").reshape(-1)[0]),
+                            device=dev, precision=precision) for n in ("up_1", "up_2")]
+        self.up3 = _Conv(g("up_3.conv.1.weight"), g("up_3.conv.1.bias"), 1, 1, 1, E.ACT_PRELU,
+                         alpha=float(g("up_3.conv.2.weight").reshape(-1)[0]), device=dev)
         self.final = _Conv(g("final.0.weight"), g("final.0.bias"), device=dev)
 
     def features(self, x, taps=None):
@@ -130,9 +136,12 @@ class _PSPPlan:
         if taps is not None:
             taps["feats"], taps["psp"] = f, p
         for i, up in enumerate(self.up):
-            p = up(E.bilinear(p, p.shape[1] * 2, p.shape[2] * 2, True))
+            p = up(p)
             if taps is not None:
                 taps["up_%d" % (i + 1)] = p
+        p = self.up3(E.bilinear(p, p.shape[1] * 2, p.shape[2] * 2, True))
+        if taps is not None:
+            taps["up_3"] = p
         return p
 
 

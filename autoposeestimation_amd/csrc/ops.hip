@@ -43,23 +43,32 @@ __global__ void maxpool3x3s2_kernel(const float4* __restrict__ x, float4* __rest
     }
 }
 
-// one workgroup per (b, oy, ox) bin; threads stride channels (float4) and loop over the bin's pixels
-__global__ void adaptive_avgpool_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W, int C4, int S)
+// grid (bins, channel chunks of 64 float4); the 4 waves of a workgroup split the bin's pixels and combine through LDS in a
+// fixed order.  (A whole-bin-per-workgroup version left 64 workgroups streaming 4800 pixels each for S = 1.)
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float4* __restrict__ x, float4* __restrict__ y, int H, int W, int C4, int S)
 {
+    __shared__ float4 part[4][64];
     const int bin = blockIdx.x;
     const int ox = bin % S, oy = (bin / S) % S, b = bin / (S * S);
     const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
     const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
-    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
-    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int iy = y0; iy < y1; ++iy)
-            for (int ix = x0; ix < x1; ++ix) {
-                const float4 v = x[((long)(b * H + iy) * W + ix) * C4 + c];
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-        // ATen divides the fp32 sum by the bin size
-        y[(long)bin * C4 + c] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    const int bw = x1 - x0, npx = (y1 - y0) * bw;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C4)
+        for (int p = g; p < npx; p += 4) {
+            const int iy = y0 + p / bw, ix = x0 + p % bw;
+            const float4 v = x[((long)(b * H + iy) * W + ix) * C4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < C4) {
+        const float inv = 1.f / (float)npx;
+        float4 t = part[0][lane];
+        for (int k = 1; k < 4; ++k) { t.x += part[k][lane].x; t.y += part[k][lane].y; t.z += part[k][lane].z; t.w += part[k][lane].w; }
+        y[(long)bin * C4 + c] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
     }
 }
 
@@ -187,6 +196,59 @@ __global__ void head_select_kernel(const float* __restrict__ h, int ldh, int off
     }
 }
 
+// conv3x3(pad 1) o bilinear-x2(align_corners=True)  ==  sum over the 9 taps of  bilinear-x2( W_tap . x )  shifted by the tap:
+// the channel mixing W_tap commutes with the (linear, per-channel) resize, so it is applied at LOW resolution by a 1x1 conv
+// producing z[B][h][w][9*C] (channel = tap*C + c), and this kernel does the resize + tap shift + sum + bias + PReLU:
+//   out(Y, X, c) = act( bias[c] + sum_{ky,kx} U_tap(Y + ky - 1, X + kx - 1)[c] ),   U_tap(q) = 0 outside the 2h x 2w image
+// (the reference zero-pads the UPSAMPLED image, pspnet.py:30-32).  4x fewer MFMA flops than convolving at high resolution
+// and the upsampled 2h x 2w x Cin tensor is never written.
+__global__ void upconv_gather_kernel(const float4* __restrict__ z, const float* __restrict__ bias, float4* __restrict__ out, int B,
+                                     int h, int w, int C4, float sh, float sw, int act, float alpha)
+{
+    const int Ho = 2 * h, Wo = 2 * w;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        long t = i / C4;
+        const int X = t % Wo; t /= Wo;
+        const int Y = t % Ho;
+        const int b = t / Ho;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = Y + ky - 1;
+            if ((unsigned)qy >= (unsigned)Ho) continue;
+            const float fy = sh * (float)qy;
+            const int iy0 = (int)fy, iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
+            const float ly1 = fy - (float)iy0, ly0 = 1.f - ly1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int qx = X + kx - 1;
+                if ((unsigned)qx >= (unsigned)Wo) continue;
+                const float fx = sw * (float)qx;
+                const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+                const float lx1 = fx - (float)ix0, lx0 = 1.f - lx1;
+                const int tc = (ky * 3 + kx) * C4 + c;
+                const float4 v00 = z[((long)(b * h + iy0) * w + ix0) * (9 * C4) + tc];
+                const float4 v01 = z[((long)(b * h + iy0) * w + ix1) * (9 * C4) + tc];
+                const float4 v10 = z[((long)(b * h + iy1) * w + ix0) * (9 * C4) + tc];
+                const float4 v11 = z[((long)(b * h + iy1) * w + ix1) * (9 * C4) + tc];
+                acc.x += ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+                acc.y += ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+                acc.z += ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+                acc.w += ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+            }
+        }
+        if (bias) { acc.x += bias[c * 4]; acc.y += bias[c * 4 + 1]; acc.z += bias[c * 4 + 2]; acc.w += bias[c * 4 + 3]; }
+        if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        else if (act == APE_ACT_PRELU) {
+            acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;
+            acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
+        }
+        out[i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int ape_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream)
@@ -204,7 +266,7 @@ extern "C" int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, in
 {
     if (!x || !y || B < 0 || H < 1 || W < 1 || C < 4 || C % 4 || S < 1) return APE_EINVAL;
     if (B == 0) return APE_OK;
-    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(B * S * S), dim3(kThreads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(B * S * S, ape::ceil_div(C / 4, 64)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (float4*)y, H, W, C / 4, S);
     return ape::check_launch("ape_adaptive_avgpool_nhwc_f32");
 }
@@ -274,4 +336,19 @@ extern "C" int ape_head_select_f32(const float* h, int ldh, int off_r, int off_t
     hipLaunchKernelGGL(head_select_kernel, grid, dim3(kThreads), 8 * K * sizeof(float), (hipStream_t)stream, h, ldh, off_r,
                        off_t, off_c, wr, br, wt, bt, wc, bc, obj, out, n, K);
     return ape::check_launch("ape_head_select_f32");
+}
+
+extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
+                                        void* stream)
+{
+    if (!z || !out || B < 0 || h < 1 || w < 1 || C < 4 || C % 4 || act < APE_ACT_NONE || act > APE_ACT_PRELU) return APE_EINVAL;
+    const long total = (long)B * 4 * h * w * (C / 4);
+    if (total == 0) return APE_OK;
+    const float sh = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    const float sw = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    long g = (total + kThreads - 1) / kThreads;
+    g = g > 65536 ? 65536 : g;
+    hipLaunchKernelGGL(upconv_gather_kernel, dim3((int)g), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
+                       h, w, C / 4, sh, sw, act, alpha);
+    return ape::check_launch("ape_upconv3x3_gather_f32");
 }

@@ -147,6 +147,27 @@ def bilinear(x, ho, wo, align_corners, out=None, yoff=0, accumulate=False):
     return out
 
 
+class UpConv:
+    """PSPUpsample (pspnet.py:27-37) as  1x1 conv at low resolution (9*Cout channels) + ape_upconv3x3_gather_f32."""
+
+    def __init__(self, weight, bias, alpha, device="cuda", precision="f32"):
+        cout, cin, kh, kw = weight.shape
+        assert (kh, kw) == (3, 3)
+        w9 = weight.detach().permute(2, 3, 0, 1).reshape(9 * cout, cin)            # row = (ky*3+kx)*Cout + co
+        self.mix = Conv(w9, None, device=device, precision=precision)
+        self.bias = bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.alpha, self.cout = float(alpha), cout
+
+    def __call__(self, x):
+        b, h, w, _ = x.shape
+        z = self.mix(x)
+        out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=x.device)
+        rc = _lib.lib().ape_upconv3x3_gather_f32(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), b, h, w,
+                                                 self.cout, ACT_PRELU, self.alpha, _st())
+        _lib.check(rc, "ape_upconv3x3_gather_f32")
+        return out
+
+
 def gather_rows(x, index):
     """x[B,R,C], index[B,n] i64 -> [B,n,C]"""
     b, r, c = x.shape

@@ -88,6 +88,12 @@ int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W,
  * concat buffer, pspnet.py:22-23); accumulate != 0 adds into y instead of overwriting. */
 int ape_bilinear_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
                           int yoff, int align_corners, int accumulate, void* stream);
+/* PSPUpsample (nn.Upsample x2 align_corners=True -> Conv2d 3x3 pad 1 -> PReLU, pspnet.py:27-37) restructured: the 3x3 conv's
+ * channel mixing runs at LOW resolution as a 1x1 conv producing z[B][h][w][9*C] (channel = tap*C + c, tap = ky*3+kx, made by
+ * ape_conv2d_* from the repacked weights W'[(tap,co)][ci]); this kernel resizes, shifts by the tap, sums, adds bias and
+ * applies the activation: out[B][2h][2w][C].  Exact up to fp32 rounding (conv and bilinear resize are both linear). */
+int ape_upconv3x3_gather_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
+                             void* stream);
 /* torch.gather(emb, 2, choose)               DenseFusion/lib/network.py:100-102.     y[b][i][:] = x[b][index[b][i]][:] */
 int ape_gather_rows_f32(const float* x, const int64_t* index, float* y, int B, int rows_in, int n, int C, void* stream);
 /* nn.LogSoftmax() over the channel run       DenseFusion/lib/pspnet.py:55.           rows x C, C contiguous */
