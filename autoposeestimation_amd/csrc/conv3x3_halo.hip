@@ -1,0 +1,302 @@
+// 3x3 stride-1 convolution (pad = dilation, dilation 1/2/4, Cin % 32 == 0) on the bf16 matrix cores with the input HALO tile
+// staged ONCE per 32-channel chunk in LDS and re-used by all nine filter taps.
+//
+// Why: the generic implicit-GEMM kernel (conv_bf16.hip) re-fetches the A operand for every tap and re-fetches the weights
+// for every 128-pixel tile; profiling showed it capped at ~9 TB/s of L2->CU operand traffic (30 KB per algorithmic MFLOP),
+// i.e. bandwidth-bound far below the MFMA rate.  Here one workgroup owns a 16x16-pixel output tile (BM = 256) x 128 output
+// channels:
+//   * A: the (16+2d)^2-pixel halo of the current 32-channel chunk is split to bf16 hi/lo while it is staged
+//        HBM -> registers -> LDS, then every tap reads its MFMA fragments from the SAME LDS image at a shifted pixel row
+//        (ds_read_b128 per fragment, row stride 80 B => at most 2-way bank conflicts at tile-row seams);
+//   * B: one [128 cout][32 ci] weight tile per tap, double-buffered in LDS, prefetched through registers under the MFMAs;
+//   * one s_barrier per tap; the next chunk's halo is fetched during taps 4..8 into the other A buffer (d = 1).
+// Operand traffic drops to ~9.8 KB per MFLOP (3x less), which moves the kernel from the L2 roof to the MFMA roof.
+// Numerics are identical to conv_bf16.hip (same split-bf16 x3 / plain bf16 products, fp32 accumulate), only the K order is
+// (channel chunk, tap) instead of (tap, channel) -- covered by the same conv tests.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TS = 16;          // output tile is TS x TS pixels
+constexpr int CK = 32;          // channels per chunk
+constexpr int LDH = CK + 8;     // bf16 per LDS row (80 B)
+constexpr int NTH = 512;        // 8 waves: BN = 128 -> 4 (pixels) x 2 (channels) of 64 px x 64 cout; BN = 64 -> 8 x 1 of 32 px x 64 cout
+
+struct HaloArgs {
+    const float* x;
+    const __bf16* w;
+    const float* bias;
+    const float* res;
+    float* y;
+    ape_conv_params p;
+    int Kp, tiles_x, tiles_y, n_tiles;
+    long plane_stride;
+};
+
+__device__ __forceinline__ float activate_h(float v, int act, float alpha)
+{
+    switch (act) {
+        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
+        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+template <int NSPLIT, int D, int BNH>
+__global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
+{
+    constexpr int NPL = NSPLIT == 3 ? 2 : 1;
+    constexpr int WNW = BNH / 64;               // waves along the channel axis (2 / 1)
+    constexpr int WMW = 8 / WNW;                // waves along the pixel axis (4 / 8)
+    constexpr int TMW = 256 / WMW / 32;         // 32-pixel MFMA tiles per wave (2 / 1)
+    constexpr int B_PASSES = (BNH * 4 + NTH - 1) / NTH;   // 16-B weight chunks per thread per plane (1; half the threads idle at BN = 64)
+    constexpr int HW_ = TS + 2 * D;            // halo width
+    constexpr int HP = HW_ * HW_;              // halo pixels
+    constexpr int A_ITEMS = (HP * (CK / 4) + NTH - 1) / NTH;   // float4 loads per thread per chunk
+    constexpr bool A_DOUBLE = (2 * NPL * HP * LDH * 2 + 2 * NPL * BNH * LDH * 2) <= 160 * 1024;
+    constexpr int NA = A_DOUBLE ? 2 : 1;
+
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    __bf16* As = smem;                                         // [NA][NPL][HP*LDH]
+    __bf16* Bs = smem + (size_t)NA * NPL * HP * LDH;           // [2][NPL][BNH*LDH]
+
+    const ape_conv_params& p = a.p;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int nwg = p.B * tiles_per_img * a.n_tiles;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const int n_tile = logical % a.n_tiles;
+    const int mt = logical / a.n_tiles;
+    const int b = mt / tiles_per_img, trem = mt - b * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TS, x0 = (trem % a.tiles_x) * TS;
+    const int n0 = n_tile * BNH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNW, wn = wave % WNW;
+
+    // ---- staging helpers -----------------------------------------------------------------------------------------
+    float4 areg[A_ITEMS];
+    uint4 breg[NPL];
+    auto load_a = [&](int ci0) {
+#pragma unroll
+        for (int j = 0; j < A_ITEMS; ++j) {
+            const int e = tid + NTH * j;
+            const int px = e >> 3, c4 = e & 7;
+            const int hy = px / HW_, hx = px - hy * HW_;
+            const int gy = y0 - D + hy, gx = x0 - D + hx;
+            const bool ok = e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned off = (unsigned)(((b * p.H + gy) * p.W + gx) * p.ldx + p.xoff + ci0 + c4 * 4);
+            areg[j] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_ITEMS; ++j) {
+            const int e = tid + NTH * j;
+            if (e >= HP * 8) continue;
+            const int px = e >> 3, c4 = e & 7;
+            const float4 v = areg[j];
+            bf16x4 hi, lo;
+            hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+            __bf16* dst = As + ((size_t)buf * NPL) * HP * LDH + px * LDH + c4 * 4;
+            *reinterpret_cast<bf16x4*>(dst) = hi;
+            if (NPL == 2) {
+                lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+                lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+                *reinterpret_cast<bf16x4*>(dst + HP * LDH) = lo;
+            }
+        }
+    };
+    // B tile: BNH rows x 32 k = 4 chunks of 8 per row: one 16-B chunk per thread per plane
+    static_assert(B_PASSES == 1, "B staging");
+    const int b_row = tid >> 2, b_k8 = tid & 3;
+    const bool b_active = b_row < BNH;
+    auto load_b = [&](int tap, int ci0) {
+        const int n = n0 + b_row;
+        const unsigned col = (unsigned)(tap * p.Cin + ci0 + b_k8 * 8);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            breg[pl] = (b_active && n < p.Cout) ? *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + (unsigned)(n * a.Kp) + col)
+                                  : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_b = [&](int buf) {
+        if (!b_active) return;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            *reinterpret_cast<uint4*>(Bs + ((size_t)buf * NPL + pl) * BNH * LDH + b_row * LDH + b_k8 * 8) = breg[pl];
+    };
+
+    f32x16 acc[TMW][2];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addressing: lane l -> pixel row r = l&31 of M-tile i (32 px = 2 tile rows of 16), k half h = l>>5
+    const int frow = lane & 31, fh = lane >> 5;
+    int a_pix[TMW];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const int pidx = wm * (32 * TMW) + i * 32 + frow;
+        a_pix[i] = (pidx >> 4) * HW_ + (pidx & 15);      // halo row index of the tap (0,0) source pixel
+    }
+    const int b_off = (wn * 64 + frow) * LDH + 8 * fh;   // each wave covers 64 output channels = two 32-wide N tiles
+
+    const int nchunks = p.Cin / CK;
+    // prologue: halo of chunk 0 and weights of (chunk 0, tap 0)
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+
+    int bbuf = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int abuf = A_DOUBLE ? (c & 1) : 0;
+        const __bf16* Ah = As + ((size_t)abuf * NPL) * HP * LDH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // prefetch the next weight tile (next tap, or tap 0 of the next chunk) and, mid-chunk, the next halo
+            const bool last = tap == 8;
+            const bool more = !(last && c + 1 == nchunks);
+            if (more) load_b(last ? 0 : tap + 1, last ? (c + 1) * CK : c * CK);
+            if (A_DOUBLE && tap == 4 && c + 1 < nchunks) load_a((c + 1) * CK);
+
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int shift = (ky * D) * HW_ + kx * D;
+            const __bf16* Bh = Bs + ((size_t)bbuf * NPL) * BNH * LDH;
+#pragma unroll
+            for (int s = 0; s < CK / 16; ++s) {
+                bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    const int ao = (a_pix[i] + shift) * LDH + s * 16 + 8 * fh;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
+                    if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(Ah + HP * LDH + ao);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + b_off + j * 32 * LDH + s * 16);
+                    if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(Bh + BNH * LDH + b_off + j * 32 * LDH + s * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (NPL == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) store_b(bbuf ^ 1);
+            if (A_DOUBLE && last && c + 1 < nchunks) store_a((c + 1) & 1);
+            __syncthreads();
+            bbuf ^= 1;
+        }
+        if (!A_DOUBLE && c + 1 < nchunks) {   // single A buffer (large dilation): refill between chunks
+            load_a((c + 1) * CK);
+            store_a(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + frow;
+        if (n >= p.Cout) continue;
+        const float bshared = (a.bias && p.bias_bstride == 0) ? a.bias[n] : 0.f;
+        const float bimg = (a.bias && p.bias_bstride != 0) ? a.bias[(size_t)b * p.bias_bstride + n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int pidx = wm * (32 * TMW) + i * 32 + row;
+                const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
+                if (gy >= p.Ho || gx >= p.Wo) continue;
+                const size_t m = ((size_t)b * p.Ho + gy) * p.Wo + gx;
+                float v = acc[i][j][e] + bshared + bimg;
+                if (a.res) v += a.res[m * p.ldr + p.roff + n];
+                a.y[m * p.ldy + p.yoff + n] = activate_h(v, p.act, p.alpha);
+            }
+        }
+    }
+}
+
+template <int NSPLIT, int D, int BNH>
+int launch_halo(const HaloArgs& a, hipStream_t st)
+{
+    constexpr int NPL = NSPLIT == 3 ? 2 : 1;
+    constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
+    constexpr bool A_DOUBLE = (2 * NPL * HP * LDH * 2 + 2 * NPL * BNH * LDH * 2) <= 160 * 1024;
+    constexpr size_t lds = ((A_DOUBLE ? 2 : 1) * NPL * HP * LDH + 2 * NPL * BNH * LDH) * 2;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            return APE_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int grid = a.p.B * a.tiles_x * a.tiles_y * a.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, st, a);
+    return ape::check_launch("ape_conv3x3_halo_bf16");
+}
+
+}  // namespace
+
+/* 1 if ape_conv3x3_halo_bf16 supports this geometry (3x3, stride 1, pad == dil in {1,2,4}, Cin % 32 == 0), else 0 */
+extern "C" int ape_conv3x3_halo_supported(const ape_conv_params* params)
+{
+    if (!params) return 0;
+    const ape_conv_params& p = *params;
+    return (p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) &&
+            p.Cin % CK == 0 && p.Cin >= CK && p.H == p.Ho && p.W == p.Wo) ? 1 : 0;
+}
+
+extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                                     const ape_conv_params* params, int nsplit, void* stream)
+{
+    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3)) return APE_EINVAL;
+    if (!ape_conv3x3_halo_supported(params)) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (p.B < 0 || p.H < 1 || p.W < 1 || p.Cout < 1) return APE_EINVAL;
+    if (p.ldx % 4 || p.xoff % 4 || p.xoff + p.Cin > p.ldx || p.yoff + p.Cout > p.ldy) return APE_EINVAL;
+    if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return APE_EINVAL;
+    if (p.B == 0) return APE_OK;
+    const long K = 9L * p.Cin, Kp = (K + 7) / 8 * 8;
+    if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * Kp >= (1L << 31)) return APE_EINVAL;
+    HaloArgs a;
+    a.x = x; a.w = (const __bf16*)w_packed; a.bias = bias; a.res = residual; a.y = y; a.p = p;
+    a.Kp = (int)Kp;
+    a.plane_stride = (long)p.Cout * Kp;
+    a.tiles_x = ape::ceil_div(p.W, TS);
+    a.tiles_y = ape::ceil_div(p.H, TS);
+    hipStream_t st = (hipStream_t)stream;
+    const bool narrow = p.Cout <= 64;
+    a.n_tiles = ape::ceil_div(p.Cout, narrow ? 64 : 128);
+#define HALO_DISPATCH(NS, DD) (narrow ? launch_halo<NS, DD, 64>(a, st) : launch_halo<NS, DD, 128>(a, st))
+    if (nsplit == 3) {
+        if (p.dil == 1) return HALO_DISPATCH(3, 1);
+        if (p.dil == 2) return HALO_DISPATCH(3, 2);
+        return HALO_DISPATCH(3, 4);
+    }
+    if (p.dil == 1) return HALO_DISPATCH(1, 1);
+    if (p.dil == 2) return HALO_DISPATCH(1, 2);
+    return HALO_DISPATCH(1, 4);
+#undef HALO_DISPATCH
+}

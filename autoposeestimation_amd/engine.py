@@ -41,6 +41,7 @@ PROFILE = None   # set to a LaunchProfile() to time conv launches
 #   "bf16x3" split-bf16, 3 products per term, ~2^-16 operand error      833 TFLOP/s effective peak
 #   "bf16"   plain bf16 operands (2^-8)                                 2.5 PFLOP/s peak
 PRECISIONS = ("f32", "bf16x3", "bf16")
+USE_HALO_KERNEL = True    # route eligible 3x3 convs of the bf16 paths to the LDS-halo kernel (conv3x3_halo.hip)
 
 
 def pack_conv_weight(w, device):
@@ -104,7 +105,16 @@ class Conv:
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.nsplit:
+        # the halo kernel tiles the image in 16x16 pixels: use it only when those tiles are mostly full (crop feature maps of
+        # 20x20 / 40x40 would waste 30..60 % of the MFMAs; the flattened-M generic kernel has no such edge effect)
+        halo = (self.nsplit and USE_HALO_KERNEL and (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256)
+                and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
+        if halo:
+            rc = _lib.lib().ape_conv3x3_halo_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
+                                                  _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
+                                                  self.nsplit, _st())
+            _lib.check(rc, "ape_conv3x3_halo_bf16")
+        elif self.nsplit:
             rc = _lib.lib().ape_conv2d_nhwc_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                  _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
                                                  self.nsplit, _st())
@@ -115,7 +125,7 @@ class Conv:
             _lib.check(rc, "ape_conv2d_nhwc_f32")
         if prof is not None:
             e1.record()
-            prof.records.append((self.variant, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+            prof.records.append(("conv3x3_halo_kernel<%d,%d>" % (self.nsplit, self.dil) if halo else self.variant, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
 
 

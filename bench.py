@@ -188,7 +188,7 @@ def main():
             ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
             # algorithmic flop (2*M*N*K of the convolution) against the peak of the instruction the kernel issues; a
             # split-bf16 kernel issues 3 bf16 MFMAs per algorithmic product, so its ceiling is the bf16 peak / 3
-            peak = PEAK_F32_MFMA_TFLOPS if "f32" in dom else PEAK_BF16_MFMA_TFLOPS / (3.0 if "<3," in dom else 1.0)
+            peak = PEAK_F32_MFMA_TFLOPS if "conv_f32" in dom else PEAK_BF16_MFMA_TFLOPS / (3.0 if "<3," in dom else 1.0)
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),

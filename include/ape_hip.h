@@ -77,6 +77,12 @@ long ape_packed_weights_bf16_elems(int cout, int K);
 int ape_pack_weights_bf16(const float* w, void* out, int cout, int K, void* stream);
 int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                          const ape_conv_params* params_host, int nsplit, void* stream);
+/* 3x3 / stride 1 / pad == dilation in {1,2,4} / Cin % 32 == 0 specialisation of ape_conv2d_nhwc_bf16: the input halo of
+ * a 16x16-pixel tile is staged once per 32-channel chunk in LDS and shared by the nine taps (3x less operand traffic).
+ * Same arguments, packed weights, numerics and epilogue; ape_conv3x3_halo_supported(params) says whether it applies. */
+int ape_conv3x3_halo_supported(const ape_conv_params* params_host);
+int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                          const ape_conv_params* params_host, int nsplit, void* stream);
 
 /* ---- HBM-bound glue of the PSPNet / PointNet graphs (NHWC f32, C multiple of 4) -----------------------------
  * nn.MaxPool2d(3, 2, 1)                      DenseFusion/lib/extractors.py:85,117.   y[B][Ho][Wo][C], Ho=(H-1)/2+1 */
