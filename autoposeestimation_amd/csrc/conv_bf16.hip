@@ -68,8 +68,14 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
     constexpr int B_ITEMS = BN / RPP;                  // 16-B chunks per thread per plane
     static_assert(B_ITEMS >= 1, "BN");
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[NPL][BM * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[NPL][BN * LD];
+    // ONE LDS array: operand tiles during the K loop, fp32 staging rows during the epilogue
+    constexpr int ELD = BN + 4;                         // floats per staged epilogue row
+    constexpr size_t kOperandBytes = (size_t)NPL * (BM + BN) * LD * 2, kStageBytes = (size_t)64 * ELD * 4;
+    __shared__ __attribute__((aligned(16))) char smem_raw[kOperandBytes > kStageBytes ? kOperandBytes : kStageBytes];
+    __bf16* const As0 = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* const Bs0 = As0 + NPL * BM * LD;
+    __bf16* As[2] = {As0, As0 + (NPL - 1) * BM * LD};
+    __bf16* Bs[2] = {Bs0, Bs0 + (NPL - 1) * BN * LD};
 
     const ape_conv_params& p = a.p;
     const int nwg = a.m_tiles * a.n_tiles;
@@ -225,22 +231,54 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
         }
     }
 
+    // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time, reusing the operand tiles) -> 16-byte coalesced stores with
+    // bias / residual / activation applied on float4s.  (Per-lane dword stores straight from the MFMA layout issued 64 store
+    // and up to 64 residual-load instructions per lane and held 1x1 layers with small K at ~1 TB/s of output bandwidth.)
+    float* stage = reinterpret_cast<float*>(smem_raw);
+    const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
+#pragma unroll 1
+    for (int half = 0; half < BM / 64; ++half) {
+        __syncthreads();
+        // waves whose rows fall in this half dump their tiles
+        if ((wm * (BM / WM)) / 64 == half || (BM / WM) > 64) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + frow;
-        if (n >= p.Cout) continue;
-        const float bshared = (a.bias && p.bias_bstride == 0) ? a.bias[n] : 0.f;
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = wm * (BM / WM) + i * 32;
+                if (rbase / 64 != half) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int m = m0 + wm * (BM / WM) + i * 32 + row;
-                if (m >= a.M) continue;
-                float v = acc[i][j][e] + bshared;
-                if (a.bias && p.bias_bstride != 0) v += a.bias[(size_t)(m / HoWo) * p.bias_bstride + n];
-                if (a.res) v += a.res[(size_t)m * p.ldr + p.roff + n];
-                a.y[(size_t)m * p.ldy + p.yoff + n] = activate(v, p.act, p.alpha);
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                        stage[(rbase - half * 64 + row) * ELD + wn * (BN / WN) + j * 32 + frow] = acc[i][j][e];
+                    }
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < 64 * (BN / 4); it += NT) {
+            const int row = it / (BN / 4), c4 = it - row * (BN / 4);
+            const int m = m0 + half * 64 + row, n = n0 + c4 * 4;
+            if (m >= a.M || n >= p.Cout) continue;
+            float4 v = *reinterpret_cast<const float4*>(&stage[row * ELD + c4 * 4]);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            const int nvalid = min(4, p.Cout - n);
+            const float* bptr = a.bias ? a.bias + (p.bias_bstride ? (size_t)(m / HoWo) * p.bias_bstride : 0) + n : nullptr;
+            if (vec_ok && nvalid == 4) {
+                if (bptr) { vv[0] += bptr[0]; vv[1] += bptr[1]; vv[2] += bptr[2]; vv[3] += bptr[3]; }
+                if (a.res) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res + (size_t)m * p.ldr + p.roff + n);
+                    vv[0] += r.x; vv[1] += r.y; vv[2] += r.z; vv[3] += r.w;
+                }
+                float4 o = make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha),
+                                       activate(vv[2], p.act, p.alpha), activate(vv[3], p.act, p.alpha));
+                *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o;
+            } else {
+                for (int k = 0; k < nvalid; ++k) {
+                    float t = vv[k];
+                    if (bptr) t += bptr[k];
+                    if (a.res) t += a.res[(size_t)m * p.ldr + p.roff + n + k];
+                    a.y[(size_t)m * p.ldy + p.yoff + n + k] = activate(t, p.act, p.alpha);
+                }
             }
         }
     }

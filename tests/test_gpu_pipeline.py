@@ -46,17 +46,23 @@ def _fit_segmentor(seg, seg_sd, frames):
     fw, fb = seg_sd["final.0.weight"].clone(), seg_sd["final.0.bias"].clone()
     fw[:13, :, 0, 0], fb[:13] = w, b
     seg_sd["final.0.weight"], seg_sd["final.0.bias"] = fw, fb
+    prec = seg.precision
     seg.load_state_dict(seg_sd)
-    return seg.cuda().eval(), seg_sd
+    return seg.cuda().eval().set_precision(prec), seg_sd
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("refine_mode", ["live_compat", "iterative"])
-def test_full_prediction_vs_oracle(refine_mode):
+def test_full_prediction_vs_oracle(refine_mode, precision):
+    """precision 'bf16x3' is the configuration bench.py measures (split-bf16 operands on the bf16 matrix cores)."""
     from autoposeestimation_amd.pipeline.utils import full_prediction
     seg, est, ref, seg_sd, est_sd, ref_sd = _models()
+    for m in (seg, est, ref):
+        m.set_precision(precision)
     frames = [S.synthetic_frame(100 + i, cls=c, box=bx, size=sz) for i, (c, bx, sz) in
               enumerate([(4, (150, 250), (150, 150)), (9, (40, 60), (70, 110))])]
     seg, seg_sd = _fit_segmentor(seg, seg_sd, frames)
+    seg.set_precision(precision)
     meta = S.REALSENSE_META
     for rgb, depth, label in frames:
         chosen = {}
