@@ -38,7 +38,7 @@ def make_frames(batch, rank):
         fid = rank * 100003 + i
         rng = np.random.default_rng(fid)
         box = (int(rng.integers(20, 480 - 150)), int(rng.integers(20, 640 - 150)))
-        frames.append(S.synthetic_frame(fid, cls=1 + (i % 6), box=box, size=(126, 126)))
+        frames.append(S.synthetic_frame(fid, cls=1 + (i % 3), box=box, size=(126, 126)))
     return frames
 
 
@@ -124,9 +124,11 @@ def main():
 
     from autoposeestimation_amd.pipeline.utils import FramePipeline
     frames = make_frames(args.batch, rank)
-    # six saturated, linearly separable colours (classes 1..6); channels 7..12 of the 13-way segmentor stay silent
+    # three primary colours (classes 1..3) that a LINEAR read-out of the frozen random features separates cleanly from the
+    # grey-noise background AND from each other's blurred borders (six colours left ~10 spurious >100-px detections per 64
+    # frames); channels 4..12 of the 13-way segmentor stay silent
     fit_frames = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 + 60 * c + 90 * k), size=(126, 126))
-                  for c in range(1, 7) for k in range(2)]
+                  for c in range(1, 4) for k in range(2)]
     seg, est, ref, seg_sd, est_sd, ref_sd = build_models(device, fit_frames)
     rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device)        # inputs resident in HBM
     depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device)
