@@ -40,6 +40,7 @@ SIGNATURES = {
     "ape_adds_select_f32": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P],
     "ape_recentre_qt_f32": [_P, _P, _P, _I, _P],
     "ape_seg_argmax_f32": [_P, _I, _I, _P, _P, _c.c_long, _I, _P],
+    "ape_seg_head_f32": [_P, _P, _P, _I, _P, _P, _c.c_long, _I, _P],
     "ape_seg_components_workspace_bytes": [_I, _I, _I, _I],
     "ape_seg_components": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_label_trust_counts": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],

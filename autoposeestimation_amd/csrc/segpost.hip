@@ -125,6 +125,7 @@ __global__ void ccl_compress_kernel(int* __restrict__ L, long npix)
 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kMaxCls = 64;
+constexpr int kMaxClsHead = 16;   // classes supported by the fused head kernel (registers)
 
 __global__ void seg_stats_kernel(const uint8_t* __restrict__ label, const float* __restrict__ score, const int* __restrict__ L,
                                  unsigned long long* __restrict__ sum, unsigned int* __restrict__ cnt,
@@ -380,6 +381,79 @@ __global__ __launch_bounds__(kT) void label_trust_kernel(const uint8_t* __restri
     if (threadIdx.x < 6 && lc[threadIdx.x]) atomicAdd(&counts[b * 6 + threadIdx.x], lc[threadIdx.x]);
 }
 
+// final 1x1 conv (64 -> C classes) + softmax (+ softmax) + argmax fused into one streaming pass over the 64-channel up_3
+// activation (pspnet.py:53-55 restricted to the first C rows, then pipeline/utils.py:429-435): the C x 480 x 640 logits are
+// never written.  The 64 -> 16 contraction runs on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32, D = W . X^T: rows =
+// classes, columns = 16 pixels): lane (px = l&15, kq = l>>4) loads four float4 of its pixel (k = 16 j + 4 kq + e), the 16
+// weight operands per lane stay in registers for the whole kernel, and each pixel's 16 logits end up 4 per lane on the four
+// lanes {px, px+16, px+32, px+48}, so max / arg-max / exp-sums need only two xor-shuffles.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+
+__global__ __launch_bounds__(kT) void seg_head_kernel(const float4* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      int C, uint8_t* __restrict__ label, float* __restrict__ score, long npix, int double_softmax)
+{
+    const int lane = threadIdx.x & 63;
+    const int px = lane & 15, kq = lane >> 4;
+    // A operand (weights): class = lane&15, k = 16 j + 4 kq + e  -> wreg[j*4+e]; rows >= C are zero
+    float wreg[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wreg[j * 4 + e] = px < C ? w[px * 64 + 16 * j + 4 * kq + e] : 0.f;
+    float breg[4];   // bias of this lane's four classes kq*4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) breg[r] = (kq * 4 + r < C && bias) ? bias[kq * 4 + r] : 0.f;
+
+    const long ngroups = (npix + 15) / 16;
+    const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long g = wave_id; g < ngroups; g += nwaves) {
+        const long p = g * 16 + px;
+        const bool in = p < npix;
+        float4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = in ? feat[p * 16 + 4 * j + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 acc = {breg[0], breg[1], breg[2], breg[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 0], x[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 1], x[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 2], x[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 3], x[j].w, acc, 0, 0, 0);
+        }
+        // acc[r] = logit of class kq*4 + r for pixel px (C/D map of 16x16x4: row = 4*(lane>>4) + r, col = lane&15)
+        float m = -__builtin_inff();
+        int am = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = kq * 4 + r;
+            if (c < C && acc[r] > m) { m = acc[r]; am = c; }      // ascending c: first maximum of this lane's four
+        }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float om = __shfl_xor(m, off);
+            const int oa = __shfl_xor(am, off);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }  // first maximum overall (torch.argmax on the CPU)
+        }
+        float e[4], s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? expf(acc[r] - m) : 0.f; s += e[r]; }
+        s = quad_sum(s);
+        float pm = 1.f / s;
+        if (double_softmax) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? expf(e[r] / s - pm) : 0.f;
+            pm = 1.f / quad_sum(s2);
+        }
+        if (in && kq == 0) {
+            label[p] = (uint8_t)am;
+            score[p] = pm;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float* score, long npix,
@@ -484,4 +558,17 @@ extern "C" int ape_label_trust_counts(const uint8_t* objmap, int cls, const uint
     hipLaunchKernelGGL(label_trust_kernel, dim3(gx, B), dim3(kT), 0, (hipStream_t)stream, objmap, cls, bs_label_or_null, depth,
                        gate_min_max, H, W, cut0, cut1, counts);
     return ape::check_launch("ape_label_trust_counts");
+}
+
+/* feat[npix][64] f32 (up_3 activation), w[C][64], bias[C] -> label u8, score f32; C <= 16 */
+extern "C" int ape_seg_head_f32(const float* feat, const float* w, const float* bias, int C, uint8_t* label, float* score, long npix,
+                                int double_softmax, void* stream)
+{
+    if (!feat || !w || !label || !score || C < 1 || C > kMaxClsHead || npix < 0) return APE_EINVAL;
+    if (npix == 0) return APE_OK;
+    long g = (npix / 16 + kT / 64 - 1) / (kT / 64);   // one wave per 16-pixel group, at most 8192 workgroups, grid-stride
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    hipLaunchKernelGGL(seg_head_kernel, dim3((int)g), dim3(kT), 0, (hipStream_t)stream, (const float4*)feat, w, bias, C, label, score,
+                       npix, double_softmax);
+    return ape::check_launch("ape_seg_head_f32");
 }

@@ -275,6 +275,19 @@ def seg_argmax(logits, n_classes, double_softmax=True):
     return label, score
 
 
+def seg_head(feat, w, bias, double_softmax=True):
+    """feat[B,H,W,64], w[C,64], bias[C] -> label[B,H,W] u8, score[B,H,W] f32 (fused final conv + softmax^2 + argmax)"""
+    b, h, wd, c = feat.shape
+    if c != 64:
+        raise ValueError("seg_head expects the 64-channel up_3 activation")
+    label = torch.empty(b, h, wd, dtype=torch.uint8, device=feat.device)
+    score = torch.empty(b, h, wd, dtype=torch.float32, device=feat.device)
+    rc = _lib.lib().ape_seg_head_f32(_lib.dptr(feat, torch.float32), _lib.dptr(w, torch.float32), _lib.dptr(bias), w.shape[0],
+                                     _lib.dptr(label), _lib.dptr(score), b * h * wd, int(bool(double_softmax)), _st())
+    _lib.check(rc, "ape_seg_head_f32")
+    return label, score
+
+
 _ws_cache = {}
 
 

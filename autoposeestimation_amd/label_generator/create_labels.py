@@ -48,7 +48,10 @@ def relabel_frames(model, rgb, depth, robot2cam, reference_point, class_id, bs_l
     rects = torch.zeros(b, 3, dtype=torch.int32)
     rects[:, 0] = torch.arange(b, dtype=torch.int32)
     x4 = E.preprocess_u8(rgb, rects.to(dev), h, w, div255=True)
-    label, score = E.seg_argmax(model.logits_nhwc(x4), n_cls, double_softmax=True)      # predict's softmax + F.softmax (:121-122)
+    if hasattr(model, "label_score_nhwc"):                                              # predict's softmax + F.softmax (:121-122)
+        label, score = model.label_score_nhwc(x4, double_softmax=True)
+    else:
+        label, score = E.seg_argmax(model.logits_nhwc(x4), n_cls, double_softmax=True)
     label = torch.where(label == target, label, torch.zeros_like(label))                # pred_arg[pred_arg != class_id+1] = 0 (:128)
     objmap, _ = E.seg_components(label, score, n_cls, min_pixels=0)                      # best mean-probability component (:131-141)
     pos = np.asarray(robot2cam, dtype=np.float64).reshape(b, 4, 4)[:, :3, 3]

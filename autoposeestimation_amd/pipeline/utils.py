@@ -47,10 +47,9 @@ class FramePipeline:
                 rects[:, 0] = torch.arange(b, dtype=torch.int32)
                 rects = self._full_rects[key] = rects.to(rgb.device)
             x4 = E.preprocess_u8(rgb, rects, h, w, div255=True)
-            logits = self.segmentor.logits_nhwc(x4)
+            label, score = self.segmentor.label_score_nhwc(x4, double_softmax=True)
         else:
-            logits = inject_logits
-        label, score = E.seg_argmax(logits, self.n_cls, double_softmax=True)
+            label, score = E.seg_argmax(inject_logits, self.n_cls, double_softmax=True)
         return E.seg_components(label, score, self.n_cls, self.min_pixels)
 
     # -- stage 2: pose for a list of detected objects --------------------------------------------------------------

@@ -37,12 +37,22 @@ class PsPNetSegmentor(PSPNet):
         # only the first `classes` rows of the final 1x1 conv are ever needed
         self._final_cls = E.Conv(sd["final.0.weight"][:self.classes], sd["final.0.bias"][:self.classes], device=dev,
                                  precision=self.precision)
+        self._head_w = sd["final.0.weight"][:self.classes].detach().to(dev, torch.float32).reshape(self.classes, 64).contiguous()
+        self._head_b = sd["final.0.bias"][:self.classes].detach().to(dev, torch.float32).contiguous()
         return pl
 
     def logits_nhwc(self, x4):
         """x4[B,H,W,4] (ToTensor+Normalize'd RGB, zero 4th channel) -> logits[B,H,W,classes]"""
         pl = self.plan()
         return self._final_cls(pl.features(x4))
+
+    def label_score_nhwc(self, x4, double_softmax=True):
+        """x4[B,H,W,4] -> (label u8[B,H,W], score f32[B,H,W]): features -> fused head (final conv rows 0..classes-1 in exact
+        fp32 + softmax(+softmax) + argmax); the logits tensor of `logits_nhwc` is never materialised."""
+        pl = self.plan()
+        if self.classes > 16:
+            return E.seg_argmax(self.logits_nhwc(x4), self.classes, double_softmax)
+        return E.seg_head(pl.features(x4), self._head_w, self._head_b, double_softmax)
 
     def predict(self, x):
         _need_cuda(x, "input")

@@ -151,6 +151,10 @@ int ape_recentre_qt_f32(const float* pts, const float* qt7, float* out, int n, v
  * score[npix] f32 = probability of the arg-max class after one (double_softmax=0) or two softmaxes. */
 int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float* score, long npix,
                        int double_softmax, void* stream);
+/* Fused segmentation head: the 64 -> C final 1x1 conv (pspnet.py:53-55, first C rows) + softmax(+softmax) + argmax in one
+ * pass over feat[npix][64] f32; same outputs as ape_conv2d_* followed by ape_seg_argmax_f32 without the logits tensor. C <= 16. */
+int ape_seg_head_f32(const float* feat, const float* w, const float* bias, int C, uint8_t* label, float* score, long npix,
+                     int double_softmax, void* stream);
 /* np.unique counts + cv2.connectedComponents(8) + best mean-probability component + mask + get_bbox
  *   pipeline/utils.py:437-469, DenseFusion/datasets/myDatasetAugmented/dataset.py:338-380.
  * label/score[B][H][W] -> objmap[B][H][W] u8 (class id inside the winning component of that class, else 0; the

@@ -174,3 +174,23 @@ def test_relabel_trust_checks_vs_numpy():
                 exp_save, exp = len(np.unique(want[30:H - 30, 50:W - 50])) > 1, want
             assert bool(save[i]) == exp_save, (cls, i)
             assert np.array_equal(labels[i], exp), (cls, i)
+
+
+def test_fused_seg_head_matches_conv_plus_argmax():
+    from autoposeestimation_amd import engine as E
+    torch.manual_seed(0)
+    feat = torch.randn(2, 96, 128, 64, device="cuda") * 2
+    w = torch.randn(13, 64, device="cuda") / 4
+    b = torch.randn(13, device="cuda")
+    label, score = E.seg_head(feat, w, b, double_softmax=True)
+    logits = (feat.double() @ w.double().t() + b.double())
+    p2 = torch.softmax(torch.softmax(logits, -1), -1)
+    top2 = logits.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-4
+    assert torch.equal(label[safe].long(), logits.argmax(-1)[safe])
+    np.testing.assert_allclose(score[safe].cpu().numpy(), p2.max(-1).values[safe].float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # and against the unfused device path
+    conv = E.Conv(w, b, device="cuda")
+    label2, score2 = E.seg_argmax(conv(feat), 13, double_softmax=True)
+    assert (label != label2).sum().item() <= 2
+    assert (score - score2).abs().max().item() < 1e-5
