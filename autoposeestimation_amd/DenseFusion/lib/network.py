@@ -139,7 +139,7 @@ class _PSPPlan:
             p = up(p)
             if taps is not None:
                 taps["up_%d" % (i + 1)] = p
-        p = self.up3(E.bilinear(p, p.shape[1] * 2, p.shape[2] * 2, True))
+        p = self.up3(p, upsample2x=True)     # bilinear x2 fused into the conv's halo load when the LDS-halo kernel applies
         if taps is not None:
             taps["up_3"] = p
         return p

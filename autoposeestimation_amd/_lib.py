@@ -66,7 +66,7 @@ class ConvParams(_c.Structure):
     """Mirror of `ape_conv_params` (include/ape_hip.h)."""
     _fields_ = [(n, _c.c_int32) for n in ("B", "H", "W", "Cin", "ldx", "xoff", "Ho", "Wo", "Cout", "ldy", "yoff",
                                           "KH", "KW", "stride", "pad", "dil", "act")] + \
-               [("alpha", _c.c_float), ("bias_bstride", _c.c_int32), ("ldr", _c.c_int32), ("roff", _c.c_int32)]
+               [("alpha", _c.c_float), ("bias_bstride", _c.c_int32), ("ldr", _c.c_int32), ("roff", _c.c_int32), ("ups", _c.c_int32)]
 
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3

@@ -47,7 +47,7 @@ __device__ __forceinline__ float activate_h(float v, int act, float alpha)
     }
 }
 
-template <int NSPLIT, int D, int BNH>
+template <int NSPLIT, int D, int BNH, bool UPS>
 __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
 {
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
@@ -83,17 +83,43 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
     // ---- staging helpers -----------------------------------------------------------------------------------------
     float4 areg[A_ITEMS];
     uint4 breg[NPL];
-    auto load_a = [&](int ci0) {
-#pragma unroll
-        for (int j = 0; j < A_ITEMS; ++j) {
-            const int e = tid + NTH * j;
-            const int px = e >> 3, c4 = e & 7;
-            const int hy = px / HW_, hx = px - hy * HW_;
-            const int gy = y0 - D + hy, gx = x0 - D + hx;
-            const bool ok = e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    // UPS: x is the half-resolution tensor; the halo pixel is its bilinear x2 (align_corners=True) sample, computed with the
+    // operation order of ops.hip:bilinear_kernel so the fused and unfused paths agree bit for bit.
+    const int hl = p.H / 2, wl = p.W / 2;
+    const float ups_sh = (UPS && p.H > 1) ? (float)(hl - 1) / (float)(p.H - 1) : 0.f;
+    const float ups_sw = (UPS && p.W > 1) ? (float)(wl - 1) / (float)(p.W - 1) : 0.f;
+    auto load_a_item = [&](int j, int ci0) {
+        const int e = tid + NTH * j;
+        const int px = e >> 3, c4 = e & 7;
+        const int hy = px / HW_, hx = px - hy * HW_;
+        const int gy = y0 - D + hy, gx = x0 - D + hx;
+        const bool ok = e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        if (!UPS) {
             const unsigned off = (unsigned)(((b * p.H + gy) * p.W + gx) * p.ldx + p.xoff + ci0 + c4 * 4);
             areg[j] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float fy = ups_sh * (float)gy, fx = ups_sw * (float)gx;
+                const int iy0 = (int)fy, ix0 = (int)fx;
+                const int iy1 = iy0 + (iy0 < hl - 1 ? 1 : 0), ix1 = ix0 + (ix0 < wl - 1 ? 1 : 0);
+                const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                const unsigned cofs = (unsigned)(p.xoff + ci0 + c4 * 4);
+                const float4 v00 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix0) * p.ldx) + cofs);
+                const float4 v01 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix1) * p.ldx) + cofs);
+                const float4 v10 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix0) * p.ldx) + cofs);
+                const float4 v11 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix1) * p.ldx) + cofs);
+                o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+                o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+                o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+                o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+            }
+            areg[j] = o;
         }
+    };
+    auto load_a = [&](int ci0) {
+#pragma unroll
+        for (int j = 0; j < A_ITEMS; ++j) load_a_item(j, ci0);
     };
     auto store_a = [&](int buf) {
 #pragma unroll
@@ -168,7 +194,16 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
             const bool last = tap == 8;
             const bool more = !(last && c + 1 == nchunks);
             if (more) load_b(last ? 0 : tap + 1, last ? (c + 1) * CK : c * CK);
-            if (A_DOUBLE && tap == 4 && c + 1 < nchunks) load_a((c + 1) * CK);
+            if (A_DOUBLE && c + 1 < nchunks) {
+                if (!UPS) {
+                    if (tap == 4) load_a((c + 1) * CK);
+                } else {
+                    // the fused up-sampling needs 4 loads + a lerp per item: one item per tap, so each tap's MFMAs cover it
+#pragma unroll
+                    for (int j = 0; j < A_ITEMS; ++j)
+                        if (tap == j + 1) load_a_item(j, (c + 1) * CK);
+                }
+            }
 
             const int ky = tap / 3, kx = tap - ky * 3;
             const int shift = (ky * D) * HW_ + kx * D;
@@ -234,7 +269,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
     }
 }
 
-template <int NSPLIT, int D, int BNH>
+template <int NSPLIT, int D, int BNH, bool UPS>
 int launch_halo(const HaloArgs& a, hipStream_t st)
 {
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
@@ -242,7 +277,8 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr bool A_DOUBLE = (2 * NPL * HP * LDH * 2 + 2 * NPL * BNH * LDH * 2) <= 160 * 1024;
     constexpr size_t lds = ((A_DOUBLE ? 2 : 1) * NPL * HP * LDH + 2 * NPL * BNH * LDH) * 2;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH>;
+    static_assert(!UPS || (A_DOUBLE && D == 1), "fused up-sampling is built for the double-buffered d = 1 kernel");
+    auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH, UPS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -279,6 +315,7 @@ extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const
     if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return APE_EINVAL;
     if (p.B == 0) return APE_OK;
     const long K = 9L * p.Cin, Kp = (K + 7) / 8 * 8;
+    if (p.ups != 0 && p.ups != 1) return APE_EINVAL;
     if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * Kp >= (1L << 31)) return APE_EINVAL;
     HaloArgs a;
     a.x = x; a.w = (const __bf16*)w_packed; a.bias = bias; a.res = residual; a.y = y; a.p = p;
@@ -289,7 +326,12 @@ extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = p.Cout <= 64;
     a.n_tiles = ape::ceil_div(p.Cout, narrow ? 64 : 128);
-#define HALO_DISPATCH(NS, DD) (narrow ? launch_halo<NS, DD, 64>(a, st) : launch_halo<NS, DD, 128>(a, st))
+#define HALO_DISPATCH(NS, DD) (narrow ? launch_halo<NS, DD, 64, false>(a, st) : launch_halo<NS, DD, 128, false>(a, st))
+    if (p.ups) {
+        if (p.dil != 1 || (p.H & 1) || (p.W & 1)) return APE_EINVAL;
+        if (nsplit == 3) return narrow ? launch_halo<3, 1, 64, true>(a, st) : launch_halo<3, 1, 128, true>(a, st);
+        return narrow ? launch_halo<1, 1, 64, true>(a, st) : launch_halo<1, 1, 128, true>(a, st);
+    }
     if (nsplit == 3) {
         if (p.dil == 1) return HALO_DISPATCH(3, 1);
         if (p.dil == 2) return HALO_DISPATCH(3, 2);

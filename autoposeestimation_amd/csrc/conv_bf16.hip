@@ -333,7 +333,7 @@ extern "C" int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const 
         return APE_EINVAL;
     if (p.Cin % 4 || p.ldx % 4 || p.xoff % 4 || p.xoff + p.Cin > p.ldx || p.yoff + p.Cout > p.ldy) return APE_EINVAL;
     if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
-    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return APE_EINVAL;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID || p.ups != 0) return APE_EINVAL;
     const int ho = (p.H + 2 * p.pad - p.dil * (p.KH - 1) - 1) / p.stride + 1;
     const int wo = (p.W + 2 * p.pad - p.dil * (p.KW - 1) - 1) / p.stride + 1;
     if (ho != p.Ho || wo != p.Wo) return APE_EINVAL;

@@ -86,9 +86,18 @@ class Conv:
         wo = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
         return ho, wo
 
-    def __call__(self, x, out=None, xoff=0, yoff=0, residual=None, roff=0, bias=None, bias_bstride=0, act=None):
-        """x[B,H,W,ldx] (reads channels xoff..xoff+cin) -> out[B,Ho,Wo,ldy] (writes yoff..yoff+cout)."""
+    def __call__(self, x, out=None, xoff=0, yoff=0, residual=None, roff=0, bias=None, bias_bstride=0, act=None, upsample2x=False):
+        """x[B,H,W,ldx] (reads channels xoff..xoff+cin) -> out[B,Ho,Wo,ldy] (writes yoff..yoff+cout).
+        upsample2x: the conv runs on the bilinear x2 (align_corners=True) up-sampling of x, fused into the LDS-halo kernel
+        when it applies, otherwise materialised by ape_bilinear_nhwc_f32 first."""
+        if upsample2x:
+            can_fuse = (self.nsplit and USE_HALO_KERNEL and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == 1
+                        and self.dil == 1 and self.cin % 32 == 0 and x.shape[3] == self.cin and xoff == 0)
+            if not can_fuse:
+                return self(bilinear(x, 2 * x.shape[1], 2 * x.shape[2], True), out, 0, yoff, residual, roff, bias, bias_bstride, act)
         b, h, w, ldx = x.shape
+        if upsample2x:
+            h, w = 2 * h, 2 * w
         ho, wo = self.out_hw(h, w)
         if out is None:
             out = torch.empty(b, ho, wo, self.cout, dtype=torch.float32, device=x.device)
@@ -100,14 +109,15 @@ class Conv:
         p = ConvParams(B=b, H=h, W=w, Cin=self.cin, ldx=ldx, xoff=xoff, Ho=ho, Wo=wo, Cout=self.cout,
                        ldy=out.shape[3], yoff=yoff, KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad,
                        dil=self.dil, act=self.act if act is None else act, alpha=self.alpha,
-                       bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff)
+                       bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff,
+                       ups=int(bool(upsample2x)))
         prof = PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         # the halo kernel tiles the image in 16x16 pixels: use it only when those tiles are mostly full (crop feature maps of
         # 20x20 / 40x40 would waste 30..60 % of the MFMAs; the flattened-M generic kernel has no such edge effect)
-        halo = (self.nsplit and USE_HALO_KERNEL and (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256)
+        halo = (self.nsplit and USE_HALO_KERNEL and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256))
                 and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
         if halo:
             rc = _lib.lib().ape_conv3x3_halo_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),

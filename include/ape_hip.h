@@ -64,6 +64,9 @@ typedef struct ape_conv_params {
     float alpha;            /* PReLU slope (pspnet.py:33, single parameter) */
     int32_t bias_bstride;
     int32_t ldr, roff;
+    int32_t ups;            /* 1: x is the LOW-resolution tensor [B][H/2][W/2][ldx] and the conv reads its bilinear x2
+                               (align_corners=True) up-sampling on the fly (nn.Upsample + Conv2d of pspnet.py:30-32 fused);
+                               only ape_conv3x3_halo_bf16 accepts it (H, W even), everything else requires 0 */
 } ape_conv_params;
 int ape_conv2d_nhwc_f32(const float* x, const float* w, const float* bias, const float* residual, float* y,
                         const ape_conv_params* params_host, void* stream);

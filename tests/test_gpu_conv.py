@@ -78,3 +78,24 @@ def test_conv_rejects_bad_geometry():
         conv(torch.zeros(1, 8, 8, 6, device="cuda"))         # ld not a multiple of 4
     with pytest.raises(ValueError):
         conv(torch.zeros(1, 8, 8, 8, device="cuda"), out=torch.zeros(1, 7, 8, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 64), (1, 17, 9, 32, 160)])
+def test_fused_upsample_conv_equals_materialised(shape, precision):
+    """nn.Upsample(x2, align_corners=True) + 3x3 conv (pspnet.py:30-32): the up-sampling fused into the LDS-halo kernel's
+    load must equal bilinear kernel -> same conv, bit for bit (same interpolation op order, same products)."""
+    from autoposeestimation_amd import engine as E
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(b, h, w, cin, generator=g) * 2).cuda()
+    conv = E.Conv(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, torch.randn(cout, generator=g), 1, 1, 1, E.ACT_PRELU,
+                  alpha=0.25, device="cuda", precision=precision)
+    fused = conv(x, upsample2x=True)
+    ref = conv(E.bilinear(x, 2 * h, 2 * w, True))
+    assert fused.shape == (b, 2 * h, 2 * w, cout)
+    assert torch.equal(fused, ref)
+    want = F.prelu(F.conv2d(F.interpolate(x.cpu().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True),
+                            conv.w.cpu().permute(0, 3, 1, 2), conv.bias.cpu(), 1, 1), torch.tensor([0.25])).permute(0, 2, 3, 1)
+    err = (fused.cpu() - want).abs().max().item() / want.abs().max().item()
+    assert err <= TOL[precision]
