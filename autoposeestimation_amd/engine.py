@@ -135,7 +135,8 @@ class Conv:
             _lib.check(rc, "ape_conv2d_nhwc_f32")
         if prof is not None:
             e1.record()
-            prof.records.append(("conv3x3_halo_kernel<%d,%d,%d>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128) if halo else self.variant, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+            prof.records.append(("conv3x3_halo_kernel<%d,%d,%d,%s>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
+                                 if halo else self.variant, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
 
 

@@ -32,6 +32,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA, dense"
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json, made by
+    tools/pmc_summary.py with the guide's FETCH_SIZE x2 gfx950 correction); None when no PMC run covers this kernel.
+    PMC collection cannot run inside bench.py itself (it needs rocprofv3 around the process)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            k = json.load(open(path))["kernels"].get(kernel.replace(" ", ""))
+        except (OSError, ValueError, KeyError):
+            continue
+        if k:
+            return k["hbm_bytes_per_launch"]
+    return None
+
+
 def make_frames(batch, rank):
     frames = []
     for i in range(batch):
@@ -192,7 +207,7 @@ def main():
             # split-bf16 kernel issues 3 bf16 MFMAs per algorithmic product, so its ceiling is the bf16 peak / 3
             peak = PEAK_F32_MFMA_TFLOPS if "conv_f32" in dom else PEAK_BF16_MFMA_TFLOPS / (3.0 if "<3," in dom else 1.0)
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
                         "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                         "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3),
                         "share_of_step_time": round(d["ms"] * 1e-3 / dt, 3)}
