@@ -83,6 +83,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
     // ---- staging helpers -----------------------------------------------------------------------------------------
     float4 areg[A_ITEMS];
     uint4 breg[NPL];
+    unsigned a_okmask = 0;      // bit j: item j of the pending halo lies inside the image (zero-filled at store time otherwise)
     // UPS: x is the half-resolution tensor; the halo pixel is its bilinear x2 (align_corners=True) sample, computed with the
     // operation order of ops.hip:bilinear_kernel so the fused and unfused paths agree bit for bit.
     const int hl = p.H / 2, wl = p.W / 2;
@@ -95,9 +96,12 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
         const int gy = y0 - D + hy, gx = x0 - D + hx;
         const bool ok = e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         if (!UPS) {
-            const unsigned off = (unsigned)(((b * p.H + gy) * p.W + gx) * p.ldx + p.xoff + ci0 + c4 * 4);
-            areg[j] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+            const unsigned off = (unsigned)(((b * p.H + cy) * p.W + cx) * p.ldx + p.xoff + ci0 + c4 * 4);
+            areg[j] = *reinterpret_cast<const float4*>(a.x + off);       // unconditional: see the note at load_b
+            a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
         } else {
+            a_okmask |= 1u << j;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) {
                 const float fy = ups_sh * (float)gy, fx = ups_sw * (float)gx;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
             const int e = tid + NTH * j;
             if (e >= HP * 8) continue;
             const int px = e >> 3, c4 = e & 7;
-            const float4 v = areg[j];
+            const float4 v = (a_okmask >> j) & 1u ? areg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             bf16x4 hi, lo;
             hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
             __bf16* dst = As + ((size_t)buf * NPL) * HP * LDH + px * LDH + c4 * 4;
@@ -143,19 +147,24 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
     static_assert(B_PASSES == 1, "B staging");
     const int b_row = tid >> 2, b_k8 = tid & 3;
     const bool b_active = b_row < BNH;
+    // Loads are UNCONDITIONAL (row clamped into range) and the zero-fill happens at LDS-store time: a `cond ? load : 0`
+    // makes hipcc branch around the load and wait vmcnt(0) right behind it, which serialises the prefetch with the MFMAs
+    // (cdna_hip_programming.md section 5, ".s-level traps", item (c)).
+    const int b_n = n0 + b_row;
+    const bool b_ok = b_active && b_n < p.Cout;
+    const unsigned b_rowoff = (unsigned)((b_n < p.Cout ? b_n : p.Cout - 1) * a.Kp);
     auto load_b = [&](int tap, int ci0) {
-        const int n = n0 + b_row;
         const unsigned col = (unsigned)(tap * p.Cin + ci0 + b_k8 * 8);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
-            breg[pl] = (b_active && n < p.Cout) ? *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + (unsigned)(n * a.Kp) + col)
-                                  : make_uint4(0u, 0u, 0u, 0u);
+            breg[pl] = *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + b_rowoff + col);
     };
     auto store_b = [&](int buf) {
         if (!b_active) return;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
-            *reinterpret_cast<uint4*>(Bs + ((size_t)buf * NPL + pl) * BNH * LDH + b_row * LDH + b_k8 * 8) = breg[pl];
+            *reinterpret_cast<uint4*>(Bs + ((size_t)buf * NPL + pl) * BNH * LDH + b_row * LDH + b_k8 * 8) =
+                b_ok ? breg[pl] : make_uint4(0u, 0u, 0u, 0u);
     };
 
     f32x16 acc[TMW][2];
