@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libape_hip.so")
+LIB_PATH = os.environ.get("APE_HIP_LIB", os.path.join(_HERE, "libape_hip.so"))   # env override: kernel A/B experiments
 
 _c = ctypes
 _P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double

@@ -30,7 +30,7 @@ def pack_results(n_frames, objects, pose, max_obj=1, device=None):
 
 def gather_results(local, dist=None):
     """all_gather of equally-shaped per-rank result blocks -> [world * frames_per_rank, max_obj, 8] in rank order."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local.contiguous())
