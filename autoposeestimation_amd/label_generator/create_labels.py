@@ -122,3 +122,125 @@ def pose_label(meta, pc_position, pc_rotation, object_name):
     cam2object = np.dot(cam2robot, robot2object)
     return {"position": list(cam2object[:3, 3]), "rotation": list(cam2object[:3, :3].flatten()), "cls_name": object_name,
             "cam2robot": list(cam2robot.flatten()), "robot2object": list(robot2object.flatten())}
+
+
+# ---- directory drivers with the reference's signatures (create_labels.py:40-289, :292-440) ----------------------------
+import json  # noqa: E402
+import time  # noqa: E402
+
+
+def create_pose_label(root, object_name, global_regression, icp_point2point, icp_point2plane, plot=False, view_label=False,
+                      with_extra=False):
+    """reference :292-440: per rotation directory find the object centre (bbox centre of `<obj>_out.ply`) and rotation
+    (object_pose of the directory's samples; for rotated directories refined by ICP of the fused cloud onto the directory's
+    cloud and constrained to the requested Euler axes), then write `<id>.meta.json` pose labels for every sample."""
+    from autoposeestimation_amd.data_generation import sample_io as io
+    from autoposeestimation_amd.pc_reconstruction import open3d_utils as pc_utils
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as pc
+    object_path = os.path.join(root, "data_generation/data", object_name)
+    dirs = sorted(os.listdir(object_path))
+    if "background" not in dirs:
+        raise ValueError("background does not exist in object_path: {}".format(object_path))
+    dirs.remove("background")
+    if "extra" in dirs:
+        dirs.remove("extra")
+        if with_extra:
+            dirs.append("extra")
+    if len(dirs) < 1:
+        raise ValueError("no foreground")
+    pc_path = os.path.join(root, "pc_reconstruction/data", object_name, "{}_out.ply".format(object_name))
+    remember = []
+    n_written = 0
+    for d in dirs:
+        pc_position = pc_rotation = None
+        data_path = os.path.join(object_path, d)
+        label_path = os.path.join(root, "label_generator/data", object_name, d)
+        samples = io.list_samples(data_path)
+        if d != "extra":
+            source = pc.read_point_cloud(pc_path)
+            pc_position = pc_utils.get_my_source_center(source)
+            pc_rotation = np.array(io.read_meta(data_path, samples[0]).get("object_pose"), dtype=np.float64).reshape(4, 4)[:3, :3]
+            old_rotation = np.rad2deg(mat2euler(pc_rotation))
+            if not np.array_equal(old_rotation, np.array([0.0, 0.0, 0.0])):
+                target = pc.read_point_cloud(os.path.join(root, "pc_reconstruction/data", object_name, "{}.ply".format(d)))
+                _, source, init_tf = pc_utils.icp_regression(target, source, voxel_size=5, threshold=10, global_regression=global_regression,
+                                                             icp_point2point=icp_point2point, icp_point2plane=icp_point2plane)
+                pc_rotation = constrain_rotation(pc_rotation, init_tf)
+                pc_position = np.array(pc_utils.get_my_source_center(source))
+            remember.append({"old_rotation": old_rotation, "pc_position": pc_position, "pc_rotation": pc_rotation})
+        for sid in samples:
+            meta = io.read_meta(data_path, sid)
+            if d == "extra":
+                rot = np.rad2deg(mat2euler(np.array(meta.get("object_pose"), dtype=np.float64).reshape(4, 4)[:3, :3]))
+                for r in remember:
+                    if np.array_equal(rot, r["old_rotation"]):
+                        pc_position, pc_rotation = r["pc_position"], r["pc_rotation"]
+                        break
+            os.makedirs(label_path, exist_ok=True)
+            with open(os.path.join(label_path, "{}.meta.json".format(sid)), "w") as f:
+                json.dump(pose_label(meta, pc_position, pc_rotation, object_name), f)
+            n_written += 1
+    return n_written
+
+
+def create_pose_data(root, classes, ds_name, reference_point=np.array([]), new_pred=True, get_extra_labels=False, plot=False,
+                     use_cuda=True, model=None, n_viewpoints=30, batch=16):
+    """reference :40-289 ("Create Pose labels"): per class (1) re-label every frame with the segmentor + trust checks
+    (`<id>.new_pred.label.png`), (2) fuse the selected views into the object's point cloud, (3) write the pose labels.
+    `model` (an already loaded segmentor) and `n_viewpoints` / `batch` are additions; everything else keeps the reference
+    names, defaults and hyper-parameters (:219-231)."""
+    from autoposeestimation_amd.data_generation import sample_io as io
+    from autoposeestimation_amd.pc_reconstruction.create_pointcloud import load_point_cloud
+    if not (torch.cuda.is_available() and use_cuda):
+        raise RuntimeError("create_pose_data needs the GPU: the MI355X path has no CPU fallback")
+    device = torch.device("cuda:0")
+    mode = "new_pred" if new_pred else "pred"
+    if model is None:
+        model = get_default_model(root, ds_name, len(classes) + 1)
+    model.to(device).eval()
+    stats = {"n_samples": 0, "n_extra_samples": 0, "bs_copied": 0, "no_depth_overlap": 0, "not_in_center": 0}
+    times = {"seg": [], "pc": [], "pose": []}
+    for class_id, cls in enumerate(classes):
+        data_path = os.path.join(root, "data_generation", "data", cls)
+        dirs = [d for d in sorted(os.listdir(data_path)) if d != "background" and (get_extra_labels or d != "extra")]
+        t0 = time.time()
+        for d in dirs:
+            if not (d == "extra" or new_pred):
+                continue
+            data_dir = os.path.join(data_path, d)
+            label_path = os.path.join(root, "label_generator/data", cls, d)
+            os.makedirs(label_path, exist_ok=True)
+            samples = io.list_samples(data_dir)
+            for s0 in range(0, len(samples), batch):
+                ids = samples[s0:s0 + batch]
+                rgb = torch.from_numpy(np.stack([io.read_color(data_dir, i) for i in ids])).to(device)
+                depth = torch.from_numpy(np.stack([io.read_depth(data_dir, i) for i in ids])).to(device)
+                r2c = np.stack([io.robot2cam(io.read_meta(data_dir, i)) for i in ids])
+                bs = None
+                if d != "extra":
+                    bs = torch.from_numpy(np.stack([io.read_label(label_path, i, "pred") for i in ids])).to(device)
+                labels, save, st = relabel_frames(model, rgb, depth, r2c, reference_point, class_id, bs, is_extra=(d == "extra"))
+                for k in ("bs_copied", "no_depth_overlap", "not_in_center"):
+                    stats[k] += st[k]
+                labels_h = labels.cpu().numpy()
+                for j, sid in enumerate(ids):
+                    new_png = os.path.join(label_path, "{}.new_pred.label.png".format(sid))
+                    if save[j]:
+                        stats["n_extra_samples" if d == "extra" else "n_samples"] += 1
+                        io.write_label(label_path, sid, "new_pred", labels_h[j])
+                    else:                                               # reference :206-214: drop stale outputs
+                        for stale in (new_png, os.path.join(label_path, "{}.meta.json".format(sid))):
+                            if os.path.exists(stale):
+                                os.remove(stale)
+        times["seg"].append(time.time() - t0)
+        t0 = time.time()
+        load_point_cloud(cls, os.path.join(root, "pc_reconstruction/data"), root, reference_point=reference_point, mode=mode,
+                         n_viewpoints=n_viewpoints, min_friends=20, min_dist=5, nb_neighbors=20, threshold=10, voxel_size=2,
+                         voxel_size_out=5, l_arrow=75, global_regression=False, icp_point2point=True, icp_point2plane=False)
+        times["pc"].append(time.time() - t0)
+        t0 = time.time()
+        create_pose_label(root, cls, False, True, False, plot=False, view_label=False, with_extra=get_extra_labels)
+        times["pose"].append(time.time() - t0)
+        print("class {}: seg {:.2f} s, pc {:.2f} s, pose {:.2f} s; stats {}".format(cls, times["seg"][-1], times["pc"][-1],
+                                                                                   times["pose"][-1], stats))
+    return stats, times

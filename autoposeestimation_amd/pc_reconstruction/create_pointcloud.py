@@ -91,4 +91,51 @@ def write_xyz(path, points):
             f.write("%s\n" % item)
 
 
-__all__ = ["get_view_distribution", "fuse_direction", "finish_object", "write_xyz", "pc"]
+def load_point_cloud(object_name, save_dir, root, reference_point=np.array([0, 0, 0]), mode="gen", n_viewpoints=10, min_friends=10,
+                     voxel_size=5, voxel_size_out=10, threshold=50, min_dist=10, nb_neighbors=5, l_arrow=30,
+                     global_regression=False, icp_point2point=True, icp_point2plane=True, plot=False, rng=None):
+    """Reference signature (pc_reconstruction/create_pointcloud.py:181-197) over the reference's directory layout:
+    for every rotation directory of `label_generator/data/<obj>` select `n_viewpoints` views, fuse them sequentially on the
+    GPU, rotate by the directory's object_pose, write `<d>.pcd/.ply`; then align the directories and export
+    `<obj>_out.{pcd,ply}`, the centred `<obj>.{pcd,ply}` and the >= 1000-point `<obj>.xyz`.  Returns the `_out` cloud."""
+    from autoposeestimation_amd.data_generation import sample_io as io
+    object_label_path = os.path.join(root, "label_generator/data", object_name)
+    dirs = [d for d in sorted(os.listdir(object_label_path)) if d != "extra"]
+    if not dirs:
+        raise ValueError("no labels obtained yet")
+    data_path = os.path.join(root, "data_generation/data", object_name)
+    pcd_path = os.path.join(save_dir, object_name)
+    os.makedirs(pcd_path, exist_ok=True)
+    n = len([f for f in os.listdir(os.path.join(object_label_path, dirs[0])) if ".{}.label.png".format(mode) in f])
+    point_clouds = []
+    for d in dirs:
+        metas = [io.read_meta(os.path.join(data_path, d), "{:06d}".format(i)) for i in range(n)]
+        cams = np.array([io.robot2cam(m)[:3, 3] for m in metas])
+        views, tf = [], None
+        for idx in get_view_distribution(cams, n_viewpoints, rng):
+            sid = "{:06d}".format(idx)
+            meta = metas[idx]
+            tf = np.array(meta.get("object_pose"), dtype=np.float64).reshape(4, 4)[:3, :3]
+            views.append((io.read_label(os.path.join(object_label_path, d), sid, mode), io.read_depth(os.path.join(data_path, d), sid),
+                          io.robot2cam(meta)))
+        intr = metas[0].get("intr")
+        cloud, _ = fuse_direction(views, intr, point_cloud_tf=tf, voxel_size=voxel_size, threshold=threshold, min_friends=min_friends,
+                                  min_dist=min_dist, nb_neighbors=nb_neighbors, icp_point2point=icp_point2point,
+                                  icp_point2plane=icp_point2plane)
+        if cloud is None:
+            raise ValueError("no valid surface in %s/%s" % (object_name, d))
+        pc.write_point_cloud(os.path.join(pcd_path, "{}.pcd".format(d)), cloud)
+        pc.write_point_cloud(os.path.join(pcd_path, "{}.ply".format(d)), cloud)
+        point_clouds.append(cloud.clone())
+    out, down, xyz = finish_object(point_clouds, min_friends=min_friends, min_dist=min_dist, nb_neighbors=nb_neighbors,
+                                   voxel_size=voxel_size, voxel_size_out=voxel_size_out, threshold=threshold)
+    for ext in ("pcd", "ply"):
+        pc.write_point_cloud(os.path.join(pcd_path, "{}_out.{}".format(object_name, ext)), out)
+        pc.write_point_cloud(os.path.join(pcd_path, "{}.{}".format(object_name, ext)), down)
+    write_xyz(os.path.join(pcd_path, "{}.xyz".format(object_name)), xyz)
+    return out
+
+
+import os  # noqa: E402
+
+__all__ = ["get_view_distribution", "fuse_direction", "finish_object", "write_xyz", "load_point_cloud", "pc"]

@@ -8,6 +8,7 @@ Points live on the GPU as a contiguous float64 [n,3] tensor; `np.array(pcd.point
 the host like open3d's Vector3dVector does; assigning `pcd.points = array` uploads.  No CPU fallback."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -368,3 +369,41 @@ def surface_points(label, depth, intr, robot2cam, device="cuda"):
     out = PointCloud(device=dev)
     out._p = buf[:int(cnt.item())].contiguous()
     return out
+
+
+# ---- o3d.io stand-ins: ASCII .ply / .pcd with xyz only (what the label path writes and reads back) ------------------
+def write_point_cloud(path, pcd):
+    pts = np.array(pcd.points, dtype=np.float64).reshape(-1, 3)
+    ext = os.path.splitext(path)[1].lower()
+    with open(path, "w") as f:
+        if ext == ".ply":
+            f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\nend_header\n" % len(pts))
+        elif ext == ".pcd":
+            f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\n"
+                    "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA ascii\n" % (len(pts), len(pts)))
+        else:
+            raise ValueError("unsupported point-cloud format %r" % ext)
+        for p in pts:
+            f.write("%.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+    return True
+
+
+def read_point_cloud(path, device="cuda"):
+    ext = os.path.splitext(path)[1].lower()
+    with open(path) as f:
+        lines = f.read().split("\n")
+    if ext == ".ply":
+        if "format ascii" not in "\n".join(lines[:10]):
+            raise ValueError("only ASCII .ply files are supported")
+        start = lines.index("end_header") + 1
+        n = int([ln for ln in lines[:start] if ln.startswith("element vertex")][0].split()[-1])
+    elif ext == ".pcd":
+        start = [i for i, ln in enumerate(lines) if ln.startswith("DATA")][0]
+        if "ascii" not in lines[start]:
+            raise ValueError("only ASCII .pcd files are supported")
+        n = int([ln for ln in lines[:start] if ln.startswith("POINTS")][0].split()[-1])
+        start += 1
+    else:
+        raise ValueError("unsupported point-cloud format %r" % ext)
+    pts = np.array([[float(v) for v in ln.split()[:3]] for ln in lines[start:start + n]], dtype=np.float64).reshape(-1, 3)
+    return PointCloud(pts, device=device)
