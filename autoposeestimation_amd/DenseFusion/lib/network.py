@@ -128,11 +128,8 @@ class _PSPPlan:
             y = c2(c1(y), residual=res)
         f = y
         b, h, w, _ = f.shape
-        acc = None
-        for i, s in enumerate((1, 2, 3, 6)):
-            z = self.bott_prior[i](self.stage[i](E.adaptive_avgpool(f, s)))
-            acc = E.bilinear(z, h, w, False, out=acc, accumulate=acc is not None)
-        p = self.bott_feats(f, residual=acc)
+        zs = [self.bott_prior[i](self.stage[i](E.adaptive_avgpool(f, s))) for i, s in enumerate((1, 2, 3, 6))]
+        p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w))
         if taps is not None:
             taps["feats"], taps["psp"] = f, p
         for i, up in enumerate(self.up):

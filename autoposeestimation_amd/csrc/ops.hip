@@ -249,6 +249,41 @@ __global__ void upconv_gather_kernel(const float4* __restrict__ z, const float* 
     }
 }
 
+// sum of the four PSP priors, each up-sampled bilinearly (align_corners=False) from its s x s map (s = 1,2,3,6) to h x w:
+// one pass writing the result once, instead of four read-modify-write passes over the [B,h,w,C] accumulator (pspnet.py:22).
+__global__ void psp_prior_sum_kernel(const float4* __restrict__ z1, const float4* __restrict__ z2, const float4* __restrict__ z3,
+                                     const float4* __restrict__ z6, float4* __restrict__ out, int B, int h, int w, int C4)
+{
+    const long total = (long)B * h * w * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        long t = i / C4;
+        const int ox = t % w; t /= w;
+        const int oy = t % h;
+        const int b = t / h;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* zs[4] = {z1, z2, z3, z6};
+        const int ss[4] = {1, 2, 3, 6};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int S = ss[k];
+            const float fy = src_index(oy, (float)S / (float)h, false), fx = src_index(ox, (float)S / (float)w, false);
+            const int iy0 = (int)fy, ix0 = (int)fx;
+            const int iy1 = iy0 + (iy0 < S - 1 ? 1 : 0), ix1 = ix0 + (ix0 < S - 1 ? 1 : 0);
+            const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float4* z = zs[k] + (long)b * S * S * C4;
+            const float4 v00 = z[(iy0 * S + ix0) * C4 + c], v01 = z[(iy0 * S + ix1) * C4 + c];
+            const float4 v10 = z[(iy1 * S + ix0) * C4 + c], v11 = z[(iy1 * S + ix1) * C4 + c];
+            // same order as four accumulating bilinear passes: acc = (((p1) + p2) + p3) + p6
+            acc.x += ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+            acc.y += ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+            acc.z += ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+            acc.w += ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        }
+        out[i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int ape_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream)
@@ -351,4 +386,15 @@ extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float
     hipLaunchKernelGGL(upconv_gather_kernel, dim3((int)g), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
                        h, w, C / 4, sh, sw, act, alpha);
     return ape::check_launch("ape_upconv3x3_gather_f32");
+}
+
+extern "C" int ape_psp_prior_sum_f32(const float* z1, const float* z2, const float* z3, const float* z6, float* out, int B, int h,
+                                     int w, int C, void* stream)
+{
+    if (!z1 || !z2 || !z3 || !z6 || !out || B < 0 || h < 1 || w < 1 || C < 4 || C % 4) return APE_EINVAL;
+    const long total = (long)B * h * w * (C / 4);
+    if (total == 0) return APE_OK;
+    hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)z1,
+                       (const float4*)z2, (const float4*)z3, (const float4*)z6, (float4*)out, B, h, w, C / 4);
+    return ape::check_launch("ape_psp_prior_sum_f32");
 }

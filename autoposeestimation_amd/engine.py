@@ -168,6 +168,15 @@ def bilinear(x, ho, wo, align_corners, out=None, yoff=0, accumulate=False):
     return out
 
 
+def psp_prior_sum(zs, h, w):
+    """zs = [z1[B,1,1,C], z2[B,2,2,C], z3[B,3,3,C], z6[B,6,6,C]] -> sum of their bilinear (align_corners=False) resizes [B,h,w,C]"""
+    b, c = zs[0].shape[0], zs[0].shape[3]
+    out = torch.empty(b, h, w, c, dtype=torch.float32, device=zs[0].device)
+    rc = _lib.lib().ape_psp_prior_sum_f32(*[_lib.dptr(z, torch.float32) for z in zs], _lib.dptr(out), b, h, w, c, _st())
+    _lib.check(rc, "ape_psp_prior_sum_f32")
+    return out
+
+
 class UpConv:
     """PSPUpsample (pspnet.py:27-37) as  1x1 conv at low resolution (9*Cout channels) + ape_upconv3x3_gather_f32."""
 

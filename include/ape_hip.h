@@ -97,6 +97,10 @@ int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W,
  * concat buffer, pspnet.py:22-23); accumulate != 0 adds into y instead of overwriting. */
 int ape_bilinear_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
                           int yoff, int align_corners, int accumulate, void* stream);
+/* sum over the four PSP priors of F.upsample(prior_s, size=(h,w), 'bilinear') (pspnet.py:22, align_corners=False), z_s[B][s][s][C]
+ * for s = 1,2,3,6 -> out[B][h][w][C]; one pass instead of four accumulating ape_bilinear_nhwc_f32 passes, same summation order */
+int ape_psp_prior_sum_f32(const float* z1, const float* z2, const float* z3, const float* z6, float* out, int B, int h,
+                          int w, int C, void* stream);
 /* PSPUpsample (nn.Upsample x2 align_corners=True -> Conv2d 3x3 pad 1 -> PReLU, pspnet.py:27-37) restructured: the 3x3 conv's
  * channel mixing runs at LOW resolution as a 1x1 conv producing z[B][h][w][9*C] (channel = tap*C + c, tap = ky*3+kx, made by
  * ape_conv2d_* from the repacked weights W'[(tap,co)][ci]); this kernel resizes, shifts by the tap, sums, adds bias and
