@@ -23,10 +23,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128;
-constexpr int BK = 64;
-constexpr int LD = BK + 8;  // bf16 elements per LDS row (144 B = 9 x 16-B slots, odd)
-constexpr int NT = 256;
+// tile shapes: <BM=128, BN<=128, BK=64, 4 waves> for everything, <BM=256, BN=256, BK=32, 8 waves> for big GEMM-like layers
+// (Cout >= 256, M large): a 256x256 tile fetches 16 KB of operands per algorithmic MFLOP instead of 30 KB -- these layers
+// (1x1 convs with K = 256..1024) sit on the ~9 TB/s L2->CU operand roof, not on the MFMA roof.
 
 struct ConvArgsB {
     const float* x;
@@ -56,15 +55,18 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo)
     lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
 }
 
-template <int NSPLIT, int BN, int WM, int WN>
-__global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
+template <int NSPLIT, int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB a)
 {
+    constexpr int NT = WM * WN * 64;
+    constexpr int LD = BK + 8;   // bf16 per LDS row: 144 B (BK = 64) or 80 B (BK = 32), an odd number of 16-B slots
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;           // operand planes (hi [, lo])
     constexpr int CPR = BK / 8;                        // 16-B (8 x bf16) chunks per tile row
     constexpr int RPP = NT / CPR;                      // rows covered per pass of the 256 threads (32)
     constexpr int A_ROWS = BM / RPP;                   // rows per thread
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % 64 == 0, "tile/staging shape");
     constexpr int B_ITEMS = BN / RPP;                  // 16-B chunks per thread per plane
     static_assert(B_ITEMS >= 1, "BN");
 
@@ -112,63 +114,74 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
 
     float4 areg[A_ROWS][2];
     uint4 breg[NPL][B_ITEMS];
-    // Fast path (every layer but the 4-channel stem / xyz inputs): Cin is a multiple of BK, so a whole k-tile lies inside
-    // ONE filter tap and (ky, kx, ci0) advance incrementally in scalar registers -- no per-lane integer division.
+    // Every global load below is UNCONDITIONAL (coordinates clamped into the tensor) and the zero-fill of halo / tail elements
+    // happens when the registers are written to LDS, from predicate bits saved here.  A `cond ? load : 0` makes hipcc wait
+    // vmcnt(0) right behind the load (the select needs the value), which exposed the full A-tile latency on every k-tile
+    // instead of hiding it under the MFMAs (cdna_hip_programming.md section 5, ".s-level traps", item (c)).
+    unsigned a_okmask = 0, b_okmask = 0;
     const bool tap_uniform = (p.Cin % BK) == 0;
-    int t_ci0 = 0, t_kx = 0, t_ky = 0;      // tap state of the NEXT tile to load (wave-uniform)
+    int t_ci0 = 0, t_kx = 0, t_ky = 0;      // tap state of the NEXT tile to load (wave-uniform), K order = (chunk, ky, kx)
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
     auto load_tiles = [&](int kt) {
         int t_kb = 0;
+        a_okmask = 0;
         if (tap_uniform) {
+            // Cin is a multiple of BK: a whole k-tile lies inside ONE filter tap and (ky, kx, ci0) advance incrementally in
+            // scalar registers -- no per-lane integer division.  The KH*KW consecutive k-tiles of one channel chunk re-read the
+            // same 128-B lines of x shifted by one pixel / row, so they hit L1/L2.
             const int dy = t_ky * p.dil, dx = t_kx * p.dil;
-            const bool kin = kt * BK < a.K;
             t_kb = (t_ky * p.KW + t_kx) * p.Cin + t_ci0;      // column of w[Cout][KH][KW][Cin] for this (tap, chunk)
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-                const bool ok = kin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const unsigned off = (unsigned)(((a_base[i] + iy) * p.W + ix) * p.ldx + p.xoff + t_ci0 + k8 * 8);
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = (unsigned)(((a_base[i] + clampi(iy, p.H - 1)) * p.W + clampi(ix, p.W - 1)) * p.ldx + p.xoff + t_ci0 + k8 * 8);
                 const float4* src = reinterpret_cast<const float4*>(a.x + off);
-                areg[i][0] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-                areg[i][1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                areg[i][0] = src[0];
+                areg[i][1] = src[1];
+                a_okmask |= ok ? (3u << (2 * i)) : 0u;
             }
-            // K order = channel chunk OUTER, filter tap INNER: the KH*KW consecutive k-tiles of one 32-channel chunk re-read
-            // the same 128-B lines of x shifted by one pixel / one image row, so they hit L1/L2 instead of the fabric
-            // (tap-outer order re-streams the whole Cin run of every pixel KH*KW times, 32..288 k-tiles apart).
             if (++t_kx == p.KW) { t_kx = 0; if (++t_ky == p.KH) { t_ky = 0; t_ci0 += BK; } }
         } else {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {   // the two float4 halves of the 8-element chunk may sit in different taps (Cin = 4)
                 const int k = kt * BK + k8 * 8 + hf * 4;
                 const bool kin = k < a.K;
-                const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                const int kc = kin ? k : 0;
+                const int tap = kc / p.Cin, ci = kc - tap * p.Cin;
                 const int ky = tap / p.KW, kx = tap - ky * p.KW;
                 const int dy = ky * p.dil, dx = kx * p.dil;
 #pragma unroll
                 for (int i = 0; i < A_ROWS; ++i) {
                     const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
                     const bool ok = kin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    const unsigned off = (unsigned)(((a_base[i] + iy) * p.W + ix) * p.ldx + p.xoff + ci);
-                    areg[i][hf] = ok ? *reinterpret_cast<const float4*>(a.x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const unsigned off = (unsigned)(((a_base[i] + clampi(iy, p.H - 1)) * p.W + clampi(ix, p.W - 1)) * p.ldx + p.xoff + ci);
+                    areg[i][hf] = *reinterpret_cast<const float4*>(a.x + off);
+                    a_okmask |= ok ? (1u << (2 * i + hf)) : 0u;
                 }
             }
         }
         const int kb = (tap_uniform ? t_kb : kt * BK) + k8 * 8;
+        const bool kb_ok = kb < a.Kp;
+        const unsigned kbc = (unsigned)(kb_ok ? kb : 0);
+        b_okmask = 0;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < B_ITEMS; ++i) {
                 const int n = n0 + srow + RPP * i;
-                const bool ok = n < p.Cout && kb < a.Kp;
-                breg[pl][i] = ok ? *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + (unsigned)(n * a.Kp + kb))
-                                 : make_uint4(0u, 0u, 0u, 0u);
+                const bool ok = kb_ok && n < p.Cout;
+                breg[pl][i] = *reinterpret_cast<const uint4*>(a.w + pl * a.plane_stride + (unsigned)((n < p.Cout ? n : p.Cout - 1) * a.Kp) + kbc);
+                b_okmask |= ok ? (1u << i) : 0u;
             }
     };
     auto store_tiles = [&]() {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             bf16x4 h0, l0, h1, l1;
-            split4(areg[i][0], h0, l0);
-            split4(areg[i][1], h1, l1);
+            split4((a_okmask >> (2 * i)) & 1u ? areg[i][0] : z4, h0, l0);
+            split4((a_okmask >> (2 * i + 1)) & 1u ? areg[i][1] : z4, h1, l1);
             bf16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { hi[e] = h0[e]; hi[4 + e] = h1[e]; lo[e] = l0[e]; lo[4 + e] = l1[e]; }
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < B_ITEMS; ++i)
-                *reinterpret_cast<uint4*>(&Bs[pl][(srow + RPP * i) * LD + k8 * 8]) = breg[pl][i];
+                *reinterpret_cast<uint4*>(&Bs[pl][(srow + RPP * i) * LD + k8 * 8]) =
+                    (b_okmask >> i) & 1u ? breg[pl][i] : make_uint4(0u, 0u, 0u, 0u);
     };
 
     f32x16 acc[TM][TN];
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
     for (int half = 0; half < BM / 64; ++half) {
         __syncthreads();
         // waves whose rows fall in this half dump their tiles
-        if ((wm * (BM / WM)) / 64 == half || (BM / WM) > 64) {
+        {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int rbase = wm * (BM / WM) + i * 32;
@@ -284,10 +298,10 @@ __global__ __launch_bounds__(NT) void conv_bf16_kernel(const ConvArgsB a)
     }
 }
 
-template <int NSPLIT, int BN, int WM, int WN>
+template <int NSPLIT, int BM, int BN, int WM, int WN, int BK>
 void launch(const ConvArgsB& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_bf16_kernel<NSPLIT, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((conv_bf16_kernel<NSPLIT, BM, BN, WM, WN, BK>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int K, int Kp)
@@ -349,14 +363,21 @@ extern "C" int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const 
     a.K = p.KH * p.KW * p.Cin;
     a.Kp = (a.K + 7) / 8 * 8;
     a.plane_stride = (long)p.Cout * a.Kp;
-    a.m_tiles = ape::ceil_div(M, BM);
     hipStream_t st = (hipStream_t)stream;
-    if (p.Cout > 64) {
+    // 256x256 tiles when they are mostly full: Cout a (near) multiple of 256 and enough rows to fill the chip
+    const int waste256 = ape::ceil_div(p.Cout, 256) * 256 - p.Cout;
+    if (p.Cout >= 256 && waste256 * 8 <= p.Cout && M >= 256L * 256) {
+        a.m_tiles = ape::ceil_div(M, 256);
+        a.n_tiles = ape::ceil_div(p.Cout, 256);
+        if (nsplit == 3) launch<3, 256, 256, 4, 2, 32>(a, st); else launch<1, 256, 256, 4, 2, 32>(a, st);
+    } else if (p.Cout > 64) {
+        a.m_tiles = ape::ceil_div(M, 128);
         a.n_tiles = ape::ceil_div(p.Cout, 128);
-        if (nsplit == 3) launch<3, 128, 2, 2>(a, st); else launch<1, 128, 2, 2>(a, st);
+        if (nsplit == 3) launch<3, 128, 128, 2, 2, 64>(a, st); else launch<1, 128, 128, 2, 2, 64>(a, st);
     } else {
+        a.m_tiles = ape::ceil_div(M, 128);
         a.n_tiles = 1;
-        if (nsplit == 3) launch<3, 64, 4, 1>(a, st); else launch<1, 64, 4, 1>(a, st);
+        if (nsplit == 3) launch<3, 128, 64, 4, 1, 64>(a, st); else launch<1, 128, 64, 4, 1, 64>(a, st);
     }
     return ape::check_launch("ape_conv2d_nhwc_bf16");
 }

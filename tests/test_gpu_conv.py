@@ -22,6 +22,7 @@ CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil
     (1, 17, 23, 64, 33, 3, 1, 1, 1),     # Cout = 33
     (1, 8, 8, 8, 13, 1, 1, 0, 1),        # tiny Cout (segmentor final conv)
     (5, 1, 1, 1024, 512, 1, 1, 0, 1),    # Linear on B rows
+    (1, 260, 256, 64, 288, 1, 1, 0, 1),  # M >= 65536 and Cout >= 256: the 256x256-tile variant, ragged in M and N
 ]
 
 
