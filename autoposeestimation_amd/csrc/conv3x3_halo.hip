@@ -7,7 +7,7 @@
 // channels:
 //   * A: the (16+2d)^2-pixel halo of the current 32-channel chunk is split to bf16 hi/lo while it is staged
 //        HBM -> registers -> LDS, then every tap reads its MFMA fragments from the SAME LDS image at a shifted pixel row
-//        (ds_read_b128 per fragment, row stride 80 B => at most 2-way bank conflicts at tile-row seams);
+//        (ds_read_b128 per fragment; 64-B rows with XOR-swizzled 16-B chunks => conflict-free reads and writes except 2-way at tile-row seams);
 //   * B: one [128 cout][32 ci] weight tile per tap, double-buffered in LDS, prefetched through registers under the MFMAs;
 //   * one s_barrier per tap; the next chunk's halo is fetched during taps 4..8 into the other A buffer (d = 1).
 // Operand traffic drops to ~9.8 KB per MFLOP (3x less), which moves the kernel from the L2 roof to the MFMA roof.
@@ -23,7 +23,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TS = 16;          // output tile is TS x TS pixels
 constexpr int CK = 32;          // channels per chunk
-constexpr int LDH = CK + 8;     // bf16 per LDS row (80 B)
+constexpr int LDH = CK;         // bf16 per LDS row: 64 B, UNPADDED; the four 16-B chunks of a row are XOR-swizzled with (row>>2)&3
+                                // (a padded 80-B stride made every ds_write 2-way bank-conflicted: 38 % of the LDS cycles)
+__device__ __forceinline__ int swz(int row, int chunk16) { return row * LDH + ((chunk16 ^ ((row >> 2) & 3)) << 3); }
 constexpr int NTH = 512;        // 8 waves: BN = 128 -> 4 (pixels) x 2 (channels) of 64 px x 64 cout; BN = 64 -> 8 x 1 of 32 px x 64 cout
 
 struct HaloArgs {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
             const float4 v = (a_okmask >> j) & 1u ? areg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             bf16x4 hi, lo;
             hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-            __bf16* dst = As + ((size_t)buf * NPL) * HP * LDH + px * LDH + c4 * 4;
+            __bf16* dst = As + ((size_t)buf * NPL) * HP * LDH + swz(px, c4 >> 1) + (c4 & 1) * 4;
             *reinterpret_cast<bf16x4*>(dst) = hi;
             if (NPL == 2) {
                 lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
         if (!b_active) return;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
-            *reinterpret_cast<uint4*>(Bs + ((size_t)buf * NPL + pl) * BNH * LDH + b_row * LDH + b_k8 * 8) =
+            *reinterpret_cast<uint4*>(Bs + ((size_t)buf * NPL + pl) * BNH * LDH + swz(b_row, b_k8)) =
                 b_ok ? breg[pl] : make_uint4(0u, 0u, 0u, 0u);
     };
 
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
         const int pidx = wm * (32 * TMW) + i * 32 + frow;
         a_pix[i] = (pidx >> 4) * HW_ + (pidx & 15);      // halo row index of the tap (0,0) source pixel
     }
-    const int b_off = (wn * 64 + frow) * LDH + 8 * fh;   // each wave covers 64 output channels = two 32-wide N tiles
+    const int b_row0 = wn * 64 + frow;   // each wave covers 64 output channels = two 32-wide N tiles
 
     const int nchunks = p.Cin / CK;
     // prologue: halo of chunk 0 and weights of (chunk 0, tap 0)
@@ -222,14 +224,15 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
                 bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) {
-                    const int ao = (a_pix[i] + shift) * LDH + s * 16 + 8 * fh;
+                    const int ao = swz(a_pix[i] + shift, 2 * s + fh);
                     ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
                     if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(Ah + HP * LDH + ao);
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + b_off + j * 32 * LDH + s * 16);
-                    if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(Bh + BNH * LDH + b_off + j * 32 * LDH + s * 16);
+                    const int bo = swz(b_row0 + j * 32, 2 * s + fh);
+                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + bo);
+                    if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(Bh + BNH * LDH + bo);
                 }
 #pragma unroll
                 for (int i = 0; i < TMW; ++i)

@@ -23,6 +23,10 @@ CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil
     (1, 8, 8, 8, 13, 1, 1, 0, 1),        # tiny Cout (segmentor final conv)
     (5, 1, 1, 1024, 512, 1, 1, 0, 1),    # Linear on B rows
     (1, 260, 256, 64, 288, 1, 1, 0, 1),  # M >= 65536 and Cout >= 256: the 256x256-tile variant, ragged in M and N
+    (2, 32, 48, 64, 256, 3, 1, 1, 1),    # LDS-halo kernel (full 16x16 tiles), two N tiles
+    (1, 30, 45, 32, 200, 3, 1, 2, 2),    # halo kernel, dilation 2, ragged tiles (94 % full) and ragged Cout
+    (1, 48, 32, 96, 130, 3, 1, 4, 4),    # halo kernel, dilation 4
+    (3, 16, 16, 64, 64, 3, 1, 1, 1),     # halo kernel, BN = 64 variant
 ]
 
 
