@@ -318,7 +318,7 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = (str(device), "seg")
+    key = (str(device), "seg", torch.cuda.current_stream().cuda_stream)   # one workspace per stream: sub-batches may overlap
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
