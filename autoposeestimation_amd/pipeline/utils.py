@@ -183,6 +183,39 @@ def full_prediction(image, depth, meta, segmentor, estimator, refiner, to_tensor
     return output_dict
 
 
+def _axangle2mat(axis, angle):
+    """transforms3d.axangles.axangle2mat (Rodrigues), as used at pipeline/utils.py:390 -- UNPINNED third-party maths"""
+    x, y, z = np.asarray(axis, dtype=np.float64) / np.linalg.norm(axis)
+    c, s = np.cos(angle), np.sin(angle)
+    C = 1 - c
+    return np.array([[x * x * C + c, x * y * C - z * s, x * z * C + y * s],
+                     [y * x * C + z * s, y * y * C + c, y * z * C - x * s],
+                     [z * x * C - y * s, z * y * C + x * s, z * z * C + c]])
+
+
+def get_robot2object(prediction, controller, end2cam):
+    """reference pipeline/utils.py:381-408: move every predicted camera-frame pose (m, wxyz) into the robot frame with the
+    controller's end-effector pose (axis-angle a,b,c + x,y,z in mm) and the hand-eye transform `end2cam`."""
+    from autoposeestimation_amd.DenseFusion.lib.transformations import quaternion_from_matrix, quaternion_matrix
+    if len(prediction["predictions"].keys()) > 0:
+        pose = controller.get_pose(return_mm=True)
+        r = np.array([pose["a"], pose["b"], pose["c"]], dtype=np.float64)
+        angle = np.linalg.norm(r)
+        robot2end = np.identity(4)
+        robot2end[:3, :3] = _axangle2mat(r / angle, angle) if angle > 0 else np.identity(3)
+        robot2end[:3, 3] = [pose["x"], pose["y"], pose["z"]]
+        robot2cam = np.dot(robot2end, end2cam)
+        for cls in prediction["predictions"]:
+            cam2obj = quaternion_matrix(prediction["predictions"][cls]["rotation"])
+            cam2obj[:3, 3] = np.asarray(prediction["predictions"][cls]["position"]) * 1000
+            robot2obj = np.dot(robot2cam, cam2obj)
+            prediction["predictions"][cls]["position"] = robot2obj[:3, 3] / 1000
+            m = np.identity(4)
+            m[:3, :3] = robot2obj[:3, :3]
+            prediction["predictions"][cls]["rotation"] = quaternion_from_matrix(m)
+    return prediction
+
+
 class _ToTensor:
     """torchvision.transforms.ToTensor stand-in returned by get_prediction_models (HWC u8 -> CHW float /255)."""
 

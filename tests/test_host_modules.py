@@ -34,3 +34,58 @@ def test_forward_on_cpu_raises_instead_of_falling_back():
 def test_knn_wrapper_importable():
     from autoposeestimation_amd.DenseFusion.lib.knn import KNearestNeighbor, knn_pytorch
     assert KNearestNeighbor(1).k == 1 and hasattr(knn_pytorch, "knn")
+
+
+def test_install_dropin_aliases_reference_names():
+    import sys
+    import autoposeestimation_amd as A
+    saved = {k: sys.modules.get(k) for k in A.DROPIN_MODULES}
+    try:
+        for k in A.DROPIN_MODULES:
+            sys.modules.pop(k, None)
+        names = A.install_dropin()
+        assert "DenseFusion.lib.network" in names and "pipeline.utils" in names
+        from DenseFusion.lib.network import PoseNet, PoseRefineNet          # noqa: F401  (the reference's import lines)
+        from DenseFusion.lib.knn import KNearestNeighbor                    # noqa: F401
+        from DenseFusion.tools.utils import my_estimator_prediction, my_refined_prediction, get_new_points  # noqa: F401
+        from DenseFusion.lib.transformations import quaternion_matrix       # noqa: F401
+        from DenseFusion.datasets.myDatasetAugmented.dataset import get_bbox  # noqa: F401
+        from segmentation.utils import get_model                           # noqa: F401
+        from pipeline.utils import full_prediction, get_prediction_models, get_robot2object  # noqa: F401
+        from label_generator.create_labels import get_default_model, create_pose_data        # noqa: F401
+        import pc_reconstruction.open3d_utils as pc_utils
+        assert hasattr(pc_utils, "icp_regression") and hasattr(pc_utils, "get_surface")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_get_robot2object_matches_manual_composition():
+    import numpy as np
+    from autoposeestimation_amd.DenseFusion.lib.transformations import quaternion_matrix
+    from autoposeestimation_amd.pipeline.utils import get_robot2object
+
+    class Ctl:
+        def get_pose(self, return_mm=True):
+            return {"a": 0.3, "b": -0.2, "c": 0.5, "x": 100.0, "y": -50.0, "z": 700.0}
+
+    end2cam = np.eye(4)
+    end2cam[:3, 3] = [0, 30, 60]
+    q = np.array([0.8, 0.2, -0.4, 0.4])
+    q /= np.linalg.norm(q)
+    pred = {"predictions": {"obj": {"position": np.array([0.01, 0.02, 0.6]), "rotation": q.copy()}}}
+    out = get_robot2object(pred, Ctl(), end2cam)
+    r = np.array([0.3, -0.2, 0.5])
+    ang = np.linalg.norm(r)
+    K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]]) / ang
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, [100.0, -50.0, 700.0]
+    cam2obj = quaternion_matrix(q)
+    cam2obj[:3, 3] = np.array([0.01, 0.02, 0.6]) * 1000
+    want = T @ end2cam @ cam2obj
+    np.testing.assert_allclose(out["predictions"]["obj"]["position"], want[:3, 3] / 1000, atol=1e-12)
+    np.testing.assert_allclose(quaternion_matrix(out["predictions"]["obj"]["rotation"])[:3, :3], want[:3, :3], atol=1e-12)
