@@ -99,7 +99,10 @@ def test_fused_upsample_conv_equals_materialised(shape, precision):
     fused = conv(x, upsample2x=True)
     ref = conv(E.bilinear(x, 2 * h, 2 * w, True))
     assert fused.shape == (b, 2 * h, 2 * w, cout)
-    assert torch.equal(fused, ref)
+    if precision == "f32" or (2 * h * 2 * w) >= 0.8 * (-(-2 * h // 16) * -(-2 * w // 16) * 256):
+        assert torch.equal(fused, ref)          # same kernel on both sides: the interpolation op order makes them bit-identical
+    else:                                       # small maps: the unfused side runs the generic kernel (different MFMA shape)
+        assert (fused - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     want = F.prelu(F.conv2d(F.interpolate(x.cpu().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True),
                             conv.w.cpu().permute(0, 3, 1, 2), conv.bias.cpu(), 1, 1), torch.tensor([0.25])).permute(0, 2, 3, 1)
     err = (fused.cpu() - want).abs().max().item() / want.abs().max().item()
