@@ -30,7 +30,11 @@ constexpr int LDH = CK;         // bf16 per LDS row: 64 B, UNPADDED; the four 16
 // permutation that keeps all 16 lanes on distinct bank slots is chunk ^ ((-(row>>2)) & 3)
 __device__ __forceinline__ int swz(int row, int chunk16) { return row * LDH + ((chunk16 ^ ((0 - (row >> 2)) & 3)) << 3); }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NTH = 512;        // 8 waves: BN = 128 -> 4 (pixels) x 2 (channels) of 64 px x 64 cout; BN = 64 -> 8 x 1 of 32 px x 64 cout
+// BN = 128: 8 waves = 4 (pixels) x 2 (channels), each 64 px x 64 cout, one workgroup per CU, halo double-buffered.
+// BN = 64:  4 waves along the pixel axis, each 64 px x 64 cout, halo single-buffered so that TWO workgroups share a CU
+//           (57 KB LDS each): one's prologue / chunk refill / epilogue is covered by the other's MFMAs.
+constexpr int halo_threads(int bnh) { return bnh == 64 ? 256 : 512; }
+constexpr bool halo_a_double(int npl, int hp, int bnh) { return bnh != 64 && (2 * npl * hp * LDH * 2 + 2 * npl * bnh * LDH * 2) <= 160 * 1024; }
 
 struct HaloArgs {
     const float* x;
@@ -54,17 +58,19 @@ __device__ __forceinline__ float activate_h(float v, int act, float alpha)
 }
 
 template <int NSPLIT, int D, int BNH, bool UPS>
-__global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
+__global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(const HaloArgs a)
 {
+    constexpr int NTH = halo_threads(BNH);
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int WNW = BNH / 64;               // waves along the channel axis (2 / 1)
-    constexpr int WMW = 8 / WNW;                // waves along the pixel axis (4 / 8)
-    constexpr int TMW = 256 / WMW / 32;         // 32-pixel MFMA tiles per wave (2 / 1)
-    constexpr int B_PASSES = (BNH * 4 + NTH - 1) / NTH;   // 16-B weight chunks per thread per plane (1; half the threads idle at BN = 64)
+    constexpr int WMW = 4;                      // waves along the pixel axis
+    constexpr int TMW = 256 / WMW / 32;         // 32-pixel MFMA tiles per wave (2)
+    static_assert(WNW * WMW * 64 == NTH, "wave grid");
+    constexpr int B_PASSES = (BNH * 4 + NTH - 1) / NTH;   // 16-B weight chunks per thread per plane (1)
     constexpr int HW_ = TS + 2 * D;            // halo width
     constexpr int HP = HW_ * HW_;              // halo pixels
     constexpr int A_ITEMS = (HP * (CK / 4) + NTH - 1) / NTH;   // float4 loads per thread per chunk
-    constexpr bool A_DOUBLE = (2 * NPL * HP * LDH * 2 + 2 * NPL * BNH * LDH * 2) <= 160 * 1024;
+    constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
     constexpr int NA = A_DOUBLE ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
@@ -95,41 +101,70 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
     const int hl = p.H / 2, wl = p.W / 2;
     const float ups_sh = (UPS && p.H > 1) ? (float)(hl - 1) / (float)(p.H - 1) : 0.f;
     const float ups_sw = (UPS && p.W > 1) ? (float)(wl - 1) / (float)(p.W - 1) : 0.f;
-    auto load_a_item = [&](int j, int ci0) {
-        const int e = tid + NTH * j;
-        const int px = e >> 3, c4 = e & 7;
+    // UPS halo items are fetched in two steps so that the four corner loads of an item can fly under a tap's MFMAs:
+    // ups_fetch issues them (unconditional, clamped coordinates), ups_lerp blends them into areg[j] later.
+    auto item_coords = [&](int j, int& c4, int& gy, int& gx) -> bool {
+        int t = tid;
+        asm volatile("" : "+v"(t));     // opaque: keeps the per-item address math next to its use instead of hoisted (and spilled)
+        const int e = t + NTH * j;
+        const int px = e >> 3;
+        c4 = e & 7;
         const int hy = px / HW_, hx = px - hy * HW_;
-        const int gy = y0 - D + hy, gx = x0 - D + hx;
-        const bool ok = e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        if (!UPS) {
-            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-            const unsigned off = (unsigned)(((b * p.H + cy) * p.W + cx) * p.ldx + p.xoff + ci0 + c4 * 4);
-            areg[j] = *reinterpret_cast<const float4*>(a.x + off);       // unconditional: see the note at load_b
-            a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
-        } else {
-            a_okmask |= 1u << j;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const float fy = ups_sh * (float)gy, fx = ups_sw * (float)gx;
-                const int iy0 = (int)fy, ix0 = (int)fx;
-                const int iy1 = iy0 + (iy0 < hl - 1 ? 1 : 0), ix1 = ix0 + (ix0 < wl - 1 ? 1 : 0);
-                const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-                const unsigned cofs = (unsigned)(p.xoff + ci0 + c4 * 4);
-                const float4 v00 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix0) * p.ldx) + cofs);
-                const float4 v01 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix1) * p.ldx) + cofs);
-                const float4 v10 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix0) * p.ldx) + cofs);
-                const float4 v11 = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix1) * p.ldx) + cofs);
-                o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
-                o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
-                o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
-                o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-            }
-            areg[j] = o;
-        }
+        gy = y0 - D + hy; gx = x0 - D + hx;
+        return e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    };
+    auto ups_fetch = [&](int j, int ci0, float4 (&r)[4]) {
+        int c4, gy, gx;
+        item_coords(j, c4, gy, gx);
+        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+        const float fy = ups_sh * (float)cy, fx = ups_sw * (float)cx;
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const int iy1 = iy0 + (iy0 < hl - 1 ? 1 : 0), ix1 = ix0 + (ix0 < wl - 1 ? 1 : 0);
+        const unsigned cofs = (unsigned)(p.xoff + ci0 + c4 * 4);
+        r[0] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix0) * p.ldx) + cofs);
+        r[1] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix1) * p.ldx) + cofs);
+        r[2] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix0) * p.ldx) + cofs);
+        r[3] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix1) * p.ldx) + cofs);
+    };
+    auto ups_lerp = [&](int j, const float4 (&r)[4]) {
+        int c4, gy, gx;
+        const bool ok = item_coords(j, c4, gy, gx);
+        a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
+        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+        const float fy = ups_sh * (float)cy, fx = ups_sw * (float)cx;
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        float4 o;
+        o.x = ly0 * (lx0 * r[0].x + lx1 * r[1].x) + ly1 * (lx0 * r[2].x + lx1 * r[3].x);
+        o.y = ly0 * (lx0 * r[0].y + lx1 * r[1].y) + ly1 * (lx0 * r[2].y + lx1 * r[3].y);
+        o.z = ly0 * (lx0 * r[0].z + lx1 * r[1].z) + ly1 * (lx0 * r[2].z + lx1 * r[3].z);
+        o.w = ly0 * (lx0 * r[0].w + lx1 * r[1].w) + ly1 * (lx0 * r[2].w + lx1 * r[3].w);
+        areg[j] = o;
+    };
+    auto load_a_item = [&](int j, int ci0) {          // !UPS: one float4 per item
+        int c4, gy, gx;
+        const bool ok = item_coords(j, c4, gy, gx);
+        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+        const unsigned off = (unsigned)(((b * p.H + cy) * p.W + cx) * p.ldx + p.xoff + ci0 + c4 * 4);
+        areg[j] = *reinterpret_cast<const float4*>(a.x + off);       // unconditional: see the note at load_b
+        a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
     };
     auto load_a = [&](int ci0) {
+        if (!UPS) {
 #pragma unroll
-        for (int j = 0; j < A_ITEMS; ++j) load_a_item(j, ci0);
+            for (int j = 0; j < A_ITEMS; ++j) load_a_item(j, ci0);
+        } else {
+            // prologue only: four items (16 float4) in flight at a time keeps the register footprint bounded
+#pragma unroll
+            for (int j0 = 0; j0 < A_ITEMS; j0 += 4) {
+                float4 r[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (j0 + q < A_ITEMS) ups_fetch(j0 + q, ci0, r[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (j0 + q < A_ITEMS) ups_lerp(j0 + q, r[q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
     auto store_a = [&](int buf) {
 #pragma unroll
@@ -207,14 +242,18 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
             const bool last = tap == 8;
             const bool more = !(last && c + 1 == nchunks);
             if (more) load_b(last ? 0 : tap + 1, last ? (c + 1) * CK : c * CK);
-            if (A_DOUBLE && c + 1 < nchunks) {
+            constexpr int IPT = (A_ITEMS + 8) / 9;          // UPS: halo items fetched per tap
+            float4 raw[IPT][4];
+            const bool nxt = c + 1 < nchunks;
+            if (nxt) {   // single-buffered: the registers hold the next halo until the chunk ends
                 if (!UPS) {
                     if (tap == 4) load_a((c + 1) * CK);
                 } else {
-                    // the fused up-sampling needs 4 loads + a lerp per item: one item per tap, so each tap's MFMAs cover it
 #pragma unroll
-                    for (int j = 0; j < A_ITEMS; ++j)
-                        if (tap == j + 1) load_a_item(j, (c + 1) * CK);
+                    for (int q = 0; q < IPT; ++q)
+#pragma unroll
+                        for (int j = q; j < A_ITEMS; j += IPT)
+                            if (tap == j / IPT) ups_fetch(j, (c + 1) * CK, raw[q]);
                 }
             }
 
@@ -247,12 +286,18 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
                     }
             }
             if (more) store_b(bbuf ^ 1);
+            if (UPS && nxt) {
+#pragma unroll
+                for (int q = 0; q < IPT; ++q)
+#pragma unroll
+                    for (int j = q; j < A_ITEMS; j += IPT)
+                        if (tap == j / IPT) ups_lerp(j, raw[q]);
+            }
             if (A_DOUBLE && last && c + 1 < nchunks) store_a((c + 1) & 1);
             __syncthreads();
             bbuf ^= 1;
         }
-        if (!A_DOUBLE && c + 1 < nchunks) {   // single A buffer (large dilation): refill between chunks
-            load_a((c + 1) * CK);
+        if (!A_DOUBLE && c + 1 < nchunks) {   // single A buffer: refill between chunks (fetched under the taps above)
             store_a(0);
             __syncthreads();
         }
@@ -262,7 +307,7 @@ __global__ __launch_bounds__(NTH) void conv3x3_halo_kernel(const HaloArgs a)
     // pixel rows (4 dword stores per lane straight from the 16x16 C/D layout would touch 64-B segments only; with K = 576 the
     // up_3 launch spent more time storing than multiplying).  C/D map: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).
     constexpr int ELD = BNH + 4;                          // floats per staged pixel row
-    constexpr int RPP = BNH == 128 ? 128 : 256;           // pixels staged per pass
+    constexpr int RPP = 128;                              // pixels staged per pass
     float* stage = reinterpret_cast<float*>(smem);
     const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
 #pragma unroll 1
@@ -316,12 +361,12 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
 {
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
-    constexpr bool A_DOUBLE = (2 * NPL * HP * LDH * 2 + 2 * NPL * BNH * LDH * 2) <= 160 * 1024;
+    constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
     constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * NPL * HP * LDH + 2 * NPL * BNH * LDH) * 2;
-    constexpr size_t lds_stage = (size_t)(BNH == 128 ? 128 : 256) * (BNH + 4) * 4;      // epilogue staging rows
+    constexpr size_t lds_stage = (size_t)128 * (BNH + 4) * 4;      // epilogue staging rows
     constexpr size_t lds = lds_ops > lds_stage ? lds_ops : lds_stage;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert(!UPS || (A_DOUBLE && D == 1), "fused up-sampling is built for the double-buffered d = 1 kernel");
+    static_assert(!UPS || D == 1, "fused up-sampling is built for the d = 1 kernel");
     auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH, UPS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -332,7 +377,7 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
         attr_set = true;
     }
     const int grid = a.p.B * a.tiles_x * a.tiles_y * a.n_tiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTH), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(halo_threads(BNH)), lds, st, a);
     return ape::check_launch("ape_conv3x3_halo_bf16");
 }
 
