@@ -83,9 +83,9 @@ class _HipModule(nn.Module):
 # ----------------------------------------------------------------------------------------------------------------
 # PSPNet  (pspnet.py:40-77 over the BN-free dilated ResNet of extractors.py:78-124)
 # ----------------------------------------------------------------------------------------------------------------
-def _pspnet_param_shapes(backend, n_classes):
+def _pspnet_param_shapes(backend, n_classes, in_channels=3):
     from autoposeestimation_amd.synthetic import pspnet_spec
-    return pspnet_spec(backend, n_classes)
+    return pspnet_spec(backend, n_classes, in_channels)
 
 
 class _PSPPlan:
@@ -146,12 +146,13 @@ class PSPNet(_HipModule):
     """pspnet.py:40-77.  forward(x[B,3,H,W]) -> log_softmax(final 1x1 conv) [B,32,H,W] (eval semantics)."""
 
     def __init__(self, n_classes=21, sizes=(1, 2, 3, 6), psp_size=512, deep_features_size=256, backend="resnet18",
-                 pretrained=False):
+                 pretrained=False, in_channels=3):
         super().__init__()
         if backend not in _BLOCKS or tuple(sizes) != (1, 2, 3, 6) or psp_size != 512:
             raise NotImplementedError("BasicBlock backends (resnet18/34) with sizes (1,2,3,6) only")
         self.backend = backend
-        for key, shape in _pspnet_param_shapes(backend, n_classes):
+        self.in_channels = in_channels
+        for key, shape in _pspnet_param_shapes(backend, n_classes, in_channels):
             _register(self, key, torch.zeros(shape))
 
     def _build_plan(self, sd, dev):

@@ -44,6 +44,8 @@ SIGNATURES = {
     "ape_seg_head_f32": [_P, _P, _P, _I, _P, _P, _c.c_long, _I, _P],
     "ape_seg_components_workspace_bytes": [_I, _I, _I, _I],
     "ape_seg_components": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
+    "ape_seg_components_scored": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
+    "ape_bgsub_features_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "ape_label_trust_counts": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ape_choose_points": [_P, _P, _P, _I, _I, _I, _I, _c.c_uint, _P, _c.c_long, _P, _P, _P],
     "ape_backproject_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],

@@ -185,13 +185,13 @@ __global__ void seg_small_init_kernel(unsigned int* hist, unsigned long long* be
 __global__ void seg_pick_max_kernel(const uint8_t* __restrict__ label, const int* __restrict__ L,
                                     const unsigned long long* __restrict__ sum, const unsigned int* __restrict__ cnt,
                                     const unsigned int* __restrict__ hist, unsigned long long* __restrict__ best_key,
-                                    int HW, int C, int min_pixels, long npix)
+                                    int HW, int C, int min_pixels, int use_sum, long npix)
 {
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         if (L[p] != (int)p) continue;
         const int b = p / HW, c = label[p];
         if (hist[(long)b * C + c] <= (unsigned)min_pixels) continue;   // counts[i] > 100 (pipeline/utils.py:445)
-        const double mean = (double)sum[p] / (double)cnt[p];
+        const double mean = use_sum ? (double)sum[p] : (double)sum[p] / (double)cnt[p];
         atomicMax(&best_key[(long)b * C + c], (unsigned long long)__double_as_longlong(mean));
     }
 }
@@ -199,13 +199,13 @@ __global__ void seg_pick_max_kernel(const uint8_t* __restrict__ label, const int
 __global__ void seg_pick_root_kernel(const uint8_t* __restrict__ label, const int* __restrict__ L,
                                      const unsigned long long* __restrict__ sum, const unsigned int* __restrict__ cnt,
                                      const unsigned int* __restrict__ hist, const unsigned long long* __restrict__ best_key,
-                                     int* __restrict__ best_root, int HW, int C, int min_pixels, long npix)
+                                     int* __restrict__ best_root, int HW, int C, int min_pixels, int use_sum, long npix)
 {
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         if (L[p] != (int)p) continue;
         const int b = p / HW, c = label[p];
         if (hist[(long)b * C + c] <= (unsigned)min_pixels) continue;
-        const double mean = (double)sum[p] / (double)cnt[p];
+        const double mean = use_sum ? (double)sum[p] : (double)sum[p] / (double)cnt[p];
         if ((unsigned long long)__double_as_longlong(mean) == best_key[(long)b * C + c])
             atomicMin(&best_root[(long)b * C + c], (int)p);   // ties: first component in raster order
     }
@@ -349,6 +349,71 @@ __global__ void crop_normalize_kernel(const uint8_t* __restrict__ rgb, const int
     }
 }
 
+// Background-subtraction features (background_subtraction/utils.py:721-828): per pixel the 7 channels
+//   |f_rgb - b_rgb| (3), |HSV(f) - HSV(b)| (3, Pillow's integer HSV), |f_depth - b_depth| after the distance gate and the
+//   mutual zero test (:756-763), every channel cast to uint8 (the depth difference WRAPS modulo 256, numpy's float -> uint8
+//   cast at :811), then ToTensor (/255) and Normalize((x - mean) / std) in float32 (:818-819).  out[B][H][W][8], channel 7 = 0.
+struct BgsubArgs {
+    float mean[7], stdv[7];
+};
+
+// Pillow's rgb2hsv_row (Convert.c, follows colorsys.py): float divisions, the hue wrap and the * 255.0 in double, truncation.
+// Pinned bit for bit against PIL over all 2^24 colours (tools/gen_golden_bgsub.py).
+__device__ __forceinline__ void pil_hsv(int r, int g, int b, int& uh, int& us, int& uv)
+{
+    const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    uv = maxc;
+    if (minc == maxc) { uh = 0; us = 0; return; }
+    const float cr = (float)(maxc - minc);
+    const float s = cr / (float)maxc;
+    const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
+    float h;
+    if (r == maxc) h = bc - gc;
+    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    const double hw = (double)h / 6.0 + 1.0;
+    h = (float)(hw - floor(hw));                    // fmod(., 1.0) of a positive double: exact
+    const int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
+    uh = ih < 0 ? 0 : (ih > 255 ? 255 : ih);
+    us = is < 0 ? 0 : (is > 255 ? 255 : is);
+}
+
+__global__ void bgsub_features_kernel(const uint8_t* __restrict__ f_rgb, const uint8_t* __restrict__ b_rgb,
+                                      const uint16_t* __restrict__ f_depth, const uint16_t* __restrict__ b_depth,
+                                      const double* __restrict__ gate /*[B][2] min,max*/, BgsubArgs a, float4* __restrict__ out,
+                                      uint8_t* __restrict__ diff /*[B][H][W][7] or null*/, int HW, long npix)
+{
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const int b = p / HW;
+        const double dmin = gate[b * 2], dmax = gate[b * 2 + 1];
+        const uint8_t* fp = f_rgb + p * 3;
+        const uint8_t* bp = b_rgb + p * 3;
+        const int fr = fp[0], fg = fp[1], fb = fp[2], br = bp[0], bg = bp[1], bb = bp[2];
+        int fh, fs, fv, bh, bs, bv;
+        pil_hsv(fr, fg, fb, fh, fs, fv);
+        pil_hsv(br, bg, bb, bh, bs, bv);
+        double fd = (double)f_depth[p], bd = (double)b_depth[p];
+        if (fd > dmax) fd = 0.0;         // :756-759
+        if (bd > dmax) bd = 0.0;
+        if (fd < dmin) fd = 0.0;
+        if (bd < dmin) bd = 0.0;
+        if (bd == 0.0) fd = 0.0;         // :762-763 (sequential: the second test sees the updated f_depth)
+        if (fd == 0.0) bd = 0.0;
+        const int dd = (int)fabs(fd - bd) & 255;
+        const int ch[7] = {abs(fr - br), abs(fg - bg), abs(fb - bb), abs(fh - bh), abs(fs - bs), abs(fv - bv), dd};
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) v[c] = ((float)ch[c] / 255.f - a.mean[c]) / a.stdv[c];
+        v[7] = 0.f;
+        out[p * 2] = make_float4(v[0], v[1], v[2], v[3]);
+        out[p * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        if (diff) {
+#pragma unroll
+            for (int c = 0; c < 7; ++c) diff[p * 7 + c] = (uint8_t)ch[c];
+        }
+    }
+}
+
 // trust checks of the pose-label relabelling (label_generator/create_labels.py:166-196): per frame six counts of
 // (condition, pred set / unset) pairs: cond 0 = background-subtraction label != 0, cond 1 = depth inside the +-gate and != 0,
 // cond 2 = centre window [cut0, H-cut0) x [cut1, W-cut1).  counts[b][6] = (c0&p, c0&!p, c1&p, c1&!p, c2&p, c2&!p).
@@ -477,6 +542,15 @@ extern "C" size_t ape_seg_components_workspace_bytes(int B, int H, int W, int C)
 extern "C" int ape_seg_components(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
                                   int C, int min_pixels, void* workspace, size_t workspace_bytes, void* stream)
 {
+    return ape_seg_components_scored(label, score, objmap, det, B, H, W, C, min_pixels, APE_SEG_SCORE_MEAN, workspace,
+                                     workspace_bytes, stream);
+}
+
+extern "C" int ape_seg_components_scored(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
+                                         int C, int min_pixels, int score_mode, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (score_mode != APE_SEG_SCORE_MEAN && score_mode != APE_SEG_SCORE_SUM) return APE_EINVAL;
+    const int use_sum = score_mode == APE_SEG_SCORE_SUM;
     if (!label || !score || !objmap || !det || !workspace || B < 0 || H < 1 || W < 1 || C < 1 || C > kMaxCls) return APE_EINVAL;
     if (B == 0) return APE_OK;
     const long npix = (long)B * H * W;
@@ -504,12 +578,12 @@ extern "C" int ape_seg_components(const uint8_t* label, const float* score, uint
     int gx = ape::ceil_div((long)H * W, kT);
     gx = gx > 64 ? 64 : gx;
     hipLaunchKernelGGL(seg_stats_kernel, dim3(gx, B), dim3(kT), 0, st, label, score, L, sum, cnt, hist, H * W, C);
-    hipLaunchKernelGGL(seg_pick_max_kernel, dim3(g), dim3(kT), 0, st, label, L, sum, cnt, hist, best_key, H * W, C, min_pixels, npix);
+    hipLaunchKernelGGL(seg_pick_max_kernel, dim3(g), dim3(kT), 0, st, label, L, sum, cnt, hist, best_key, H * W, C, min_pixels, use_sum, npix);
     hipLaunchKernelGGL(seg_pick_root_kernel, dim3(g), dim3(kT), 0, st, label, L, sum, cnt, hist, best_key, best_root, H * W, C,
-                       min_pixels, npix);
+                       min_pixels, use_sum, npix);
     hipLaunchKernelGGL(seg_mask_kernel, dim3(g), dim3(kT), 0, st, label, L, best_root, objmap, tight, H, W, C, npix);
     hipLaunchKernelGGL(seg_bbox_kernel, dim3(ape::ceil_div(BC, kT)), dim3(kT), 0, st, tight, best_root, det, BC, H, W);
-    return ape::check_launch("ape_seg_components");
+    return ape::check_launch("ape_seg_components_scored");
 }
 
 /* objects[n][6] i32 = (frame, cls, rmin, rmax, cmin, cmax) -> choose[n][N] i64 (index inside the crop, row-major over Wc),
@@ -571,4 +645,24 @@ extern "C" int ape_seg_head_f32(const float* feat, const float* w, const float* 
     hipLaunchKernelGGL(seg_head_kernel, dim3((int)g), dim3(kT), 0, (hipStream_t)stream, (const float4*)feat, w, bias, C, label, score,
                        npix, double_softmax);
     return ape::check_launch("ape_seg_head_f32");
+}
+
+/* gate_min_max[B][2] f64 DEVICE; mean7 / std7 HOST pointers (7 floats each); out[B][H][W][8] f32; diff_or_null[B][H][W][7] u8 */
+extern "C" int ape_bgsub_features_f32(const uint8_t* f_rgb, const uint8_t* b_rgb, const uint16_t* f_depth, const uint16_t* b_depth,
+                                      const double* gate_min_max, const float* mean7_host, const float* std7_host, float* out,
+                                      uint8_t* diff_or_null, int B, int H, int W, void* stream)
+{
+    if (!f_rgb || !b_rgb || !f_depth || !b_depth || !gate_min_max || !mean7_host || !std7_host || !out || B < 0 || H < 1 || W < 1)
+        return APE_EINVAL;
+    const long npix = (long)B * H * W;
+    if (npix == 0) return APE_OK;
+    BgsubArgs a;
+    for (int c = 0; c < 7; ++c) {
+        if (!(std7_host[c] != 0.f)) return APE_EINVAL;
+        a.mean[c] = mean7_host[c];
+        a.stdv[c] = std7_host[c];
+    }
+    hipLaunchKernelGGL(bgsub_features_kernel, dim3(grid_for(npix)), dim3(kT), 0, (hipStream_t)stream, f_rgb, b_rgb, f_depth, b_depth,
+                       gate_min_max, a, (float4*)out, diff_or_null, H * W, npix);
+    return ape::check_launch("ape_bgsub_features_f32");
 }

@@ -326,17 +326,40 @@ def _workspace(nbytes, device):
     return ws
 
 
-def seg_components(label, score, n_classes, min_pixels=100):
-    """-> objmap[B,H,W] u8, det[B,C,5] i32 (valid,rmin,rmax,cmin,cmax)"""
+SEG_SCORE_MEAN, SEG_SCORE_SUM = 0, 1
+
+
+def seg_components(label, score, n_classes, min_pixels=100, score_mode=SEG_SCORE_MEAN):
+    """-> objmap[B,H,W] u8, det[B,C,5] i32 (valid,rmin,rmax,cmin,cmax); score_mode: best component by mean (full_prediction)
+    or summed (do_cca) probability"""
     b, h, w = label.shape
     objmap = torch.empty_like(label)
     det = torch.empty(b, n_classes, 5, dtype=torch.int32, device=label.device)
     nbytes = _lib.lib().ape_seg_components_workspace_bytes(b, h, w, n_classes)
     ws = _workspace(nbytes, label.device)
-    rc = _lib.lib().ape_seg_components(_lib.dptr(label, torch.uint8), _lib.dptr(score, torch.float32), _lib.dptr(objmap),
-                                       _lib.dptr(det), b, h, w, n_classes, min_pixels, _lib.dptr(ws), ws.numel(), _st())
-    _lib.check(rc, "ape_seg_components")
+    rc = _lib.lib().ape_seg_components_scored(_lib.dptr(label, torch.uint8), _lib.dptr(score, torch.float32), _lib.dptr(objmap),
+                                              _lib.dptr(det), b, h, w, n_classes, min_pixels, score_mode, _lib.dptr(ws),
+                                              ws.numel(), _st())
+    _lib.check(rc, "ape_seg_components_scored")
     return objmap, det
+
+
+def bgsub_features(f_rgb, b_rgb, f_depth, b_depth, gate, mean, std, want_diff=False):
+    """f_rgb/b_rgb[B,H,W,3] u8, f_depth/b_depth[B,H,W] u16, gate[B,2] f64 (min,max) -> x8[B,H,W,8] f32 (7 normalised difference
+    channels + a zero), optionally the uint8 channels diff[B,H,W,7]."""
+    import ctypes
+    b, h, w, _ = f_rgb.shape
+    out = torch.empty(b, h, w, 8, dtype=torch.float32, device=f_rgb.device)
+    diff = torch.empty(b, h, w, 7, dtype=torch.uint8, device=f_rgb.device) if want_diff else None
+    m = (ctypes.c_float * 7)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 7)(*[float(v) for v in std])
+    rc = _lib.lib().ape_bgsub_features_f32(_lib.dptr(f_rgb, torch.uint8), _lib.dptr(b_rgb, torch.uint8),
+                                           _lib.dptr(f_depth, torch.uint16), _lib.dptr(b_depth, torch.uint16),
+                                           _lib.dptr(gate, torch.float64), ctypes.cast(m, ctypes.c_void_p),
+                                           ctypes.cast(s, ctypes.c_void_p), _lib.dptr(out),
+                                           _lib.dptr(diff) if want_diff else None, b, h, w, _st())
+    _lib.check(rc, "ape_bgsub_features_f32")
+    return (out, diff) if want_diff else out
 
 
 def choose_points(objmap, depth, objects, n_points, seed=0):

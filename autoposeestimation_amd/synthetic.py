@@ -36,9 +36,10 @@ def _uniform(seed, key, shape, bound):
     return torch.from_numpy(((_rng(seed, key).random(shape, dtype=np.float32) * 2 - 1) * np.float32(bound)))
 
 
-def pspnet_spec(backend="resnet18", n_classes=21):
-    """[(key, shape)] of DenseFusion/lib/pspnet.py:PSPNet with a BasicBlock encoder, in state_dict order."""
-    spec = [("feats.conv1.weight", (64, 3, 7, 7))]
+def pspnet_spec(backend="resnet18", n_classes=21, in_channels=3):
+    """[(key, shape)] of DenseFusion/lib/pspnet.py:PSPNet with a BasicBlock encoder, in state_dict order.
+    in_channels != 3 only for the segmentor stand-ins (the background-subtraction network reads 7 channels)."""
+    spec = [("feats.conv1.weight", (64, in_channels, 7, 7))]
     inplanes = 64
     for li, (planes, nblk, stride) in enumerate(zip((64, 128, 256, 512), _BLOCKS[backend], (1, 2, 1, 1)), start=1):
         for b in range(nblk):
@@ -78,11 +79,11 @@ def _fill(spec, seed, prefix="", overrides=None):
     return sd
 
 
-def pspnet_state_dict(backend="resnet18", seed=0, prefix="", n_classes=21, stem_gain=1.0 / 256.0):
+def pspnet_state_dict(backend="resnet18", seed=0, prefix="", n_classes=21, stem_gain=1.0 / 256.0, in_channels=3):
     """stem_gain: the PoseNet crop encoder sees raw 0-255-scale pixels (pipeline/utils.py:559-560), so its stem is scaled
     by 1/256 to bring them to O(1) like a trained first layer would; a SEGMENTOR sees ToTensor'd [0,1] pixels
     (pipeline/utils.py:421-424) -> use stem_gain=1.0 there."""
-    spec = pspnet_spec(backend, n_classes)
+    spec = pspnet_spec(backend, n_classes, in_channels)
     over = {"feats.conv1.weight": stem_gain, "final.0.weight": 0.35}
     # residual branches at half gain so 8..16 un-normalised blocks do not blow the variance up
     over.update({k: 0.5 for k, _ in spec if k.startswith("feats.layer") and k.endswith("conv2.weight")})

@@ -170,6 +170,22 @@ int ape_seg_head_f32(const float* feat, const float* w, const float* bias, int C
 size_t ape_seg_components_workspace_bytes(int B, int H, int W, int C);
 int ape_seg_components(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
                        int C, int min_pixels, void* workspace, size_t workspace_bytes, void* stream);
+/* Same with the component score selectable: APE_SEG_SCORE_MEAN = mean probability (pipeline/utils.py:456-462),
+ * APE_SEG_SCORE_SUM = summed probability, the rule of do_cca (background_subtraction/utils.py:199-222: label 0/1,
+ * biggest = arg max_u sum(max-prob[labels == u]), first component wins ties). */
+#define APE_SEG_SCORE_MEAN 0
+#define APE_SEG_SCORE_SUM 1
+int ape_seg_components_scored(const uint8_t* label, const float* score, uint8_t* objmap, int* det, int B, int H, int W,
+                              int C, int min_pixels, int score_mode, void* workspace, size_t workspace_bytes, void* stream);
+/* Background-subtraction network input   background_subtraction/utils.py:721-828 (get_mask_prediction's per-frame block):
+ * f_rgb/b_rgb[B][H][W][3] u8 and f_depth/b_depth[B][H][W] u16 of the object frame and of the empty-scene frame taken from
+ * the same view point -> the 7 channels |dRGB|, |dHSV| (Pillow's 8-bit HSV), |d depth| (gate [min,max] per frame, :747-763,
+ * gate_min_max[B][2] f64 on the DEVICE), each cast to uint8 as numpy does (:811, the depth channel wraps mod 256), then
+ * ToTensor + Normalize(mean7, std7) (:818-819; HOST pointers).  out[B][H][W][8] f32 NHWC (channel 7 = 0);
+ * diff_or_null[B][H][W][7] receives the uint8 channels when not NULL. */
+int ape_bgsub_features_f32(const uint8_t* f_rgb, const uint8_t* b_rgb, const uint16_t* f_depth, const uint16_t* b_depth,
+                           const double* gate_min_max, const float* mean7_host, const float* std7_host, float* out,
+                           uint8_t* diff_or_null, int B, int H, int W, void* stream);
 /* trust checks of the relabelling loop   label_generator/create_labels.py:166-196.  objmap from ape_seg_components
  * (min_pixels = 0), cls = target class; counts[B][6] u32 (zeroed by the caller) = (bs&pred, bs&!pred, depth&pred,
  * depth&!pred, centre&pred, centre&!pred) with the depth gate [min,max] per frame (:106-112) and the 30/50 px centre window. */

@@ -53,6 +53,7 @@ def test_install_dropin_aliases_reference_names():
         from segmentation.utils import get_model                           # noqa: F401
         from pipeline.utils import full_prediction, get_prediction_models, get_robot2object  # noqa: F401
         from label_generator.create_labels import get_default_model, create_pose_data        # noqa: F401
+        from background_subtraction.utils import get_mask_prediction                         # noqa: F401  (main.py:6)
         import pc_reconstruction.open3d_utils as pc_utils
         assert hasattr(pc_utils, "icp_regression") and hasattr(pc_utils, "get_surface")
     finally:
