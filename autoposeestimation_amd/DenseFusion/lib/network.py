@@ -128,7 +128,10 @@ class _PSPPlan:
             y = c2(c1(y), residual=res)
         f = y
         b, h, w, _ = f.shape
-        zs = [self.bott_prior[i](self.stage[i](E.adaptive_avgpool(f, s))) for i, s in enumerate((1, 2, 3, 6))]
+        pools = {s: E.adaptive_avgpool(f, s) for s in (2, 3, 6)}
+        # the 1x1 pool is the mean of the four 2x2 bins when they tile the map evenly (one workgroup per frame otherwise)
+        pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f, 1)
+        zs = [self.bott_prior[i](self.stage[i](pools[s])) for i, s in enumerate((1, 2, 3, 6))]
         p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w))
         if taps is not None:
             taps["feats"], taps["psp"] = f, p
