@@ -1,4 +1,5 @@
-"""Drop-in for DenseFusion/lib/loss_refiner.py (`Loss_refine`, reference :67-76 over loss_calculation :12-64), forward only."""
+"""Drop-in for DenseFusion/lib/loss_refiner.py (`Loss_refine`, reference :67-76 over loss_calculation :12-64).  When the
+refiner's outputs require grad (training, train.py:219-222) `dis` sits on the tape of autoposeestimation_amd/autograd.py."""
 import torch
 
 from autoposeestimation_amd import engine as E
@@ -14,7 +15,12 @@ def loss_calculation(pred_r, pred_t, target, model_points, idx, points, num_poin
     n_in = points.shape[1]
     pts = points.detach().float().reshape(n_in, 3).contiguous()
     symmetric = int(idx.reshape(-1)[0].item()) in sym_list                              # loss_refiner.py:41
-    dis, _, pred = E.adds_dis(r, t, None, mdl, tgt, symmetric, want_pred=True, want_std=False)
+    if torch.is_grad_enabled() and (pred_r.requires_grad or pred_t.requires_grad):
+        from autoposeestimation_amd.autograd import RefineDisFn
+        dis, pred = RefineDisFn.apply(pred_r.float().reshape(1, 4), pred_t.float().reshape(1, 3), mdl, tgt, symmetric)
+        dis = dis.reshape(1)
+    else:
+        dis, _, pred = E.adds_dis(r, t, None, mdl, tgt, symmetric, want_pred=True, want_std=False)
     qt = torch.cat([r.view(4), t.view(3)]).contiguous()
     new_points = E.recentre_qt(pts, qt).view(1, n_in, 3)
     new_target = E.recentre_qt(tgt, qt).view(1, num_point_mesh, 3)

@@ -50,6 +50,7 @@ class _HipModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._plan = None
+        self._drop = None
         self.precision = "f32"
 
     def set_precision(self, precision):
@@ -63,6 +64,21 @@ class _HipModule(nn.Module):
     def _apply(self, fn, *a, **k):
         self._plan = None
         return super()._apply(fn, *a, **k)
+
+    def train(self, mode=True):
+        """train(True): parameters become leaves of the tape (autoposeestimation_amd/autograd.py) and forward() runs the
+        unfused training graph; either way the cached inference plan is dropped (an optimizer may have changed the weights)."""
+        self._plan = None
+        if mode:
+            for p in self.parameters():
+                p.requires_grad_(True)
+        return super().train(mode)
+
+    def set_dropout_masks(self, masks):
+        """Fix the Dropout2d channel multipliers of the next training forwards (parity tests): dict with 'drop_1' [B,1024],
+        'drop_2a' [B,256], 'drop_2b' [B,64] holding 0 or 1/(1-p); None -> sampled per forward like nn.Dropout2d."""
+        self._drop = masks
+        return self
 
     def load_state_dict(self, state_dict, strict=True, **k):
         self._plan = None
@@ -175,6 +191,72 @@ class PSPNet(_HipModule):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Training graphs: the same networks written op by op over the tape of autograd.py, unfused, so that
+# loss.backward() (train.py:221-225) reaches every reference parameter.  Dropout2d (pspnet.py:48,50: p = 0.3 / 0.15) is a
+# per-(sample, channel) multiplier.
+# ----------------------------------------------------------------------------------------------------------------
+def _dropout2d(x, masks, key, p):
+    if masks is not None and key in masks:
+        m = masks[key].to(device=x.device, dtype=torch.float32)
+    else:
+        m = torch.bernoulli(torch.full((x.shape[0], x.shape[3]), 1.0 - p, device=x.device)) / (1.0 - p)
+    return x * m[:, None, None, :]
+
+
+def _pspnet_train(mod, prefix, backend, x, masks, precision):
+    """x[B,H,W,4] -> log-softmax embedding [B,H,W,32] (pspnet.py:64-77 in train mode)"""
+    from autoposeestimation_amd import autograd as A
+    P = lambda k: mod.get_parameter(prefix + k)  # noqa: E731
+    cv = lambda *a, **k: A.conv(*a, precision=precision, **k)  # noqa: E731
+    y = A.MaxPoolFn.apply(cv(x, P("feats.conv1.weight"), stride=2, pad=3, act=E.ACT_RELU))
+    inplanes = 64
+    for li, (planes, nblk, stride, dil) in enumerate(zip((64, 128, 256, 512), _BLOCKS[backend], (1, 2, 1, 1), (1, 1, 2, 4)), 1):
+        for b in range(nblk):
+            first = b == 0
+            s, d = (stride if first else 1), (1 if first else dil)
+            k = "feats.layer%d.%d." % (li, b)
+            res = cv(y, P(k + "downsample.0.weight"), stride=s) if first and (stride != 1 or inplanes != planes) else y
+            h = cv(y, P(k + "conv1.weight"), stride=s, pad=d, dil=d, act=E.ACT_RELU)
+            y = cv(h, P(k + "conv2.weight"), residual=res, pad=d, dil=d, act=E.ACT_RELU)
+        inplanes = planes
+    f = y
+    _, h, w, _ = f.shape
+    priors = [A.BilinearFn.apply(cv(A.AdaptiveAvgPoolFn.apply(f, s), P("psp.stages.%d.1.weight" % i)), h, w, False)
+              for i, s in enumerate((1, 2, 3, 6))]
+    p = cv(torch.cat(priors + [f], 3), P("psp.bottleneck.weight"), P("psp.bottleneck.bias"), act=E.ACT_RELU)
+    p = _dropout2d(p, masks, "drop_1", 0.3)
+    for name, dkey in (("up_1", "drop_2a"), ("up_2", "drop_2b"), ("up_3", None)):
+        u = A.BilinearFn.apply(p, 2 * p.shape[1], 2 * p.shape[2], True)
+        u = cv(u, P(name + ".conv.1.weight"), P(name + ".conv.1.bias"), pad=1)
+        p = A.PReLUFn.apply(u, P(name + ".conv.2.weight"))
+        if dkey is not None:
+            p = _dropout2d(p, masks, dkey, 0.15)
+    return A.LogSoftmaxRowsFn.apply(cv(p, P("final.0.weight"), P("final.0.bias")))
+
+
+def _feat_train(mod, x4, emb, refine, precision):
+    """PoseNetFeat / PoseRefineNetFeat (network.py:39-68, 136-168): x4[1,N,1,4], emb[1,N,1,32] -> pf[1,N,1,384], ap[1,1024]"""
+    from autoposeestimation_amd import autograd as A
+    g = lambda k: (mod.get_parameter("feat.%s.weight" % k), mod.get_parameter("feat.%s.bias" % k))  # noqa: E731
+    cv = lambda x, k: A.conv(x, *g(k), act=E.ACT_RELU, precision=precision)  # noqa: E731
+    c1, e1 = cv(x4, "conv1"), cv(emb, "e_conv1")
+    c2, e2 = cv(c1, "conv2"), cv(e1, "e_conv2")
+    pf = torch.cat([c1, e1, c2, e2], 3)
+    x6 = cv(cv(pf if refine else torch.cat([c2, e2], 3), "conv5"), "conv6")
+    return pf, A.MeanRowsFn.apply(x6.view(1, -1, 1024))
+
+
+def _select_rows(w, b, obj, k):
+    """rows obj*k..obj*k+k of the last layer (network.py:123-125 index_selects the object's outputs), padded to 4 rows"""
+    w = w.reshape(w.shape[0], -1)[obj * k:(obj + 1) * k]
+    b = b[obj * k:(obj + 1) * k]
+    if k < 4:
+        w = torch.cat([w, torch.zeros(4 - k, w.shape[1], dtype=w.dtype, device=w.device)], 0)
+        b = torch.cat([b, torch.zeros(4 - k, dtype=b.dtype, device=b.device)], 0)
+    return w, b
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # PointNet trunks and heads
 # ----------------------------------------------------------------------------------------------------------------
 class _FeatPlan:
@@ -267,10 +349,38 @@ class PoseNet(_HipModule):
             raise IndexError("obj index %d out of range" % o)
         img4 = torch.zeros(1, img.shape[2], img.shape[3], 4, dtype=torch.float32, device=img.device)
         img4[..., :3] = img.permute(0, 2, 3, 1)
+        if self.training:
+            return self._forward_train(img4, E.pad3to4(x.float().contiguous()), choose.reshape(1, -1).contiguous(), o)
         heads, emb = self.forward_batch(img4, E.pad3to4(x.float().contiguous()), choose.reshape(1, -1).contiguous(),
                                         obj.reshape(1).contiguous())
         return (heads[:, :, 0:4].contiguous(), heads[:, :, 4:7].contiguous(), heads[:, :, 7:8].contiguous(),
                 emb.transpose(1, 2).contiguous())
+
+
+def _posenet_forward_train(self, img4, points4, choose, o):
+    """train-mode PoseNet.forward (network.py:95-132) on the tape"""
+    from autoposeestimation_amd import autograd as A
+    pr = self.precision
+    _, hc, wc, _ = img4.shape
+    n = points4.shape[1]
+    emb_map = _pspnet_train(self, "cnn.model.module.", "resnet18", img4, self._drop, pr)
+    emb = A.GatherRowsFn.apply(emb_map.view(1, hc * wc, 32), choose)                      # [1,N,32]
+    pf, ap = _feat_train(self, points4.view(1, n, 1, 4), emb.view(1, n, 1, 32), False, pr)
+    outs = []
+    for h, k in (("r", 4), ("t", 3), ("c", 1)):
+        w1 = self.get_parameter("conv1_%s.weight" % h)[:, :, 0]                              # [640,1408]
+        gb = A.conv(ap.view(1, 1, 1, 1024), w1[:, 384:], self.get_parameter("conv1_%s.bias" % h), precision=pr)
+        y = A.conv(pf, w1[:, :384], gb, act=E.ACT_RELU, precision=pr)
+        for l in (2, 3):
+            y = A.conv(y, self.get_parameter("conv%d_%s.weight" % (l, h)), self.get_parameter("conv%d_%s.bias" % (l, h)),
+                       act=E.ACT_RELU, precision=pr)
+        w4, b4 = _select_rows(self.get_parameter("conv4_%s.weight" % h), self.get_parameter("conv4_%s.bias" % h), o, k)
+        y = A.conv(y, w4, b4, act=E.ACT_SIGMOID if h == "c" else E.ACT_NONE, precision=pr)
+        outs.append(y.view(1, n, 4)[:, :, :k])
+    return outs[0], outs[1], outs[2], emb.transpose(1, 2)
+
+
+PoseNet._forward_train = _posenet_forward_train
 
 
 class PoseRefineNet(_HipModule):
@@ -313,8 +423,26 @@ class PoseRefineNet(_HipModule):
         o = int(obj.reshape(-1)[0])
         if not 0 <= o < self.num_obj:
             raise IndexError("obj index %d out of range" % o)
+        if self.training:
+            return self._forward_train(E.pad3to4(x.float().contiguous()), emb.transpose(1, 2).contiguous(), o)
         out = self.forward_batch(E.pad3to4(x.float().contiguous()), emb.transpose(1, 2).contiguous(), obj.reshape(1).contiguous())
         return out[:, 0:4].contiguous(), out[:, 4:7].contiguous()
+
+    def _forward_train(self, points4, emb, o):
+        """train-mode PoseRefineNet.forward (network.py:187-206) on the tape: points4[1,N,4], emb[1,N,32]"""
+        from autoposeestimation_amd import autograd as A
+        pr = self.precision
+        n = points4.shape[1]
+        _, ap = _feat_train(self, points4.view(1, n, 1, 4), emb.reshape(1, n, 1, 32), True, pr)
+        outs = []
+        for h, k in (("r", 4), ("t", 3)):
+            y = ap.view(1, 1, 1, 1024)
+            for l in (1, 2):
+                y = A.conv(y, self.get_parameter("conv%d_%s.weight" % (l, h)), self.get_parameter("conv%d_%s.bias" % (l, h)),
+                           act=E.ACT_RELU, precision=pr)
+            w3, b3 = _select_rows(self.get_parameter("conv3_%s.weight" % h), self.get_parameter("conv3_%s.bias" % h), o, k)
+            outs.append(A.conv(y, w3, b3, precision=pr).view(1, 4)[:, :k])
+        return outs[0], outs[1]
 
 
 class ModifiedResnet(nn.Module):

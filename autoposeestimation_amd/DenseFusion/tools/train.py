@@ -1,0 +1,80 @@
+"""Drop-in for the training loop of DenseFusion/tools/train.py: the per-sample step (:205-227), the
+optimizer cadence (:229-238) and the evaluation pass (:262-296), without the argparse / logging / plotting shell.
+
+    estimator, refiner = PoseNet(N, num_obj).cuda(), PoseRefineNet(N, num_obj).cuda()
+    optimizer = Adam(estimator.parameters(), lr=opt.lr)            # autoposeestimation_amd.autograd.Adam (train.py:109)
+    stats = train_epoch(estimator, refiner, optimizer, Loss(M, sym), Loss_refine(M, sym), dataloader, opt)
+
+`dataloader` yields the reference's 6-tuples (points[1,N,3], choose[1,1,N], img[1,3,Hc,Wc], target[1,M,3],
+model_points[1,M,3], idx[1,1]); `opt` needs .w, .refine_start, .iteration, .batch_size, .repeat_epoch.
+Forward, loss, backward and the Adam update are gfx950 kernels (autograd.py keeps the tape)."""
+import numpy as np
+import torch
+
+
+def _dev(data, device):
+    return [d.to(device) for d in data]
+
+
+def train_step(estimator, refiner, criterion, criterion_refine, data, opt, device="cuda:0"):
+    """train.py:205-227 for one sample -> (loss value, refiner dis value or 0, dis value)"""
+    points, choose, img, target, model_points, idx = _dev(data[:6], device)
+    pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+    loss, dis, new_points, new_target, _ = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, opt.refine_start)
+    loss_value, refiner_value = float(loss.detach()), 0.0
+    if opt.refine_start:
+        for _ in range(opt.iteration):
+            pred_r, pred_t = refiner(new_points, emb, idx)
+            dis, new_points, new_target, _ = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
+            dis.backward()
+        refiner_value = float(dis.detach())
+    else:
+        loss.backward()
+    return loss_value, refiner_value, float(dis.detach())
+
+
+def train_epoch(estimator, refiner, optimizer, criterion, criterion_refine, dataloader, opt, device="cuda:0"):
+    """train.py:190-238: one epoch (x opt.repeat_epoch) with an optimizer step every opt.batch_size samples and for the remainder"""
+    if opt.refine_start:
+        estimator.eval()
+        refiner.train()
+    else:
+        estimator.train()
+    optimizer.zero_grad()
+    losses, refiner_losses, train_count, dis_sum, steps = [], [], 0, 0.0, 0
+    for _ in range(getattr(opt, "repeat_epoch", 1)):
+        for data in dataloader:
+            loss_value, refiner_value, dis_value = train_step(estimator, refiner, criterion, criterion_refine, data, opt, device)
+            losses.append(loss_value)
+            refiner_losses.append(refiner_value)
+            dis_sum += dis_value
+            train_count += 1
+            if train_count % opt.batch_size == 0:
+                optimizer.step()
+                optimizer.zero_grad()
+                steps += 1
+        if train_count % opt.batch_size != 0:
+            optimizer.step()
+            optimizer.zero_grad()
+            steps += 1
+    return {"loss": float(np.mean(losses)) if losses else float("nan"), "refiner_loss": float(np.mean(refiner_losses)) if losses else 0.0,
+            "train_dis": dis_sum / max(train_count, 1), "samples": train_count, "optimizer_steps": steps}
+
+
+@torch.no_grad()
+def evaluate(estimator, refiner, criterion, criterion_refine, dataloader, opt, device="cuda:0"):
+    """train.py:252-296 without the plotting: mean ADD(-S) distance over the test set"""
+    estimator.eval()
+    refiner.eval()
+    test_dis, test_count = 0.0, 0
+    for data in dataloader:
+        points, choose, img, target, model_points, idx = _dev(data[:6], device)
+        pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
+        _, dis, new_points, new_target, _ = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, opt.refine_start)
+        if opt.refine_start:
+            for _ in range(opt.iteration):
+                pred_r, pred_t = refiner(new_points, emb, idx)
+                dis, new_points, new_target, _ = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
+        test_dis += float(dis)
+        test_count += 1
+    return test_dis / max(test_count, 1)

@@ -8,7 +8,7 @@ import sys
 
 DROPIN_MODULES = (
     "DenseFusion", "DenseFusion.lib", "DenseFusion.lib.network", "DenseFusion.lib.knn", "DenseFusion.lib.loss",
-    "DenseFusion.lib.loss_refiner", "DenseFusion.lib.transformations", "DenseFusion.tools", "DenseFusion.tools.utils",
+    "DenseFusion.lib.loss_refiner", "DenseFusion.lib.transformations", "DenseFusion.tools", "DenseFusion.tools.utils", "DenseFusion.tools.train",
     "DenseFusion.datasets", "DenseFusion.datasets.myDatasetAugmented", "DenseFusion.datasets.myDatasetAugmented.dataset",
     "segmentation", "segmentation.utils", "pipeline", "pipeline.utils", "label_generator", "label_generator.create_labels",
     "pc_reconstruction", "pc_reconstruction.open3d_utils", "pc_reconstruction.create_pointcloud", "experiments", "experiments.eval",

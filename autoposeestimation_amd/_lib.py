@@ -46,6 +46,20 @@ SIGNATURES = {
     "ape_seg_components": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_seg_components_scored": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_bgsub_features_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "ape_conv2d_wgrad_workspace_bytes": [_P],
+    "ape_conv2d_wgrad_nhwc_f32": [_P, _P, _P, _P, _P, _c.c_size_t, _P],
+    "ape_act_bwd_f32": [_P, _P, _P, _c.c_long, _I, _F, _P],
+    "ape_prelu_f32": [_P, _P, _c.c_long, _F, _P],
+    "ape_prelu_dalpha_f32": [_P, _P, _P, _c.c_long, _P, _P],
+    "ape_colsum_f32": [_P, _P, _c.c_long, _I, _I, _I, _P, _P],
+    "ape_maxpool3x3s2_bwd_nhwc_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ape_adaptive_avgpool_bwd_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ape_bilinear_bwd_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ape_log_softmax_bwd_rows_f32": [_P, _P, _P, _c.c_long, _I, _P],
+    "ape_scatter_add_rows_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ape_mean_rows_bwd_f32": [_P, _P, _I, _I, _I, _P],
+    "ape_adds_grad_f32": [_P] * 9 + [_I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "ape_adam_step_f32": [_P, _P, _P, _P, _c.c_long, _F, _F, _F, _F, _I, _F, _P],
     "ape_label_trust_counts": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ape_choose_points": [_P, _P, _P, _I, _I, _I, _I, _c.c_uint, _P, _c.c_long, _P, _P, _P],
     "ape_backproject_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
@@ -74,7 +88,8 @@ class ConvParams(_c.Structure):
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 _RESTYPES = {"ape_last_error": _c.c_char_p, "ape_seg_components_workspace_bytes": _c.c_size_t,
-             "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t}
+             "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t,
+             "ape_conv2d_wgrad_workspace_bytes": _c.c_size_t}
 
 _lib = None
 

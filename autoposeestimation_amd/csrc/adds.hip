@@ -183,6 +183,90 @@ __global__ void recentre_qt_kernel(const float* __restrict__ pts, const float* _
     }
 }
 
+// Gradient of the DenseFusion loss (loss.py:50-53: mean((dis + 2 std) c - w log c)) or, full == 0, of Loss_refine's `dis`
+// (loss_refiner.py:47) with respect to pred_r, pred_t (and pred_c).  One workgroup per pose n:
+//   dL/d nrm_nm = coef_n * (1/M + 2 (nrm_nm - dis_n) / ((M-1) std_n))     coef_n = g c_n / N   (full)   |   g / M-weighted mean only (refine)
+//   dL/d pred_nm = dL/d nrm_nm * (pred_nm - tgt_nm) / nrm_nm ; tgt is the matched target (recomputed 1-NN for symmetric objects)
+//   dL/d t_n = sum_m dL/d pred_nm ;  dL/d R_n = sum_m dL/d pred_nm (x) model_m ;  R(q/|q|) chain rule to pred_r
+__global__ __launch_bounds__(kT) void adds_grad_kernel(const float* __restrict__ pred_r, const float* __restrict__ pred_t,
+                                                       const float* __restrict__ points, const float* __restrict__ model,
+                                                       const float* __restrict__ target, const float* __restrict__ pred_c,
+                                                       const float* __restrict__ dis, const float* __restrict__ stdv,
+                                                       const float* __restrict__ gscale, int N, int M, int symmetric, int full, float w,
+                                                       float* __restrict__ d_r, float* __restrict__ d_t, float* __restrict__ d_c)
+{
+    extern __shared__ float4 tgt[];
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    for (int m = threadIdx.x; m < M; m += kT) tgt[m] = make_float4(target[m * 3], target[m * 3 + 1], target[m * 3 + 2], 0.f);
+    const float* rp = pred_r + (size_t)n * 4;
+    const float rn = sqrtf(((rp[0] * rp[0] + rp[1] * rp[1]) + rp[2] * rp[2]) + rp[3] * rp[3]);
+    float q[4], R[9];
+    normalise4(rp, q);
+    quat_base(q[0], q[1], q[2], q[3], R);
+    float tx = pred_t[n * 3], ty = pred_t[n * 3 + 1], tz = pred_t[n * 3 + 2];
+    if (points) { tx += points[n * 3]; ty += points[n * 3 + 1]; tz += points[n * 3 + 2]; }
+    const float g = gscale[0];
+    const float mean = dis[n];
+    const float sd = full ? stdv[n] : 0.f;
+    const float coef = full ? g * pred_c[n] / (float)N : g;
+    const float a = 1.f / (float)M;
+    const float bcoef = (full && M > 1 && sd > 0.f) ? 2.f / ((float)(M - 1) * sd) : 0.f;
+    __syncthreads();
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int m = threadIdx.x; m < M; m += kT) {
+        const float mx = model[m * 3], my = model[m * 3 + 1], mz = model[m * 3 + 2];
+        const float px = ((mx * R[0] + my * R[1]) + mz * R[2]) + tx;
+        const float py = ((mx * R[3] + my * R[4]) + mz * R[5]) + ty;
+        const float pz = ((mx * R[6] + my * R[7]) + mz * R[8]) + tz;
+        float4 t = tgt[m];
+        if (symmetric) {
+            float best = __builtin_inff();
+            int bi = 0;
+            for (int r = 0; r < M; ++r) {
+                const float4 c = tgt[r];
+                const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
+                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                if (d < best) { best = d; bi = r; }
+            }
+            t = tgt[bi];
+        }
+        const float dx = px - t.x, dy = py - t.y, dz = pz - t.z;
+        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz);
+        if (nrm > 0.f) {
+            const float k = coef * (a + bcoef * (nrm - mean)) / nrm;
+            const float gx = k * dx, gy = k * dy, gz = k * dz;
+            acc[0] += gx * mx; acc[1] += gx * my; acc[2] += gx * mz;
+            acc[3] += gy * mx; acc[4] += gy * my; acc[5] += gy * mz;
+            acc[6] += gz * mx; acc[7] += gz * my; acc[8] += gz * mz;
+            acc[9] += gx; acc[10] += gy; acc[11] += gz;
+        }
+    }
+    float G[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) G[i] = block_sum(acc[i], red);
+    if (threadIdx.x == 0) {
+        const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+        // d R_k / d (w, x, y, z) of quat_base, contracted with G
+        const float dw = -2.f * qz * G[1] + 2.f * qy * G[2] + 2.f * qz * G[3] - 2.f * qx * G[5] - 2.f * qy * G[6] + 2.f * qx * G[7];
+        const float dxq = 2.f * qy * G[1] + 2.f * qz * G[2] + 2.f * qy * G[3] - 4.f * qx * G[4] - 2.f * qw * G[5] + 2.f * qz * G[6] +
+                          2.f * qw * G[7] - 4.f * qx * G[8];
+        const float dyq = -4.f * qy * G[0] + 2.f * qx * G[1] + 2.f * qw * G[2] + 2.f * qx * G[3] + 2.f * qz * G[5] - 2.f * qw * G[6] +
+                          2.f * qz * G[7] - 4.f * qy * G[8];
+        const float dzq = -4.f * qz * G[0] - 2.f * qw * G[1] + 2.f * qx * G[2] + 2.f * qw * G[3] - 4.f * qz * G[4] + 2.f * qy * G[5] +
+                          2.f * qx * G[6] + 2.f * qy * G[7];
+        const float dot = ((qw * dw + qx * dxq) + qy * dyq) + qz * dzq;
+        d_r[(size_t)n * 4 + 0] = (dw - qw * dot) / rn;
+        d_r[(size_t)n * 4 + 1] = (dxq - qx * dot) / rn;
+        d_r[(size_t)n * 4 + 2] = (dyq - qy * dot) / rn;
+        d_r[(size_t)n * 4 + 3] = (dzq - qz * dot) / rn;
+        d_t[n * 3 + 0] = G[9]; d_t[n * 3 + 1] = G[10]; d_t[n * 3 + 2] = G[11];
+        if (full && d_c) d_c[n] = g * ((mean + 2.f * sd) - w / pred_c[n]) / (float)N;
+    }
+}
+
 }  // namespace
 
 extern "C" int ape_adds_dis_f32(const float* pred_r, const float* pred_t, const float* points, const float* model,
@@ -214,4 +298,18 @@ extern "C" int ape_recentre_qt_f32(const float* pts, const float* qt7, float* ou
     g = g > 1024 ? 1024 : g;
     hipLaunchKernelGGL(recentre_qt_kernel, dim3(g), dim3(kT), 0, (hipStream_t)stream, pts, qt7, out, n);
     return ape::check_launch("ape_recentre_qt_f32");
+}
+
+/* Backward of ape_adds_dis_f32 + ape_adds_select_f32 (loss.py:50-53) when full != 0, of Loss_refine's dis (loss_refiner.py:47)
+ * when full == 0 (N = 1, pred_c / stdv / d_c unused).  gscale: DEVICE scalar = upstream gradient. */
+extern "C" int ape_adds_grad_f32(const float* pred_r, const float* pred_t, const float* points, const float* model,
+                                 const float* target, const float* pred_c, const float* dis, const float* stdv, const float* gscale,
+                                 int N, int M, int symmetric, int full, float w, float* d_r, float* d_t, float* d_c, void* stream)
+{
+    if (!pred_r || !pred_t || !model || !target || !dis || !gscale || !d_r || !d_t || N < 0 || M < 1 || M > 8192) return APE_EINVAL;
+    if (full && (!pred_c || !stdv || !d_c)) return APE_EINVAL;
+    if (N == 0) return APE_OK;
+    hipLaunchKernelGGL(adds_grad_kernel, dim3(N), dim3(kT), (size_t)M * sizeof(float4), (hipStream_t)stream, pred_r, pred_t, points,
+                       model, target, pred_c, dis, stdv, gscale, N, M, symmetric, full, w, d_r, d_t, d_c);
+    return ape::check_launch("ape_adds_grad_f32");
 }

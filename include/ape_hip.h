@@ -245,6 +245,46 @@ int ape_mahalanobis_f64(const double* pts, int n, const double* mean_cinv12_host
 int ape_select_points_f64(const double* pts, const uint8_t* keep, int n, double* out, int* sel_idx, int* n_out, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* ---- training step: the backward kernels behind DenseFusion/tools/train.py:205-238 -------------------
+ * `loss.backward()` / `dis.backward()` there run torch autograd over cuDNN; each entry below is one backward rule of the ops
+ * the estimator / refiner / losses are built from (DenseFusion/lib/{network,pspnet,extractors,loss,loss_refiner}.py). */
+/* Convolution weight gradient (nn.Conv2d / Conv1d / Linear backward w.r.t. weight): x, dy NHWC as in ape_conv2d_nhwc_f32 with
+ * the same ape_conv_params; dw[Cout][KH][KW][Cin] in the packed forward layout (Cin % 4 == 0).  The input gradient is the
+ * forward kernel applied to dy with the flipped, transposed weights. */
+size_t ape_conv2d_wgrad_workspace_bytes(const ape_conv_params* params);
+int ape_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, const ape_conv_params* params, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* dx = dy * act'(ref): ref = the OUTPUT for APE_ACT_RELU / APE_ACT_SIGMOID, the INPUT for APE_ACT_PRELU (nn.ReLU, nn.PReLU
+ * pspnet.py:33, torch.sigmoid network.py:117); in place allowed */
+int ape_act_bwd_f32(const float* dy, const float* ref, float* dx, long n, int act, float alpha, void* stream);
+/* nn.PReLU with one slope (pspnet.py:33) as a separate op of the training forward, and its slope gradient
+ * dalpha[0] = sum dy * x * [x <= 0]; scratch1024: 1024 floats */
+int ape_prelu_f32(const float* x, float* y, long n, float alpha, void* stream);
+int ape_prelu_dalpha_f32(const float* dy, const float* x, float* dalpha, long n, float* scratch1024, void* stream);
+/* bias gradient: out[C] = column sums of x[rows][ld] at channel offset off; scratch: 64 * C floats */
+int ape_colsum_f32(const float* x, float* out, long rows, int C, int ld, int off, float* scratch, void* stream);
+/* nn.MaxPool2d(3, 2, 1) backward (extractors.py:91), ATen's first-maximum tie rule */
+int ape_maxpool3x3s2_bwd_nhwc_f32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* nn.AdaptiveAvgPool2d((S, S)) backward (pspnet.py:16) */
+int ape_adaptive_avgpool_bwd_nhwc_f32(const float* dy, float* dx, int B, int H, int W, int C, int S, void* stream);
+/* F.upsample(..., mode='bilinear') backward, both conventions of ape_bilinear_nhwc_f32 (pspnet.py:22, :37) */
+int ape_bilinear_bwd_nhwc_f32(const float* dy, float* dx, int B, int H, int W, int C, int Ho, int Wo, int align_corners,
+                              void* stream);
+/* nn.LogSoftmax backward per row (pspnet.py:55) */
+int ape_log_softmax_bwd_rows_f32(const float* dy, const float* y, float* dx, long rows, int C, void* stream);
+/* torch.gather backward (network.py:100-102): dx[B][rows_in][C] = scatter-add of dy[B][n][C] at index[B][n] */
+int ape_scatter_add_rows_f32(const float* dy, const int64_t* index, float* dx, int B, int rows_in, int n, int C, void* stream);
+/* AvgPool1d(num_points) backward (network.py:64): dx[B][n][C] = dy[B][C] / n */
+int ape_mean_rows_bwd_f32(const float* dy, float* dx, int B, int n, int C, void* stream);
+/* Gradient of Loss (full = 1; loss.py:50-53) or of Loss_refine's dis (full = 0; loss_refiner.py:47) w.r.t. pred_r[N][4],
+ * pred_t[N][3] (and pred_c[N]); dis / stdv from ape_adds_dis_f32, gscale = DEVICE scalar upstream gradient */
+int ape_adds_grad_f32(const float* pred_r, const float* pred_t, const float* points, const float* model, const float* target,
+                      const float* pred_c, const float* dis, const float* stdv, const float* gscale, int N, int M, int symmetric,
+                      int full, float w, float* d_r, float* d_t, float* d_c, void* stream);
+/* optim.Adam(lr) update of one flat parameter buffer (train.py:109,113; torch defaults betas (0.9, 0.999), eps 1e-8) */
+int ape_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                      float beta2, float eps, int step, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

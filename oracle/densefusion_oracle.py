@@ -70,14 +70,20 @@ def psp_upsample(sd, p, x):
     return F.prelu(x, sd[p + "conv.2.weight"])
 
 
-def pspnet_forward(sd, x, prefix="", backend="resnet18", taps=None, logits_only=False):
-    """pspnet.py:64-77 in eval mode (Dropout2d = identity).  Returns log_softmax(final conv) [B,32,H,W]."""
+def pspnet_forward(sd, x, prefix="", backend="resnet18", taps=None, logits_only=False, drop=None):
+    """pspnet.py:64-77.  Eval mode (Dropout2d = identity) unless `drop` gives the train-mode channel multipliers
+    {'drop_1': [B,1024], 'drop_2a': [B,256], 'drop_2b': [B,64]} (0 or 1/(1-p), what nn.Dropout2d(p) multiplies by at :48,50).
+    Returns log_softmax(final conv) [B,32,H,W]."""
     f = resnet_features(sd, prefix + "feats.", x, backend, taps)
     p = psp_module(sd, prefix + "psp.", f)
     if taps is not None:
         taps["feats"], taps["psp"] = f, p
-    for name in ("up_1", "up_2", "up_3"):
+    if drop is not None:
+        p = p * drop["drop_1"][:, :, None, None]
+    for name, dkey in (("up_1", "drop_2a"), ("up_2", "drop_2b"), ("up_3", None)):
         p = psp_upsample(sd, f"{prefix}{name}.", p)
+        if drop is not None and dkey is not None:
+            p = p * drop[dkey][:, :, None, None]
         if taps is not None:
             taps[name] = p
     logits = F.conv2d(p, sd[prefix + "final.0.weight"], sd[prefix + "final.0.bias"])
@@ -109,9 +115,9 @@ def posenet_feat(sd, x, emb):
     return torch.cat([pf1, pf2, ap], 1)
 
 
-def posenet_forward(sd, img, x, choose, obj, num_obj, taps=None):
-    """network.py:95-132.  img[1,3,H,W], x[1,N,3], choose[1,1,N] i64, obj[1,1] i64."""
-    out_img = pspnet_forward(sd, img, "cnn.model.module.", "resnet18", taps)
+def posenet_forward(sd, img, x, choose, obj, num_obj, taps=None, drop=None):
+    """network.py:95-132.  img[1,3,H,W], x[1,N,3], choose[1,1,N] i64, obj[1,1] i64.  drop: train-mode Dropout2d multipliers."""
+    out_img = pspnet_forward(sd, img, "cnn.model.module.", "resnet18", taps, drop=drop)
     bs, di = out_img.shape[:2]
     n = x.shape[1]
     emb = torch.gather(out_img.view(bs, di, -1), 2, choose.repeat(1, di, 1)).contiguous()
