@@ -202,42 +202,84 @@ __global__ void head_select_kernel(const float* __restrict__ h, int ldh, int off
 //   out(Y, X, c) = act( bias[c] + sum_{ky,kx} U_tap(Y + ky - 1, X + kx - 1)[c] ),   U_tap(q) = 0 outside the 2h x 2w image
 // (the reference zero-pads the UPSAMPLED image, pspnet.py:30-32).  4x fewer MFMA flops than convolving at high resolution
 // and the upsampled 2h x 2w x Cin tensor is never written.
-__global__ void upconv_gather_kernel(const float4* __restrict__ z, const float* __restrict__ bias, float4* __restrict__ out, int B,
-                                     int h, int w, int C4, float sh, float sw, int act, float alpha)
+constexpr int kUpCols = 12;     // low-resolution columns under 16 + 2 output columns at scale ~1/2 (at most 11)
+
+__global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __restrict__ z, const float* __restrict__ bias,
+                                                            float4* __restrict__ out, int B, int h, int w, int C4, float sh, float sw,
+                                                            int act, float alpha)
 {
+    // one workgroup = 16 consecutive output pixels of one row, all channels; consecutive workgroups (same / adjacent rows, which
+    // read the same 2-3 low-resolution rows of z) are kept on ONE XCD so that its L2 serves the ~9x re-use of every z element
     const int Ho = 2 * h, Wo = 2 * w;
-    const long total = (long)B * Ho * Wo * C4;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = i % C4;
-        long t = i / C4;
-        const int X = t % Wo; t /= Wo;
-        const int Y = t % Ho;
-        const int b = t / Ho;
+    const int xt_n = (Wo + 15) / 16;
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const int xt = logical % xt_n;
+    const int Y = (logical / xt_n) % Ho;
+    const int b = logical / (xt_n * Ho);
+    float ly0[3], ly1[3];
+    int iy0[3], iy1[3];
+    bool yok[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int qy = Y + ky - 1;
+        yok[ky] = (unsigned)qy < (unsigned)Ho;
+        const float fy = sh * (float)(yok[ky] ? qy : 0);
+        iy0[ky] = (int)fy;
+        iy1[ky] = iy0[ky] + (iy0[ky] < h - 1 ? 1 : 0);
+        ly1[ky] = fy - (float)iy0[ky];
+        ly0[ky] = 1.f - ly1[ky];
+    }
+    // The resize is separable and its x weights do not depend on the tap row, so for this output row
+    //   out(X) = sum_kx lerp_x( S_kx, X + kx - 1 ),   S_kx(ix) = sum_ky lerp_y( z_{ky,kx}(., ix), Y + ky - 1 )
+    // phase 1 builds S_kx for the ~10 low-resolution columns under the 16 + 2 output columns in LDS (6 loads per value instead
+    // of 36 per output: the kernel was bound by L1 request rate, not by HBM), phase 2 does the x interpolation from LDS.
+    extern __shared__ float4 S[];                       // [3][kMaxCols][C4]
+    const int X0 = xt * 16;
+    const int qx_lo = X0 - 1 < 0 ? 0 : X0 - 1, qx_hi = X0 + 16 > Wo - 1 ? Wo - 1 : X0 + 16;
+    const int ix_lo = (int)(sw * (float)qx_lo);
+    int ix_hi = (int)(sw * (float)qx_hi);
+    ix_hi = ix_hi + (ix_hi < w - 1 ? 1 : 0);
+    const int ni = ix_hi - ix_lo + 1;                   // <= kUpCols (host checks)
+    for (int item = threadIdx.x; item < 3 * ni * C4; item += 256) {
+        const int c = item % C4;
+        const int ii = (item / C4) % ni;
+        const int kx = item / (C4 * ni);
+        const int ix = ix_lo + ii;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int qy = Y + ky - 1;
-            if ((unsigned)qy >= (unsigned)Ho) continue;
-            const float fy = sh * (float)qy;
-            const int iy0 = (int)fy, iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
-            const float ly1 = fy - (float)iy0, ly0 = 1.f - ly1;
+            if (!yok[ky]) continue;
+            const int tc = (ky * 3 + kx) * C4 + c;
+            const float4 v0 = z[((long)(b * h + iy0[ky]) * w + ix) * (9 * C4) + tc];
+            const float4 v1 = z[((long)(b * h + iy1[ky]) * w + ix) * (9 * C4) + tc];
+            acc.x += ly0[ky] * v0.x + ly1[ky] * v1.x;
+            acc.y += ly0[ky] * v0.y + ly1[ky] * v1.y;
+            acc.z += ly0[ky] * v0.z + ly1[ky] * v1.z;
+            acc.w += ly0[ky] * v0.w + ly1[ky] * v1.w;
+        }
+        S[(kx * kUpCols + ii) * C4 + c] = acc;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < 16 * C4; item += 256) {
+        const int c = item % C4;
+        const int X = X0 + item / C4;
+        if (X >= Wo) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int qx = X + kx - 1;
-                if ((unsigned)qx >= (unsigned)Wo) continue;
-                const float fx = sw * (float)qx;
-                const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
-                const float lx1 = fx - (float)ix0, lx0 = 1.f - lx1;
-                const int tc = (ky * 3 + kx) * C4 + c;
-                const float4 v00 = z[((long)(b * h + iy0) * w + ix0) * (9 * C4) + tc];
-                const float4 v01 = z[((long)(b * h + iy0) * w + ix1) * (9 * C4) + tc];
-                const float4 v10 = z[((long)(b * h + iy1) * w + ix0) * (9 * C4) + tc];
-                const float4 v11 = z[((long)(b * h + iy1) * w + ix1) * (9 * C4) + tc];
-                acc.x += ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
-                acc.y += ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
-                acc.z += ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
-                acc.w += ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-            }
+        for (int kx = 0; kx < 3; ++kx) {
+            const int qx = X + kx - 1;
+            if ((unsigned)qx >= (unsigned)Wo) continue;
+            const float fx = sw * (float)qx;
+            const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+            const float lx1 = fx - (float)ix0, lx0 = 1.f - lx1;
+            const float4 s0 = S[(kx * kUpCols + ix0 - ix_lo) * C4 + c], s1 = S[(kx * kUpCols + ix1 - ix_lo) * C4 + c];
+            acc.x += lx0 * s0.x + lx1 * s1.x;
+            acc.y += lx0 * s0.y + lx1 * s1.y;
+            acc.z += lx0 * s0.z + lx1 * s1.z;
+            acc.w += lx0 * s0.w + lx1 * s1.w;
         }
         if (bias) { acc.x += bias[c * 4]; acc.y += bias[c * 4 + 1]; acc.z += bias[c * 4 + 2]; acc.w += bias[c * 4 + 3]; }
         if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
@@ -245,7 +287,7 @@ __global__ void upconv_gather_kernel(const float4* __restrict__ z, const float* 
             acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;
             acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
         }
-        out[i] = acc;
+        out[((long)(b * Ho + Y) * Wo + X) * C4 + c] = acc;
     }
 }
 
@@ -381,9 +423,11 @@ extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float
     if (total == 0) return APE_OK;
     const float sh = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sw = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    long g = (total + kThreads - 1) / kThreads;
-    g = g > 65536 ? 65536 : g;
-    hipLaunchKernelGGL(upconv_gather_kernel, dim3((int)g), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
+    const long g = (long)B * 2 * h * ((2 * w + 15) / 16);
+    if (g >= (1L << 31)) return APE_EINVAL;
+    const size_t lds = (size_t)3 * kUpCols * (C / 4) * sizeof(float4);
+    if (lds > 64 * 1024) return APE_EINVAL;             // C <= 1364
+    hipLaunchKernelGGL(upconv_gather_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
                        h, w, C / 4, sh, sw, act, alpha);
     return ape::check_launch("ape_upconv3x3_gather_f32");
 }
