@@ -136,7 +136,12 @@ class _PSPPlan:
                          alpha=float(g("up_3.conv.2.weight").reshape(-1)[0]), device=dev)
         self.final = _Conv(g("final.0.weight"), g("final.0.bias"), device=dev)
 
-    def features(self, x, taps=None):
+    def label_score(self, x, head_w, head_b, double_softmax=True):
+        """x[B,H,W,4] -> (label u8, score f32)[B,H,W]: features with the classification head (first C rows of the final 1x1 conv +
+        softmax(+softmax) + arg-max) fused into up_3's epilogue -- the full-resolution 64-channel activation is never stored."""
+        return E.conv_seg_head(self.up3, self.features(x, stop_before_up3=True), head_w, head_b, double_softmax, upsample2x=True)
+
+    def features(self, x, taps=None, stop_before_up3=False):
         """x[B,H,W,4] (RGB + zero pad) -> up_3 activation [B,H,W,64]"""
         y = E.maxpool3x3s2(self.stem(x))
         for c1, c2, down in self.blocks:
@@ -155,6 +160,8 @@ class _PSPPlan:
             p = up(p)
             if taps is not None:
                 taps["up_%d" % (i + 1)] = p
+        if stop_before_up3:
+            return p
         p = self.up3(p, upsample2x=True)     # bilinear x2 fused into the conv's halo load when the LDS-halo kernel applies
         if taps is not None:
             taps["up_3"] = p

@@ -16,6 +16,7 @@
 // Numerics are identical to conv_bf16.hip (same split-bf16 x3 / plain bf16 products, fp32 accumulate), only the K order is
 // (channel chunk, tap) instead of (tap, channel) -- covered by the same conv tests.
 #include "common.h"
+#include "seg_head.h"
 
 namespace {
 
@@ -45,6 +46,12 @@ struct HaloArgs {
     ape_conv_params p;
     int Kp, tiles_x, tiles_y, n_tiles;
     long plane_stride;
+    // fused segmentation head (HEAD kernels only): y is not written, label / score are
+    const float* head_w;
+    const float* head_b;
+    uint8_t* label;
+    float* score;
+    int head_c, head_dsm;
 };
 
 __device__ __forceinline__ float activate_h(float v, int act, float alpha)
@@ -57,7 +64,7 @@ __device__ __forceinline__ float activate_h(float v, int act, float alpha)
     }
 }
 
-template <int NSPLIT, int D, int BNH, bool UPS>
+template <int NSPLIT, int D, int BNH, bool UPS, bool HEAD>
 __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(const HaloArgs a)
 {
     constexpr int NTH = halo_threads(BNH);
@@ -303,6 +310,54 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         }
     }
 
+    if constexpr (HEAD) {
+        // ---- fused head epilogue (Cout == 64, one channel tile): bias + activation on the accumulators, the 256 x 64 tile goes
+        // through the same LDS staging rows, then every wave runs the 64 -> C head + softmax(+softmax) + arg-max of seg_head.h on
+        // 16-pixel groups (one tile row each): the 64-channel activation never reaches HBM.
+        static_assert(BNH == 64, "the fused head needs the whole 64-channel pixel in one workgroup");
+        constexpr int ELD = BNH + 4;          // 272-B rows: the eight lanes of a ds_read_b128 phase land on distinct banks
+        constexpr int RPP = 128;
+        float* stage = reinterpret_cast<float*>(smem);
+        float wreg[16], hbias[4];
+        ape_seg::seg_head_load_weights(a.head_w, a.head_b, a.head_c, lane, wreg, hbias);
+        float cb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = j * 16 + r16;
+            cb[j] = (a.bias && n < p.Cout) ? a.bias[(p.bias_bstride ? (size_t)b * p.bias_bstride : 0) + n] : 0.f;
+        }
+#pragma unroll 1
+        for (int pass = 0; pass < 256 / RPP; ++pass) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int p0 = wm * (32 * TMW) + i * 16;
+                if (p0 / RPP != pass) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        stage[(p0 - pass * RPP + kq * 4 + e) * ELD + j * 16 + r16] = activate_h(acc[i][j][e] + cb[j], p.act, p.alpha);
+            }
+            __syncthreads();
+            for (int gi = wave; gi < RPP / 16; gi += NTH / 64) {
+                const int pidx = pass * RPP + gi * 16 + r16;
+                const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
+                float4 xv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const float4*>(&stage[(gi * 16 + r16) * ELD + (4 * j + kq) * 4]);
+                int am;
+                float pm;
+                ape_seg::seg_head_group(xv, wreg, hbias, a.head_c, lane, a.head_dsm, am, pm);
+                if (kq == 0 && gy < p.Ho && gx < p.Wo) {
+                    const size_t m = ((size_t)b * p.Ho + gy) * p.Wo + gx;
+                    a.label[m] = (uint8_t)am;
+                    a.score[m] = pm;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // ---- epilogue: accumulators -> LDS staging rows (fp32) -> 16-byte stores, 64 consecutive lanes covering whole 256/512-B
     // pixel rows (4 dword stores per lane straight from the 16x16 C/D layout would touch 64-B segments only; with K = 576 the
     // up_3 launch spent more time storing than multiplying).  C/D map: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).
@@ -356,7 +411,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     }
 }
 
-template <int NSPLIT, int D, int BNH, bool UPS>
+template <int NSPLIT, int D, int BNH, bool UPS, bool HEAD = false>
 int launch_halo(const HaloArgs& a, hipStream_t st)
 {
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
@@ -367,7 +422,7 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr size_t lds = lds_ops > lds_stage ? lds_ops : lds_stage;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!UPS || D == 1, "fused up-sampling is built for the d = 1 kernel");
-    auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH, UPS>;
+    auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH, UPS, HEAD>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -412,6 +467,7 @@ extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const
     a.plane_stride = (long)p.Cout * Kp;
     a.tiles_x = ape::ceil_div(p.W, TS);
     a.tiles_y = ape::ceil_div(p.H, TS);
+    a.head_w = a.head_b = nullptr; a.label = nullptr; a.score = nullptr; a.head_c = 0; a.head_dsm = 0;
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = p.Cout <= 64;
     a.n_tiles = ape::ceil_div(p.Cout, narrow ? 64 : 128);
@@ -430,4 +486,32 @@ extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const
     if (p.dil == 2) return HALO_DISPATCH(1, 2);
     return HALO_DISPATCH(1, 4);
 #undef HALO_DISPATCH
+}
+
+/* Same convolution (Cout must be 64, no residual) with the segmentation head fused into its epilogue: see include/ape_hip.h */
+extern "C" int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params,
+                                             int nsplit, const float* head_w, const float* head_b, int C, uint8_t* label, float* score,
+                                             int double_softmax, void* stream)
+{
+    if (!x || !w_packed || !params || !head_w || !label || !score || (nsplit != 1 && nsplit != 3) || C < 1 || C > 16) return APE_EINVAL;
+    if (!ape_conv3x3_halo_supported(params)) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (p.Cout != 64 || p.dil != 1 || p.B < 0 || p.H < 1 || p.W < 1) return APE_EINVAL;
+    if (p.ldx % 4 || p.xoff % 4 || p.xoff + p.Cin > p.ldx) return APE_EINVAL;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID || (p.ups != 0 && p.ups != 1)) return APE_EINVAL;
+    if (p.ups && ((p.H & 1) || (p.W & 1))) return APE_EINVAL;
+    if (p.B == 0) return APE_OK;
+    const long K = 9L * p.Cin, Kp = (K + 7) / 8 * 8;
+    if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * Kp >= (1L << 31)) return APE_EINVAL;
+    HaloArgs a;
+    a.x = x; a.w = (const __bf16*)w_packed; a.bias = bias; a.res = nullptr; a.y = nullptr; a.p = p;
+    a.Kp = (int)Kp;
+    a.plane_stride = (long)p.Cout * Kp;
+    a.tiles_x = ape::ceil_div(p.W, TS);
+    a.tiles_y = ape::ceil_div(p.H, TS);
+    a.n_tiles = 1;
+    a.head_w = head_w; a.head_b = head_b; a.label = label; a.score = score; a.head_c = C; a.head_dsm = double_softmax;
+    hipStream_t st = (hipStream_t)stream;
+    if (nsplit == 3) return p.ups ? launch_halo<3, 1, 64, true, true>(a, st) : launch_halo<3, 1, 64, false, true>(a, st);
+    return p.ups ? launch_halo<1, 1, 64, true, true>(a, st) : launch_halo<1, 1, 64, false, true>(a, st);
 }

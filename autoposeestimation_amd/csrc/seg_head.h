@@ -1,0 +1,71 @@
+// Shared device code of the segmentation head: final 1x1 conv (64 -> C <= 16 classes, pspnet.py:53-55) + softmax (+ softmax)
+// + arg-max for a group of 16 pixels on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32, D = W . X^T: rows = classes,
+// columns = 16 pixels).  Lane (px = lane & 15, kq = lane >> 4) holds, for j = 0..3, the float4 of channels 16 j + 4 kq .. + 3
+// of ITS pixel in x[j]; the 16 weight operands and 4 biases per lane are loaded once by seg_head_load_weights.  Used by
+// seg_head_kernel (streaming over a feature tensor) and by the LDS-halo convolution's fused-head epilogue, so both paths
+// produce bit-identical labels and scores.
+#pragma once
+#include "common.h"
+
+namespace ape_seg {
+
+typedef float f32x4h __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+
+__device__ __forceinline__ void seg_head_load_weights(const float* __restrict__ w, const float* __restrict__ bias, int C, int lane,
+                                                      float (&wreg)[16], float (&breg)[4])
+{
+    const int px = lane & 15, kq = lane >> 4;
+    // A operand (weights): class = lane&15, k = 16 j + 4 kq + e  -> wreg[j*4+e]; rows >= C are zero
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wreg[j * 4 + e] = px < C ? w[px * 64 + 16 * j + 4 * kq + e] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) breg[r] = (kq * 4 + r < C && bias) ? bias[kq * 4 + r] : 0.f;
+}
+
+// -> am (arg-max class, first maximum) and pm (its probability after one or two softmaxes), valid on every lane of the pixel
+__device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float (&wreg)[16], const float (&breg)[4], int C, int lane,
+                                               int double_softmax, int& am_out, float& pm_out)
+{
+    const int kq = lane >> 4;
+    f32x4h acc = {breg[0], breg[1], breg[2], breg[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 0], x[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 1], x[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 2], x[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 3], x[j].w, acc, 0, 0, 0);
+    }
+    // acc[r] = logit of class kq*4 + r for pixel px (C/D map of 16x16x4: row = 4*(lane>>4) + r, col = lane&15)
+    float m = -__builtin_inff();
+    int am = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = kq * 4 + r;
+        if (c < C && acc[r] > m) { m = acc[r]; am = c; }      // ascending c: first maximum of this lane's four
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float om = __shfl_xor(m, off);
+        const int oa = __shfl_xor(am, off);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }  // first maximum overall (torch.argmax on the CPU)
+    }
+    float e[4], s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? expf(acc[r] - m) : 0.f; s += e[r]; }
+    s = quad_sum(s);
+    float pm = 1.f / s;
+    if (double_softmax) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? expf(e[r] / s - pm) : 0.f;
+        pm = 1.f / quad_sum(s2);
+    }
+    am_out = am;
+    pm_out = pm;
+}
+
+}  // namespace ape_seg

@@ -22,6 +22,7 @@
 //   backproject    float32 pin-hole back-projection, bit-identical to the numpy arithmetic
 //   crop_normalize u8 RGB -> NHWC4 f32 (x[/255] - mean) / std
 #include "common.h"
+#include "seg_head.h"
 
 namespace {
 
@@ -454,23 +455,13 @@ __global__ __launch_bounds__(kT) void label_trust_kernel(const uint8_t* __restri
 // lanes {px, px+16, px+32, px+48}, so max / arg-max / exp-sums need only two xor-shuffles.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
-
 __global__ __launch_bounds__(kT) void seg_head_kernel(const float4* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ bias,
                                                       int C, uint8_t* __restrict__ label, float* __restrict__ score, long npix, int double_softmax)
 {
     const int lane = threadIdx.x & 63;
     const int px = lane & 15, kq = lane >> 4;
-    // A operand (weights): class = lane&15, k = 16 j + 4 kq + e  -> wreg[j*4+e]; rows >= C are zero
-    float wreg[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wreg[j * 4 + e] = px < C ? w[px * 64 + 16 * j + 4 * kq + e] : 0.f;
-    float breg[4];   // bias of this lane's four classes kq*4 + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) breg[r] = (kq * 4 + r < C && bias) ? bias[kq * 4 + r] : 0.f;
-
+    float wreg[16], breg[4];
+    ape_seg::seg_head_load_weights(w, bias, C, lane, wreg, breg);
     const long ngroups = (npix + 15) / 16;
     const long wave_id = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     for (long g = wave_id; g < ngroups; g += nwaves) {
@@ -479,39 +470,9 @@ __global__ __launch_bounds__(kT) void seg_head_kernel(const float4* __restrict__
         float4 x[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[j] = in ? feat[p * 16 + 4 * j + kq] : make_float4(0.f, 0.f, 0.f, 0.f);
-        f32x4 acc = {breg[0], breg[1], breg[2], breg[3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 0], x[j].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 1], x[j].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 2], x[j].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 3], x[j].w, acc, 0, 0, 0);
-        }
-        // acc[r] = logit of class kq*4 + r for pixel px (C/D map of 16x16x4: row = 4*(lane>>4) + r, col = lane&15)
-        float m = -__builtin_inff();
-        int am = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = kq * 4 + r;
-            if (c < C && acc[r] > m) { m = acc[r]; am = c; }      // ascending c: first maximum of this lane's four
-        }
-#pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float om = __shfl_xor(m, off);
-            const int oa = __shfl_xor(am, off);
-            if (om > m || (om == m && oa < am)) { m = om; am = oa; }  // first maximum overall (torch.argmax on the CPU)
-        }
-        float e[4], s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? expf(acc[r] - m) : 0.f; s += e[r]; }
-        s = quad_sum(s);
-        float pm = 1.f / s;
-        if (double_softmax) {
-            float s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? expf(e[r] / s - pm) : 0.f;
-            pm = 1.f / quad_sum(s2);
-        }
+        int am;
+        float pm;
+        ape_seg::seg_head_group(x, wreg, breg, C, lane, double_softmax, am, pm);
         if (in && kq == 0) {
             label[p] = (uint8_t)am;
             score[p] = pm;

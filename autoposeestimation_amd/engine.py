@@ -146,6 +146,37 @@ class Conv:
         return out
 
 
+def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False):
+    """`seg_head(conv(x))` for a 64-channel 3x3 layer: fused into the LDS-halo kernel's epilogue when that kernel applies
+    (split-bf16 / bf16 precision, Cin % 32 == 0), otherwise the two calls.  -> label[B,H,W] u8, score[B,H,W] f32"""
+    b, h, w, ldx = x.shape
+    if upsample2x:
+        h, w = 2 * h, 2 * w
+    c = head_w.shape[0]
+    fusable = (conv.nsplit and USE_HALO_KERNEL and conv.cout == 64 and conv.kh == 3 and conv.kw == 3 and conv.stride == 1
+               and conv.pad == 1 and conv.dil == 1 and conv.cin % 32 == 0 and ldx == conv.cin and c <= 16
+               and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256)))
+    if not fusable:
+        return seg_head(conv(x, upsample2x=upsample2x), head_w, head_b, double_softmax)
+    p = ConvParams(B=b, H=h, W=w, Cin=conv.cin, ldx=ldx, xoff=0, Ho=h, Wo=w, Cout=conv.cout, ldy=conv.cout, yoff=0, KH=3, KW=3,
+                   stride=1, pad=1, dil=1, act=conv.act, alpha=conv.alpha, bias_bstride=0, ldr=0, roff=0, ups=int(bool(upsample2x)))
+    label = torch.empty(b, h, w, dtype=torch.uint8, device=x.device)
+    score = torch.empty(b, h, w, dtype=torch.float32, device=x.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().ape_conv3x3_halo_seghead_bf16(_lib.dptr(x, torch.float32), _lib.dptr(conv.wp), _lib.dptr(conv.bias), ctypes.byref(p),
+                                                  conv.nsplit, _lib.dptr(head_w, torch.float32), _lib.dptr(head_b), c, _lib.dptr(label),
+                                                  _lib.dptr(score), int(bool(double_softmax)), _st())
+    _lib.check(rc, "ape_conv3x3_halo_seghead_bf16")
+    if prof is not None:
+        e1.record()
+        prof.records.append(("conv3x3_halo_kernel<%d,1,64,%s,head>" % (conv.nsplit, "true" if upsample2x else "false"),
+                             2.0 * b * h * w * conv.cout * 9 * conv.cin_real, e0, e1))
+    return label, score
+
+
 def maxpool3x3s2(x):
     b, h, w, c = x.shape
     y = torch.empty(b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c, dtype=torch.float32, device=x.device)

@@ -52,7 +52,7 @@ class PsPNetSegmentor(PSPNet):
         pl = self.plan()
         if self.classes > 16:
             return E.seg_argmax(self.logits_nhwc(x4), self.classes, double_softmax)
-        return E.seg_head(pl.features(x4), self._head_w, self._head_b, double_softmax)
+        return pl.label_score(x4, self._head_w, self._head_b, double_softmax)
 
     def predict(self, x):
         _need_cuda(x, "input")

@@ -245,6 +245,13 @@ int ape_mahalanobis_f64(const double* pts, int n, const double* mean_cinv12_host
 int ape_select_points_f64(const double* pts, const uint8_t* keep, int n, double* out, int* sel_idx, int* n_out, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* ape_conv3x3_halo_bf16 for a 64-channel layer (the segmentor's up_3, pspnet.py:51) with ape_seg_head_f32 fused into its
+ * epilogue: the [B][H][W][64] activation is never written, label[B][H][W] u8 / score[B][H][W] f32 are (bit-identical to the
+ * unfused pair).  params->Cout must be 64, no residual; params->ups as in ape_conv3x3_halo_bf16. */
+int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params, int nsplit,
+                                  const float* head_w, const float* head_b, int C, uint8_t* label, float* score, int double_softmax,
+                                  void* stream);
+
 /* ---- training step: the backward kernels behind DenseFusion/tools/train.py:205-238 -------------------
  * `loss.backward()` / `dis.backward()` there run torch autograd over cuDNN; each entry below is one backward rule of the ops
  * the estimator / refiner / losses are built from (DenseFusion/lib/{network,pspnet,extractors,loss,loss_refiner}.py). */

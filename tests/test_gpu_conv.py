@@ -107,3 +107,25 @@ def test_fused_upsample_conv_equals_materialised(shape, precision):
                             conv.w.cpu().permute(0, 3, 1, 2), conv.bias.cpu(), 1, 1), torch.tensor([0.25])).permute(0, 2, 3, 1)
     err = (fused.cpu() - want).abs().max().item() / want.abs().max().item()
     assert err <= TOL[precision]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("ups,h,w", [(True, 24, 40), (False, 48, 80), (True, 21, 33)])
+def test_halo_conv_with_fused_seg_head_is_bit_identical_to_the_unfused_pair(precision, ups, h, w):
+    """ape_conv3x3_halo_seghead_bf16 == ape_conv3x3_halo_bf16 followed by ape_seg_head_f32 (labels and scores bit for bit),
+    incl. ragged tiles and the fused x2 up-sampling"""
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(h * 100 + w)
+    b, c = 3, 5
+    x = torch.randn(b, h, w, 64, generator=g).to("cuda")
+    wt = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to("cuda")
+    bias = (torch.randn(64, generator=g) * 0.1).to("cuda")
+    hw = (torch.randn(c, 64, generator=g) * 0.3).to("cuda").contiguous()
+    hb = (torch.randn(c, generator=g) * 0.1).to("cuda")
+    conv = E.Conv(wt, bias, 1, 1, 1, E.ACT_PRELU, alpha=0.25, device="cuda", precision=precision)
+    feat = conv(x, upsample2x=ups)
+    want_label, want_score = E.seg_head(feat, hw, hb, True)
+    label, score = E.conv_seg_head(conv, x, hw, hb, True, upsample2x=ups)
+    assert label.shape == want_label.shape
+    assert torch.equal(label, want_label) and torch.equal(score, want_score)
+    assert len(torch.unique(label)) > 1

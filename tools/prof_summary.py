@@ -17,10 +17,10 @@ a = ap.parse_args()
 assert a.warmup >= 1, "needs at least one warm-up step to locate the start of the timed region"
 rows = list(csv.DictReader(open(a.trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# Step structure: every step launches the segmentation head (seg_head_kernel, or seg_argmax_kernel in older builds) exactly once
-# after its segmentation CNN and ends with pose_compose_kernel launches.  The timed region starts after the last pose_compose
-# of warm-up step W.
-argmax = [i for i, r in enumerate(rows) if "seg_head_kernel" in r["Kernel_Name"] or "seg_argmax_kernel" in r["Kernel_Name"]]
+# Step structure: every step labels the connected components of its segmentation exactly once (ccl_init_kernel, right after
+# the segmentation CNN and its head) and ends with pose_compose_kernel launches.  The timed region starts after the last
+# pose_compose of warm-up step W.
+argmax = [i for i, r in enumerate(rows) if "ccl_init_kernel" in r["Kernel_Name"]]
 assert len(argmax) == a.steps + a.warmup, (len(argmax), a.steps, a.warmup)
 last_compose = max(i for i, r in enumerate(rows[:argmax[a.warmup]]) if "pose_compose_kernel" in r["Kernel_Name"])
 t0 = int(rows[last_compose]["End_Timestamp"])
