@@ -55,11 +55,17 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo)
     lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
 }
 
-template <int NSPLIT, int BM, int BN, int WM, int WN, int BK>
+// DB = true: BK = 32, two LDS stages of unpadded 64-B rows whose four 16-B chunks are XOR-swizzled with (row >> 1) & 3
+// (conflict-free ds_read_b128 fragments and ds_write_b128 staging), ONE barrier per k-tile: the next tile is written into
+// the other stage right after this tile's MFMAs are issued, so a wave's split + LDS-store phase overlaps the other waves'
+// MFMA phase instead of sitting between two barriers.
+template <int NSPLIT, int BM, int BN, int WM, int WN, int BK, bool DB>
 __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB a)
 {
+    static_assert(!DB || BK == 32, "the double-buffered layout is built for 32-deep k-tiles");
     constexpr int NT = WM * WN * 64;
-    constexpr int LD = BK + 8;   // bf16 per LDS row: 144 B (BK = 64) or 80 B (BK = 32), an odd number of 16-B slots
+    constexpr int LD = DB ? BK : BK + 8;   // bf16 per LDS row: padded 144 B (BK = 64) / 80 B (BK = 32), or unpadded swizzled 64 B
+    constexpr int NSTAGE = DB ? 2 : 1;
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;           // operand planes (hi [, lo])
@@ -72,12 +78,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB
 
     // ONE LDS array: operand tiles during the K loop, fp32 staging rows during the epilogue
     constexpr int ELD = BN + 4;                         // floats per staged epilogue row
-    constexpr size_t kOperandBytes = (size_t)NPL * (BM + BN) * LD * 2, kStageBytes = (size_t)64 * ELD * 4;
+    constexpr size_t kOperandBytes = (size_t)NSTAGE * NPL * (BM + BN) * LD * 2, kStageBytes = (size_t)64 * ELD * 4;
     __shared__ __attribute__((aligned(16))) char smem_raw[kOperandBytes > kStageBytes ? kOperandBytes : kStageBytes];
-    __bf16* const As0 = reinterpret_cast<__bf16*>(smem_raw);
-    __bf16* const Bs0 = As0 + NPL * BM * LD;
-    __bf16* As[2] = {As0, As0 + (NPL - 1) * BM * LD};
-    __bf16* Bs[2] = {Bs0, Bs0 + (NPL - 1) * BN * LD};
+    __bf16* const As0 = reinterpret_cast<__bf16*>(smem_raw);                 // [NSTAGE][NPL][BM * LD]
+    __bf16* const Bs0 = As0 + NSTAGE * NPL * BM * LD;                        // [NSTAGE][NPL][BN * LD]
+    auto a_tile = [&](int stage, int pl) { return As0 + ((size_t)stage * NPL + pl) * BM * LD; };
+    auto b_tile = [&](int stage, int pl) { return Bs0 + ((size_t)stage * NPL + pl) * BN * LD; };
+    // element offset of the 16-B chunk `c16` of tile row `row`
+    auto lds_off = [](int row, int c16) { return DB ? row * LD + ((c16 ^ ((row >> 1) & 3)) << 3) : row * LD + c16 * 8; };
 
     const ape_conv_params& p = a.p;
     const int nwg = a.m_tiles * a.n_tiles;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB
                 b_okmask |= ok ? (1u << i) : 0u;
             }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int stage) {
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
@@ -185,14 +193,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB
             bf16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { hi[e] = h0[e]; hi[4 + e] = h1[e]; lo[e] = l0[e]; lo[4 + e] = l1[e]; }
-            *reinterpret_cast<bf16x8*>(&As[0][(srow + RPP * i) * LD + k8 * 8]) = hi;
-            if (NPL == 2) *reinterpret_cast<bf16x8*>(&As[NPL - 1][(srow + RPP * i) * LD + k8 * 8]) = lo;
+            *reinterpret_cast<bf16x8*>(a_tile(stage, 0) + lds_off(srow + RPP * i, k8)) = hi;
+            if (NPL == 2) *reinterpret_cast<bf16x8*>(a_tile(stage, NPL - 1) + lds_off(srow + RPP * i, k8)) = lo;
         }
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int i = 0; i < B_ITEMS; ++i)
-                *reinterpret_cast<uint4*>(&Bs[pl][(srow + RPP * i) * LD + k8 * 8]) =
+                *reinterpret_cast<uint4*>(b_tile(stage, pl) + lds_off(srow + RPP * i, k8)) =
                     (b_okmask >> i) & 1u ? breg[pl][i] : make_uint4(0u, 0u, 0u, 0u);
     };
 
@@ -206,26 +214,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB
 
     const int nk = (a.K + BK - 1) / BK;
     const int frow = lane & 31, fh = lane >> 5;
-    const int a_off = (wm * (BM / WM) + frow) * LD + 8 * fh;
-    const int b_off = (wn * (BN / WN) + frow) * LD + 8 * fh;
-
-    load_tiles(0);
-    store_tiles();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    const int a_row0 = wm * (BM / WM) + frow, b_row0 = wn * (BN / WN) + frow;
+    auto compute = [&](int stage) {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][a_off + i * 32 * LD + s * 16]);
-                if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(&As[NPL - 1][a_off + i * 32 * LD + s * 16]);
+                const int o = lds_off(a_row0 + i * 32, 2 * s + fh);
+                ah[i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, 0) + o);
+                if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, NPL - 1) + o);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][b_off + j * 32 * LD + s * 16]);
-                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[NPL - 1][b_off + j * 32 * LD + s * 16]);
+                const int o = lds_off(b_row0 + j * 32, 2 * s + fh);
+                bh[j] = *reinterpret_cast<const bf16x8*>(b_tile(stage, 0) + o);
+                if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(b_tile(stage, NPL - 1) + o);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -238,10 +242,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            store_tiles();
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    if (DB) {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(kt + 1);
+            compute(kt & 1);
+            if (kt + 1 < nk) store_tiles((kt + 1) & 1);
             __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(kt + 1);
+            compute(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                store_tiles(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -298,10 +319,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_bf16_kernel(const ConvArgsB
     }
 }
 
-template <int NSPLIT, int BM, int BN, int WM, int WN, int BK>
+template <int NSPLIT, int BM, int BN, int WM, int WN, int BK, bool DB = false>
 void launch(const ConvArgsB& a, hipStream_t st)
 {
-    hipLaunchKernelGGL((conv_bf16_kernel<NSPLIT, BM, BN, WM, WN, BK>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_bf16_kernel<NSPLIT, BM, BN, WM, WN, BK, DB>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int cout, int K, int Kp)
@@ -364,12 +385,15 @@ extern "C" int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const 
     a.Kp = (a.K + 7) / 8 * 8;
     a.plane_stride = (long)p.Cout * a.Kp;
     hipStream_t st = (hipStream_t)stream;
+    // A/B on MI355X (tools/microbench_generic.py): the double-buffered layout pays for the 256x256 tile (+1..8 %) and for the
+    // Cout <= 64 tile (stem: +10 %); the 128x128 tile is bound by L2 -> CU operand traffic (30 KB per algorithmic MFLOP,
+    // ~6.7 TB/s at 220 TFLOP/s) either way and keeps the 64-deep single-buffered k-tile (fewer barriers per flop).
     // 256x256 tiles when they are mostly full: Cout a (near) multiple of 256 and enough rows to fill the chip
     const int waste256 = ape::ceil_div(p.Cout, 256) * 256 - p.Cout;
     if (p.Cout >= 256 && waste256 * 8 <= p.Cout && M >= 256L * 256) {
         a.m_tiles = ape::ceil_div(M, 256);
         a.n_tiles = ape::ceil_div(p.Cout, 256);
-        if (nsplit == 3) launch<3, 256, 256, 4, 2, 32>(a, st); else launch<1, 256, 256, 4, 2, 32>(a, st);
+        if (nsplit == 3) launch<3, 256, 256, 4, 2, 32, true>(a, st); else launch<1, 256, 256, 4, 2, 32, true>(a, st);
     } else if (p.Cout > 64) {
         a.m_tiles = ape::ceil_div(M, 128);
         a.n_tiles = ape::ceil_div(p.Cout, 128);
@@ -377,7 +401,7 @@ extern "C" int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const 
     } else {
         a.m_tiles = ape::ceil_div(M, 128);
         a.n_tiles = 1;
-        if (nsplit == 3) launch<3, 128, 64, 4, 1, 64>(a, st); else launch<1, 128, 64, 4, 1, 64>(a, st);
+        if (nsplit == 3) launch<3, 128, 64, 4, 1, 32, true>(a, st); else launch<1, 128, 64, 4, 1, 32, true>(a, st);
     }
     return ape::check_launch("ape_conv2d_nhwc_bf16");
 }

@@ -75,7 +75,7 @@ class Conv:
             self.wp = torch.empty(n, dtype=torch.bfloat16, device=device)
             _lib.check(_lib.lib().ape_pack_weights_bf16(_lib.dptr(self.w), _lib.dptr(self.wp), self.cout, k, _st()),
                        "ape_pack_weights_bf16")
-            self.variant = "conv_bf16_kernel<%d,%s>" % (self.nsplit, "128,128,2,2,64" if self.cout > 64 else "128,64,4,1,64")
+            self.variant = "conv_bf16_kernel<%d,%s>" % (self.nsplit, "128,128,2,2,64,false" if self.cout > 64 else "128,64,4,1,32,true")
         else:
             self.variant = "conv_f32_kernel<%s>" % ("128,2,2" if self.cout > 64 else "64,4,1" if self.cout > 32 else "32,4,1")
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -84,7 +84,7 @@ class Conv:
     def _generic_variant(self, m):
         """name of the template instantiation ape_conv2d_nhwc_* dispatches to (mirrors the C++ rule; profiling label only)"""
         if self.nsplit and self.cout >= 256 and ((-(-self.cout // 256)) * 256 - self.cout) * 8 <= self.cout and m >= 65536:
-            return "conv_bf16_kernel<%d,256,256,4,2,32>" % self.nsplit
+            return "conv_bf16_kernel<%d,256,256,4,2,32,true>" % self.nsplit
         return self.variant
 
     def out_hw(self, h, w):
@@ -141,7 +141,7 @@ class Conv:
             _lib.check(rc, "ape_conv2d_nhwc_f32")
         if prof is not None:
             e1.record()
-            prof.records.append(("conv3x3_halo_kernel<%d,%d,%d,%s>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
+            prof.records.append(("conv3x3_halo_kernel<%d,%d,%d,%s,false>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
                                  if halo else self._generic_variant(b * ho * wo), 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
 
@@ -172,7 +172,7 @@ def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False
     _lib.check(rc, "ape_conv3x3_halo_seghead_bf16")
     if prof is not None:
         e1.record()
-        prof.records.append(("conv3x3_halo_kernel<%d,1,64,%s,head>" % (conv.nsplit, "true" if upsample2x else "false"),
+        prof.records.append(("conv3x3_halo_kernel<%d,1,64,%s,true>" % (conv.nsplit, "true" if upsample2x else "false"),
                              2.0 * b * h * w * conv.cout * 9 * conv.cin_real, e0, e1))
     return label, score
 
