@@ -1,0 +1,38 @@
+"""Training-step timing (development aid): DenseFusion/tools/train.py:205-238 on one synthetic 160x160 / N=1000 sample."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from types import SimpleNamespace
+from autoposeestimation_amd import synthetic as S
+from autoposeestimation_amd.autograd import Adam
+from autoposeestimation_amd.DenseFusion.lib.loss import Loss
+from autoposeestimation_amd.DenseFusion.lib.loss_refiner import Loss_refine
+from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
+from autoposeestimation_amd.DenseFusion.tools.train import train_step
+dev = "cuda:0"
+N, M, NOBJ, HC, WC = 1000, 500, 12, 160, 160
+prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+est, ref = PoseNet(N, NOBJ), PoseRefineNet(N, NOBJ)
+est.load_state_dict(S.posenet_state_dict(NOBJ, seed=1)); ref.load_state_dict(S.refiner_state_dict(NOBJ, seed=2))
+est.to(dev); ref.to(dev); est.set_precision(prec); ref.set_precision(prec)
+g = torch.Generator().manual_seed(0)
+img = torch.randn(1, 3, HC, WC, generator=g); pts = torch.randn(1, N, 3, generator=g) * 0.1
+choose = torch.randperm(HC * WC, generator=g)[:N].sort()[0].view(1, 1, N)
+model = torch.randn(1, M, 3, generator=g) * 0.05; target = model + 0.01
+data = (pts, choose, img, target, model, torch.tensor([[3]]))
+crit, crit_r = Loss(M, [3]), Loss_refine(M, [3])
+for refine in (False, True):
+    opt = SimpleNamespace(w=0.015, refine_start=refine, iteration=2)
+    net = ref if refine else est
+    if refine: est.eval(); ref.train()
+    else: est.train()
+    optim = Adam(net.parameters(), lr=1e-4)
+    for _ in range(2):
+        optim.zero_grad(); train_step(est, ref, crit, crit_r, data, opt, dev); optim.step()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        optim.zero_grad(); train_step(est, ref, crit, crit_r, data, opt, dev); optim.step()
+    torch.cuda.synchronize()
+    print("%s phase (%s): %.1f ms per sample (forward + loss + backward + Adam), symmetric object, N=%d M=%d crop %dx%d"
+          % ("refiner" if refine else "estimator", prec, (time.perf_counter() - t) / n * 1e3, N, M, HC, WC))
