@@ -387,7 +387,7 @@ def _posenet_forward_train(self, img4, points4, choose, o):
     return outs[0], outs[1], outs[2], emb.transpose(1, 2)
 
 
-PoseNet._forward_train = _posenet_forward_train
+PoseNet._forward_train = _posenet_forward_train      # defined after _pspnet_train / _feat_train, which it calls
 
 
 class PoseRefineNet(_HipModule):

@@ -15,6 +15,7 @@
 // Operand traffic drops to ~9.8 KB per MFLOP (3x less), which moves the kernel from the L2 roof to the MFMA roof.
 // Numerics are identical to conv_bf16.hip (same split-bf16 x3 / plain bf16 products, fp32 accumulate), only the K order is
 // (channel chunk, tap) instead of (tap, channel) -- covered by the same conv tests.
+#include <type_traits>
 #include "common.h"
 #include "seg_head.h"
 
@@ -239,71 +240,112 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     store_b(0);
     __syncthreads();
 
+    // The nine taps are unrolled (tap, ky, kx, the halo shift and the prefetch schedule are compile-time constants).  APF: the A
+    // fragments of tap t + 1 are read from the (unchanged) halo image while tap t's MFMAs run, into the other of two register
+    // sets -- after the per-tap barrier only the eight B fragments stand between a wave and its MFMAs.  (With all 16 fragment
+    // reads behind the barrier the eight waves queued ~128 KB on the LDS port before any MFMA could start: ~1/3 of a tap.)
+    constexpr bool APF = !UPS && !HEAD;
     int bbuf = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const int abuf = A_DOUBLE ? (c & 1) : 0;
-        const __bf16* Ah = As + ((size_t)abuf * NPL) * HP * LDH;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            // prefetch the next weight tile (next tap, or tap 0 of the next chunk) and, mid-chunk, the next halo
-            const bool last = tap == 8;
-            const bool more = !(last && c + 1 == nchunks);
-            if (more) load_b(last ? 0 : tap + 1, last ? (c + 1) * CK : c * CK);
-            constexpr int IPT = (A_ITEMS + 8) / 9;          // UPS: halo items fetched per tap
-            float4 raw[IPT][4];
-            const bool nxt = c + 1 < nchunks;
-            if (nxt) {   // single-buffered: the registers hold the next halo until the chunk ends
-                if (!UPS) {
-                    if (tap == 4) load_a((c + 1) * CK);
-                } else {
+    bf16x8 afh[2][TI], afl[2][TI];
+    auto read_a = [&](const __bf16* Ah, int shift, bf16x8 (&h)[TI], bf16x8 (&l)[TI]) {
 #pragma unroll
-                    for (int q = 0; q < IPT; ++q)
-#pragma unroll
-                        for (int j = q; j < A_ITEMS; j += IPT)
-                            if (tap == j / IPT) ups_fetch(j, (c + 1) * CK, raw[q]);
-                }
-            }
-
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int shift = (ky * D) * HW_ + kx * D;
-            const __bf16* Bh = Bs + ((size_t)bbuf * NPL) * BNH * LDH;
-            {
-                bf16x8 ah[TI], al[TI], bh[4], bl[4];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int ao = swz(a_pix16[i] + shift, kq);
-                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
-                    if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(Ah + HP * LDH + ao);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int bo = swz(wn * 64 + j * 16 + r16, kq);
-                    bh[j] = *reinterpret_cast<const bf16x8*>(Bh + bo);
-                    if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(Bh + BNH * LDH + bo);
-                }
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (NPL == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
-            if (more) store_b(bbuf ^ 1);
-            if (UPS && nxt) {
+        for (int i = 0; i < TI; ++i) {
+            int px = a_pix16[i];
+            if (BNH == 128) asm volatile("" : "+v"(px));   // opaque: with the taps unrolled hipcc hoists all 9 x TI swizzled addresses
+                                                           // (8-wave kernels only: the 4-wave ones have the registers and lose 7 %)
+            const int ao = swz(px + shift, kq);
+            h[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
+            if (NPL == 2) l[i] = *reinterpret_cast<const bf16x8*>(Ah + HP * LDH + ao);
+        }
+    };
+    auto tap_body = [&](auto tapc, const int c, const __bf16* Ah) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr bool last = tap == 8;
+        constexpr int ky = tap / 3, kx = tap % 3;
+        constexpr int shift = (ky * D) * HW_ + kx * D;
+        constexpr int nshift = (((tap + 1) / 3) * D) * HW_ + ((tap + 1) % 3) * D;
+        constexpr int S = APF ? (tap & 1) : 0;
+        // prefetch the next weight tile (next tap, or tap 0 of the next chunk) and, mid-chunk, the next halo
+        const bool more = !(last && c + 1 == nchunks);
+        if (more) load_b(last ? 0 : tap + 1, last ? (c + 1) * CK : c * CK);
+        constexpr int IPT = (A_ITEMS + 8) / 9;          // UPS: halo items fetched per tap
+        float4 raw[IPT][4];
+        const bool nxt = c + 1 < nchunks;
+        if (nxt) {   // single-buffered: the registers hold the next halo until the chunk ends
+            if (!UPS) {
+                if (tap == 4) load_a((c + 1) * CK);
+            } else {
 #pragma unroll
                 for (int q = 0; q < IPT; ++q)
 #pragma unroll
                     for (int j = q; j < A_ITEMS; j += IPT)
-                        if (tap == j / IPT) ups_lerp(j, raw[q]);
+                        if (tap == j / IPT) ups_fetch(j, (c + 1) * CK, raw[q]);
             }
-            if (A_DOUBLE && last && c + 1 < nchunks) store_a((c + 1) & 1);
-            __syncthreads();
-            bbuf ^= 1;
         }
+        // keep the global prefetches at the top of the tap: with the taps unrolled (no branch around them) hipcc sinks the loads
+        // to their first use below the MFMAs, which exposes the full L2 round trip in front of every barrier
+        __builtin_amdgcn_sched_barrier(0);
+        const __bf16* Bh = Bs + ((size_t)bbuf * NPL) * BNH * LDH;
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bo = swz(wn * 64 + j * 16 + r16, kq);
+            bh[j] = *reinterpret_cast<const bf16x8*>(Bh + bo);
+            if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(Bh + BNH * LDH + bo);
+        }
+        if (!APF) read_a(Ah, shift, afh[0], afl[0]);
+        auto mfma_rows = [&](int i0, int i1) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (NPL == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[S][i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[S][i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[S][i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        };
+        if (APF && !last && BNH == 64) {
+            read_a(Ah, nshift, afh[1 - S], afl[1 - S]);     // 4-wave kernels: left to hipcc's scheduler (end of the burst)
+            mfma_rows(0, TI);
+        } else if (APF && !last) {
+            // look-ahead reads in the MIDDLE of the MFMA burst: left alone hipcc puts them at its end (the lgkmcnt(0) in front of
+            // the barrier then waits for them), pinned in front of the burst they cost 30 more live registers and spill
+            mfma_rows(0, TI / 2);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(Ah, nshift, afh[1 - S], afl[1 - S]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_rows(TI / 2, TI);
+        } else {
+            mfma_rows(0, TI);
+        }
+        if (more) store_b(bbuf ^ 1);
+        if (UPS && nxt) {
+#pragma unroll
+            for (int q = 0; q < IPT; ++q)
+#pragma unroll
+                for (int j = q; j < A_ITEMS; j += IPT)
+                    if (tap == j / IPT) ups_lerp(j, raw[q]);
+        }
+        if (A_DOUBLE && last && nxt) store_a((c + 1) & 1);
+        __syncthreads();
+        bbuf ^= 1;
+    };
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const int abuf = A_DOUBLE ? (c & 1) : 0;
+        const __bf16* Ah = As + ((size_t)abuf * NPL) * HP * LDH;
+        if (APF) read_a(Ah, 0, afh[0], afl[0]);
+        tap_body(std::integral_constant<int, 0>{}, c, Ah);
+        tap_body(std::integral_constant<int, 1>{}, c, Ah);
+        tap_body(std::integral_constant<int, 2>{}, c, Ah);
+        tap_body(std::integral_constant<int, 3>{}, c, Ah);
+        tap_body(std::integral_constant<int, 4>{}, c, Ah);
+        tap_body(std::integral_constant<int, 5>{}, c, Ah);
+        tap_body(std::integral_constant<int, 6>{}, c, Ah);
+        tap_body(std::integral_constant<int, 7>{}, c, Ah);
+        tap_body(std::integral_constant<int, 8>{}, c, Ah);
         if (!A_DOUBLE && c + 1 < nchunks) {   // single A buffer: refill between chunks (fetched under the taps above)
             store_a(0);
             __syncthreads();

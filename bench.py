@@ -231,7 +231,7 @@ def main():
             "achieved_tflops_algorithmic": round(total_frames * GFLOP_PER_FRAME / dt / 1e3, 2),
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             line["cpu_baseline"] = cpu_baseline(frames, seg_sd, est_sd, ref_sd)
         print(json.dumps(line))
     if dist:
