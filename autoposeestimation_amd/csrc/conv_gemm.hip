@@ -1,0 +1,359 @@
+// GEMM-shaped convolutions (every 1x1 conv / Conv1d(k=1) / Linear of the path, and k x k convs the LDS-halo kernel does not
+// take) on the gfx950 bf16 matrix cores with split-bf16 operands: the successor of conv_bf16_kernel for Cin % 32 == 0.
+//
+// Same contract as ape_conv2d_nhwc_bf16 (NHWC fp32 activations in HBM, packed hi/lo bf16 weight planes, fp32 accumulate,
+// bias / residual / activation fused, XCD-aware bijective tile map).  What differs is the main loop:
+//   * v_mfma_f32_16x16x32_bf16 (one 32-deep k-tile per instruction; the chip holds a higher clock on this shape than on
+//     32x32x16 at equal LDS traffic), wave tile 128x64 (256x256 block, 8 waves) or 64x64 (128x128 / 256x64 block, 4 waves);
+//   * two LDS stages of unpadded 64-B rows, 16-B chunks XOR-swizzled with (row >> 2) & 3: the 16 rows x 4 chunks of one
+//     ds_read_b128 fragment and the 4 rows x 4 chunks of one ds_write_b128 lane group each cover 16 distinct bank slots;
+//   * register staging in the "write after the barrier, re-issue at once" order: tile t+1 sits in registers while tile t
+//     is multiplied; at the top of iteration t it is split into hi/lo planes and written to the other stage (that stage
+//     was last read in iteration t-1, before the barrier), and the global loads of tile t+2 are issued immediately, so a
+//     load has a whole iteration of MFMAs (~3000 cycles) to land and the split + ds_write pass runs under the MFMAs
+//     instead of in front of the barrier; ONE barrier per k-tile.
+// Loads are unconditional (coordinates clamped into the tensor); out-of-image taps are zeroed when the registers are
+// written to LDS, rows >= M and columns >= Cout are computed on clamped data and dropped by the epilogue.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    const float* x;
+    const __bf16* w;   // plane 0 (hi) at w, plane 1 (lo) at w + plane_stride
+    const float* bias;
+    const float* res;
+    float* y;
+    ape_conv_params p;
+    int M, Kp, m_tiles, n_tiles, nk;
+    long plane_stride;
+};
+
+__device__ __forceinline__ float activate(float v, int act, float alpha)
+{
+    switch (act) {
+        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
+        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& lo)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (__bf16)v0[e];
+        lo[e] = (__bf16)(v0[e] - (float)hi[e]);
+        hi[4 + e] = (__bf16)v1[e];
+        lo[4 + e] = (__bf16)(v1[e] - (float)hi[4 + e]);
+    }
+}
+
+constexpr int BK = 32;
+
+// element offset of 16-B chunk c of tile row `row` (rows of 32 bf16)
+__device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^ ((row >> 2) & 3)) << 3); }
+
+// PURE: 1x1 / stride 1 / pad 0 (a row-major GEMM: row m of A starts at x + m * ldx + xoff)
+template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs a)
+{
+    constexpr int NT = WM * WN * 64;
+    constexpr int NPL = NSPLIT == 3 ? 2 : 1;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_IT = BM * 4 / NT;            // 8-float chunks per thread
+    constexpr int B_IT = (BN * 4 + NT - 1) / NT; // 16-B chunks per thread per plane (the last one predicated when BN*4 % NT != 0)
+    constexpr bool B_RAGGED = (BN * 4) % NT != 0;
+    static_assert(BM * 4 % NT == 0 && A_IT >= 1 && B_IT >= 1, "staging shape");
+    static_assert(WTM % 32 == 0 && WTN % 16 == 0 && BM % 64 == 0, "wave tile");
+
+    constexpr int ELD = BN + 4;                  // floats per staged epilogue row
+    constexpr size_t kStageElems = (size_t)NPL * (BM + BN) * BK;             // bf16 per pipeline stage
+    constexpr size_t kOperandBytes = 2 * kStageElems * 2, kEpiBytes = (size_t)64 * ELD * 4;
+    __shared__ __attribute__((aligned(16))) char smem_raw[kOperandBytes > kEpiBytes ? kOperandBytes : kEpiBytes];
+    __bf16* const S0 = reinterpret_cast<__bf16*>(smem_raw);
+    auto a_tile = [&](int stage, int pl) { return S0 + stage * kStageElems + (size_t)pl * BM * BK; };
+    auto b_tile = [&](int stage, int pl) { return S0 + stage * kStageElems + (size_t)NPL * BM * BK + (size_t)pl * BN * BK; };
+
+    const ape_conv_params& p = a.p;
+    const int nwg = a.m_tiles * a.n_tiles;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const int n_tile = logical % a.n_tiles;
+    const int m_tile = logical / a.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- staging coordinates -------------------------------------------------------------------------------------
+    const int sc = tid & 3;          // 16-B chunk (8 elements) of the 32-deep k-tile
+    const int srow = tid >> 2;       // + i * (NT / 4)
+    unsigned a_off[A_IT];            // PURE: element offset of the row start;  else: b * H
+    int a_iy0[PURE ? 1 : A_IT], a_ix0[PURE ? 1 : A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + srow + i * (NT / 4);
+        m = m < a.M ? m : a.M - 1;
+        if (PURE) {
+            a_off[i] = (unsigned)m * (unsigned)p.ldx + (unsigned)p.xoff + sc * 8;
+        } else {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
+            a_off[i] = (unsigned)(b * p.H);
+        }
+    }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        int n = n0 + srow + i * (NT / 4);
+        n = n < p.Cout ? n : p.Cout - 1;      // (also keeps the predicated-off rows of a ragged last item in bounds)
+        b_off[i] = (unsigned)n * (unsigned)a.Kp + sc * 8;
+    }
+
+    f32x4 areg[A_IT][2];
+    u32x4 breg[NPL][B_IT];
+    unsigned a_ok = 0;                       // bit i: item i of the tile held in registers lies inside the image
+    int t_ci0 = 0, t_ky = 0, t_kx = 0;       // (chunk, tap) of the NEXT tile to load; K order = chunk outer, taps inner
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    auto load_tiles = [&]() {
+        unsigned kb;
+        if (PURE) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.x + a_off[i] + (unsigned)t_ci0);
+                areg[i][0] = src[0];
+                areg[i][1] = src[1];
+            }
+            kb = (unsigned)t_ci0;
+            t_ci0 += BK;
+        } else {
+            const int dy = t_ky * p.dil, dx = t_kx * p.dil;
+            a_ok = 0;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned off = (unsigned)((((int)a_off[i] + clampi(iy, p.H - 1)) * p.W + clampi(ix, p.W - 1)) * p.ldx + p.xoff + t_ci0 + sc * 8);
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.x + off);
+                areg[i][0] = src[0];
+                areg[i][1] = src[1];
+                a_ok |= ok ? (1u << i) : 0u;
+            }
+            kb = (unsigned)((t_ky * p.KW + t_kx) * p.Cin + t_ci0);
+            if (++t_kx == p.KW) { t_kx = 0; if (++t_ky == p.KH) { t_ky = 0; t_ci0 += BK; } }
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                breg[pl][i] = *reinterpret_cast<const u32x4*>(a.w + pl * a.plane_stride + b_off[i] + kb);
+    };
+    auto store_tiles = [&](int stage) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const bool ok = PURE || ((a_ok >> i) & 1u);
+            bf16x8 hi, lo;
+            split8(ok ? areg[i][0] : z4, ok ? areg[i][1] : z4, hi, lo);
+            const int o = lds_off(srow + i * (NT / 4), sc);
+            *reinterpret_cast<bf16x8*>(a_tile(stage, 0) + o) = hi;
+            if (NPL == 2) *reinterpret_cast<bf16x8*>(a_tile(stage, NPL - 1) + o) = lo;
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                if (!B_RAGGED || i + 1 < B_IT || srow + i * (NT / 4) < BN)
+                    *reinterpret_cast<u32x4*>(b_tile(stage, pl) + lds_off(srow + i * (NT / 4), sc)) = breg[pl][i];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 15, fc = lane >> 4;
+    const int a_row0 = wm * WTM + frow, b_row0 = wn * WTN + frow;
+    bf16x8 bh[TN], bl[TN];
+    auto read_b = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int o = lds_off(b_row0 + j * 16, fc);
+            bh[j] = *reinterpret_cast<const bf16x8*>(b_tile(stage, 0) + o);
+            if (NPL == 2) bl[j] = *reinterpret_cast<const bf16x8*>(b_tile(stage, NPL - 1) + o);
+        }
+    };
+    constexpr int TMH = TM / 2;
+    bf16x8 ah[TMH], al[TMH];
+    auto read_a = [&](int stage, int i0) {
+#pragma unroll
+        for (int i = 0; i < TMH; ++i) {
+            const int o = lds_off(a_row0 + (i0 + i) * 16, fc);
+            ah[i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, 0) + o);
+            if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, NPL - 1) + o);
+        }
+    };
+    auto mfma_half = [&](int i0) {
+#pragma unroll
+        for (int i = 0; i < TMH; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (NPL == 2) {
+                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+                }
+                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+            }
+    };
+
+    const int nk = a.nk;
+    load_tiles();
+    store_tiles(0);
+    if (nk > 1) load_tiles();
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        read_b(cur);
+        read_a(cur, 0);
+        if (kt + 1 < nk) store_tiles(cur ^ 1);      // tile kt+1: registers -> the stage last read in iteration kt-1
+        if (kt + 2 < nk) load_tiles();              // tile kt+2: lands during this iteration's MFMAs
+        mfma_half(0);
+        read_a(cur, TMH);
+        mfma_half(TMH);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time, reusing the operand stages) -> 16-byte coalesced stores
+    // with bias / residual / activation applied on float4s
+    float* stage = reinterpret_cast<float*>(smem_raw);
+    const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
+#pragma unroll 1
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = wm * WTM + i * 16;
+            if (rbase / 64 != pass) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    stage[(rbase - pass * 64 + fc * 4 + e) * ELD + wn * WTN + j * 16 + frow] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int it = tid; it < 64 * (BN / 4); it += NT) {
+            const int row = it / (BN / 4), c4 = it - row * (BN / 4);
+            const int m = m0 + pass * 64 + row, n = n0 + c4 * 4;
+            if (m >= a.M || n >= p.Cout) continue;
+            const float4 v = *reinterpret_cast<const float4*>(&stage[row * ELD + c4 * 4]);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            const int nvalid = min(4, p.Cout - n);
+            const float* bptr = a.bias ? a.bias + (p.bias_bstride ? (size_t)(m / HoWo) * p.bias_bstride : 0) + n : nullptr;
+            if (vec_ok && nvalid == 4) {
+                if (bptr) { vv[0] += bptr[0]; vv[1] += bptr[1]; vv[2] += bptr[2]; vv[3] += bptr[3]; }
+                if (a.res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(a.res + (size_t)m * p.ldr + p.roff + n);
+                    vv[0] += rr.x; vv[1] += rr.y; vv[2] += rr.z; vv[3] += rr.w;
+                }
+                const float4 o = make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha),
+                                             activate(vv[2], p.act, p.alpha), activate(vv[3], p.act, p.alpha));
+                *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o;
+            } else {
+                for (int k = 0; k < nvalid; ++k) {
+                    float t = vv[k];
+                    if (bptr) t += bptr[k];
+                    if (a.res) t += a.res[(size_t)m * p.ldr + p.roff + n + k];
+                    a.y[(size_t)m * p.ldy + p.yoff + n + k] = activate(t, p.act, p.alpha);
+                }
+            }
+        }
+    }
+}
+
+template <int NSPLIT, int BM, int BN, int WM, int WN>
+void launch(GemmArgs& a, bool pure, hipStream_t st)
+{
+    a.m_tiles = ape::ceil_div(a.M, BM);
+    a.n_tiles = ape::ceil_div(a.p.Cout, BN);
+    if (pure)
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+}
+
+bool supported(const ape_conv_params& p)
+{
+    if (p.B < 0 || p.H < 1 || p.W < 1 || p.Cin < 32 || p.Cin % 32 || p.Cout < 1 || p.KH < 1 || p.KW < 1 || p.stride < 1 ||
+        p.dil < 1 || p.pad < 0 || p.Ho < 1 || p.Wo < 1 || p.ups != 0)
+        return false;
+    if (p.ldx % 4 || p.xoff % 4 || p.xoff + p.Cin > p.ldx || p.yoff + p.Cout > p.ldy) return false;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return false;
+    const int ho = (p.H + 2 * p.pad - p.dil * (p.KH - 1) - 1) / p.stride + 1;
+    const int wo = (p.W + 2 * p.pad - p.dil * (p.KW - 1) - 1) / p.stride + 1;
+    if (ho != p.Ho || wo != p.Wo) return false;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    // 32-bit element offsets into x and w
+    if (M > (1L << 30) || (long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * p.KH * p.KW * p.Cin >= (1L << 31)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int ape_conv_gemm_supported(const ape_conv_params* params) { return params && supported(*params) ? 1 : 0; }
+
+/* variant: 0 = chosen from the shape; 1 = 256x256 block (8 waves); 2 = 128x128 block (4 waves); 3 = 256x64 block (4 waves);
+ * 4 = 256x192 block (8 waves; Cout = 576 of the up_2 channel mix is 3 x 192) */
+extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                                  const ape_conv_params* params, int nsplit, int variant, void* stream)
+{
+    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3) || variant < 0 || variant > 4) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (!supported(p)) return APE_EINVAL;
+    if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    if (M == 0) return APE_OK;
+    GemmArgs a;
+    a.x = x; a.w = (const __bf16*)w_packed; a.bias = bias; a.res = residual; a.y = y; a.p = p;
+    a.M = (int)M;
+    const int K = p.KH * p.KW * p.Cin;
+    a.Kp = (K + 7) / 8 * 8;
+    a.nk = K / BK;
+    a.plane_stride = (long)p.Cout * a.Kp;
+    const bool pure = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) {
+        const int waste256 = ape::ceil_div(p.Cout, 256) * 256 - p.Cout;
+        const int waste192 = ape::ceil_div(p.Cout, 192) * 192 - p.Cout;
+        if (p.Cout <= 64) variant = 3;
+        // the 256-row blocks need about a chip's worth of workgroups (256 CUs); below that the 128x128 block fills it better
+        else if (p.Cout >= 256 && waste256 * 8 <= p.Cout && K >= 256 && (long)ape::ceil_div(M, 256) * ape::ceil_div(p.Cout, 256) >= 192) variant = 1;
+        else if (p.Cout >= 192 && waste192 * 8 <= p.Cout && K >= 256 && (long)ape::ceil_div(M, 256) * ape::ceil_div(p.Cout, 192) >= 192) variant = 4;
+        else variant = 2;
+    }
+    if (variant == 1) {
+        if (nsplit == 3) launch<3, 256, 256, 2, 4>(a, pure, st); else launch<1, 256, 256, 2, 4>(a, pure, st);
+    } else if (variant == 2) {
+        if (nsplit == 3) launch<3, 128, 128, 2, 2>(a, pure, st); else launch<1, 128, 128, 2, 2>(a, pure, st);
+    } else if (variant == 3) {
+        if (nsplit == 3) launch<3, 256, 64, 4, 1>(a, pure, st); else launch<1, 256, 64, 4, 1>(a, pure, st);
+    } else {
+        if (nsplit == 3) launch<3, 256, 192, 2, 4>(a, pure, st); else launch<1, 256, 192, 2, 4>(a, pure, st);
+    }
+    return ape::check_launch("ape_conv_gemm_bf16");
+}

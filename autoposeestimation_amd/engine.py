@@ -6,6 +6,7 @@ Device layout (DESIGN.md "Data layout in HBM"): activations NHWC fp32 `[B,H,W,C]
 weights `[Cout][KH][KW][Cin4]` with Cin zero-padded to a multiple of 4.
 """
 import ctypes
+import os
 
 import torch
 
@@ -42,6 +43,8 @@ PROFILE = None   # set to a LaunchProfile() to time conv launches
 #   "bf16"   plain bf16 operands (2^-8)                                 2.5 PFLOP/s peak
 PRECISIONS = ("f32", "bf16x3", "bf16")
 USE_HALO_KERNEL = True    # route eligible 3x3 convs of the bf16 paths to the LDS-halo kernel (conv3x3_halo.hip)
+USE_GEMM_KERNEL = os.environ.get("APE_USE_GEMM_KERNEL", "1") != "0"    # route Cin % 32 == 0 layers the halo kernel does not take to conv_gemm.hip (else conv_bf16.hip)
+GEMM_VARIANT = 0          # 0 = chosen from the shape; 1..4 force a block shape (tools/microbench_generic.py)
 
 
 def pack_conv_weight(w, device):
@@ -87,6 +90,24 @@ class Conv:
             return "conv_bf16_kernel<%d,256,256,4,2,32,true>" % self.nsplit
         return self.variant
 
+    def _gemm_variant(self, m):
+        """name of the conv_gemm.hip instantiation ape_conv_gemm_bf16 dispatches to (mirrors the C++ rule; profiling label only)"""
+        pure = "true" if (self.kh == 1 and self.kw == 1 and self.stride == 1 and self.pad == 0) else "false"
+        v = GEMM_VARIANT
+        if v == 0:
+            k = self.kh * self.kw * self.cin
+            if self.cout <= 64:
+                v = 3
+            elif (self.cout >= 256 and ((-(-self.cout // 256)) * 256 - self.cout) * 8 <= self.cout and k >= 256
+                  and -(-m // 256) * -(-self.cout // 256) >= 192):
+                v = 1
+            elif (self.cout >= 192 and ((-(-self.cout // 192)) * 192 - self.cout) * 8 <= self.cout and k >= 256
+                  and -(-m // 256) * -(-self.cout // 192) >= 192):
+                v = 4
+            else:
+                v = 2
+        return "conv_gemm_kernel<%d,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4"}[v], pure)
+
     def out_hw(self, h, w):
         ho = (h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1
         wo = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
@@ -125,11 +146,18 @@ class Conv:
         # 20x20 / 40x40 would waste 30..60 % of the MFMAs; the flattened-M generic kernel has no such edge effect)
         halo = (self.nsplit and USE_HALO_KERNEL and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256))
                 and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
+        gemm = False
         if halo:
             rc = _lib.lib().ape_conv3x3_halo_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                   _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
                                                   self.nsplit, _st())
             _lib.check(rc, "ape_conv3x3_halo_bf16")
+        elif self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)):
+            gemm = True
+            rc = _lib.lib().ape_conv_gemm_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
+                                               _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
+                                               self.nsplit, GEMM_VARIANT, _st())
+            _lib.check(rc, "ape_conv_gemm_bf16")
         elif self.nsplit:
             rc = _lib.lib().ape_conv2d_nhwc_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                  _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
@@ -142,7 +170,7 @@ class Conv:
         if prof is not None:
             e1.record()
             prof.records.append(("conv3x3_halo_kernel<%d,%d,%d,%s,false>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
-                                 if halo else self._generic_variant(b * ho * wo), 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+                                 if halo else self._gemm_variant(b * ho * wo) if gemm else self._generic_variant(b * ho * wo), 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
 
 

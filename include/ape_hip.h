@@ -80,6 +80,14 @@ long ape_packed_weights_bf16_elems(int cout, int K);
 int ape_pack_weights_bf16(const float* w, void* out, int cout, int K, void* stream);
 int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                          const ape_conv_params* params_host, int nsplit, void* stream);
+/* Cin % 32 == 0 successor of ape_conv2d_nhwc_bf16 (same arguments, packed weights, numerics class and fused epilogue):
+ * 16x16x32 MFMA, swizzled double-buffered LDS stages, register staging that writes tile t+1 after the barrier and re-issues
+ * tile t+2 at once.  Takes every 1x1 conv / Conv1d(k=1) / Linear of the path (pspnet.py:12-17,53, network.py:42-49,76-92,
+ * 139-146,175-182) and the k x k convs the LDS-halo kernel leaves.  variant: 0 = block shape chosen from (M, Cout, K),
+ * 1 = 256x256, 2 = 128x128, 3 = 256x64, 4 = 256x192 (tuning aid).  ape_conv_gemm_supported(params) says whether it applies. */
+int ape_conv_gemm_supported(const ape_conv_params* params_host);
+int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                       const ape_conv_params* params_host, int nsplit, int variant, void* stream);
 /* 3x3 / stride 1 / pad == dilation in {1,2,4} / Cin % 32 == 0 specialisation of ape_conv2d_nhwc_bf16: the input halo of
  * a 16x16-pixel tile is staged once per 32-channel chunk in LDS and shared by the nine taps (3x less operand traffic).
  * Same arguments, packed weights, numerics and epilogue; ape_conv3x3_halo_supported(params) says whether it applies. */

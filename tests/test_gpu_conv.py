@@ -51,6 +51,46 @@ def test_conv_matches_torch(case, precision):
     assert err <= TOL[precision], (case, precision, err)
 
 
+GEMM_CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil
+    (1, 300, 1, 64, 200, 1, 1, 0, 1),    # pure GEMM, ragged M and N
+    (2, 64, 130, 32, 288, 1, 1, 0, 1),   # single k-tile (nk = 1), M = 16640
+    (1, 23, 21, 96, 72, 3, 1, 1, 1),     # 3x3 with zero-filled taps, odd image, three 32-channel chunks
+    (1, 12, 12, 256, 512, 3, 1, 4, 4),   # dilation 4 (crop layer4 geometry)
+    (1, 9, 11, 64, 128, 1, 2, 0, 1),     # 1x1 stride 2 (not a pure GEMM)
+]
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_kernel_every_block_shape(case, variant, precision):
+    """conv_gemm.hip with each block shape forced (256x256 / 128x128 / 256x64 / 256x192), against F.conv2d and against the older
+    conv_bf16.hip kernel (same operand rounding, different summation order)."""
+    from autoposeestimation_amd import engine as E
+    b, h, w, cin, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000 + variant)
+    x = torch.randn(b, cin, h, w, generator=g) * 3
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    want = F.conv2d(x, wt, bias, stride, pad, dil)
+    res = torch.randn(want.shape, generator=g)
+    want = F.relu(want + res)
+    conv = E.Conv(wt, bias, stride, pad, dil, E.ACT_RELU, device="cuda", precision=precision)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().cuda()
+    old = (E.USE_HALO_KERNEL, E.USE_GEMM_KERNEL, E.GEMM_VARIANT)
+    try:
+        E.USE_HALO_KERNEL, E.USE_GEMM_KERNEL, E.GEMM_VARIANT = False, True, variant
+        got = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
+        E.USE_GEMM_KERNEL = False
+        ref = conv(xd, residual=rd).permute(0, 3, 1, 2).cpu()
+    finally:
+        E.USE_HALO_KERNEL, E.USE_GEMM_KERNEL, E.GEMM_VARIANT = old
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() / scale <= TOL[precision], (case, variant, precision)
+    assert (got - ref).abs().max().item() / scale <= 2e-6, (case, variant, precision)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_conv_channel_slices_per_image_bias_prelu(precision):
     """(ld, offset) slices on input/output/residual, per-image bias, PReLU and sigmoid epilogues."""
