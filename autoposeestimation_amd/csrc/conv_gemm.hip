@@ -5,7 +5,7 @@
 // bias / residual / activation fused, XCD-aware bijective tile map).  What differs is the main loop:
 //   * v_mfma_f32_16x16x32_bf16 (one 32-deep k-tile per instruction; the chip holds a higher clock on this shape than on
 //     32x32x16 at equal LDS traffic), wave tile 128x64 (256x256 block, 8 waves) or 64x64 (128x128 / 256x64 block, 4 waves);
-//   * two LDS stages of unpadded 64-B rows, 16-B chunks XOR-swizzled with (row >> 2) & 3: the 16 rows x 4 chunks of one
+//   * two LDS stages of unpadded 64-B rows, 16-B chunks XOR-swizzled with -(row >> 2) & 3: the 16 rows x 4 chunks of one
 //     ds_read_b128 fragment and the 4 rows x 4 chunks of one ds_write_b128 lane group each cover 16 distinct bank slots;
 //   * register staging in the "write after the barrier, re-issue at once" order: tile t+1 sits in registers while tile t
 //     is multiplied; at the top of iteration t it is split into hi/lo planes and written to the other stage (that stage
@@ -30,6 +30,7 @@ struct GemmArgs {
     float* y;
     ape_conv_params p;
     int M, Kp, m_tiles, n_tiles, nk;
+    int dbg;           // ablation bits (timing experiments only, results are wrong): 1 no in-loop global loads, 2 no in-loop LDS restage, 4 no MFMAs
     long plane_stride;
 };
 
@@ -57,12 +58,22 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& h
 constexpr int BK = 32;
 
 // element offset of 16-B chunk c of tile row `row` (rows of 32 bf16)
-__device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^ ((row >> 2) & 3)) << 3); }
+// (ds_read_b128 services the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: the permutation that keeps the 16 lanes of
+// a group on 16 distinct 16-B bank slots for the fragment map lane -> (row = lane & 15, chunk = lane >> 4) is chunk ^ (-(row >> 2) & 3))
+__device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^ ((0 - (row >> 2)) & 3)) << 3); }
 
 // PURE: 1x1 / stride 1 / pad 0 (a row-major GEMM: row m of A starts at x + m * ldx + xoff)
-template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE>
+//
+// PP ("ping-pong", 8-wave blocks): the k-tile is cut into four segments -- read fragments + restage | MFMAs of the first row
+// half | read the second half's A fragments | its MFMAs -- each closed by a barrier, and the waves of the second row half
+// (wm = 1, the second wave of every SIMD) run ONE segment behind the first: while one wave of a SIMD issues its 48 MFMAs the
+// other one does its LDS reads / split / ds_writes / global loads, instead of all eight waves queueing on the LDS port and
+// then all eight on the matrix pipes.  The LDS stage protocol is unchanged (tile t+1 is written >= 2 barriers after the last
+// read of tile t-1 and >= 2 barriers before the first read of tile t+1 by either group).
+template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP>
 __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs a)
 {
+    static_assert(!PP || WM == 2, "the ping-pong schedule pairs the two row halves of an 8-wave block");
     constexpr int NT = WM * WN * 64;
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
                 areg[i][1] = src[1];
             }
             kb = (unsigned)t_ci0;
-            t_ci0 += BK;
+            t_ci0 = t_ci0 + BK < p.Cin ? t_ci0 + BK : t_ci0;      // the loads run two tiles ahead of the loop: stay inside K
         } else {
             const int dy = t_ky * p.dil, dx = t_kx * p.dil;
             a_ok = 0;
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
                 a_ok |= ok ? (1u << i) : 0u;
             }
             kb = (unsigned)((t_ky * p.KW + t_kx) * p.Cin + t_ci0);
-            if (++t_kx == p.KW) { t_kx = 0; if (++t_ky == p.KH) { t_ky = 0; t_ci0 += BK; } }
+            if (++t_kx == p.KW) { t_kx = 0; if (++t_ky == p.KH) { t_ky = 0; t_ci0 = t_ci0 + BK < p.Cin ? t_ci0 + BK : t_ci0; } }
         }
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
@@ -224,20 +235,35 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
     const int nk = a.nk;
     load_tiles();
     store_tiles(0);
-    if (nk > 1) load_tiles();
+    load_tiles();
     __syncthreads();
+    const bool behind = PP && __builtin_amdgcn_readfirstlane(wm) == 1;
+    auto seg = [&]() {
+        if (PP) {
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (behind) __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         read_b(cur);
         read_a(cur, 0);
-        if (kt + 1 < nk) store_tiles(cur ^ 1);      // tile kt+1: registers -> the stage last read in iteration kt-1
-        if (kt + 2 < nk) load_tiles();              // tile kt+2: lands during this iteration's MFMAs
+        // branch-free body (one basic block, so the scheduler can place the restage / loads between the MFMAs): the last two
+        // iterations restage and load a clamped, never-read tile
+        store_tiles(cur ^ 1);      // tile kt+1: registers -> the stage last read in iteration kt-1
+        load_tiles();              // tile kt+2: lands during this iteration's MFMAs
+        seg();
         mfma_half(0);
+        seg();
         read_a(cur, TMH);
+        seg();
         mfma_half(TMH);
         __syncthreads();
     }
+    if (PP && !behind) __syncthreads();
 
     // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time, reusing the operand stages) -> 16-byte coalesced stores
     // with bias / residual / activation applied on float4s
@@ -286,15 +312,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
     }
 }
 
-template <int NSPLIT, int BM, int BN, int WM, int WN>
+template <int NSPLIT, int BM, int BN, int WM, int WN, bool PP = false>
 void launch(GemmArgs& a, bool pure, hipStream_t st)
 {
     a.m_tiles = ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.p.Cout, BN);
     if (pure)
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true, PP>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false, PP>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
 }
 
 bool supported(const ape_conv_params& p)
@@ -322,7 +348,7 @@ extern "C" int ape_conv_gemm_supported(const ape_conv_params* params) { return p
 extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                                   const ape_conv_params* params, int nsplit, int variant, void* stream)
 {
-    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3) || variant < 0 || variant > 4) return APE_EINVAL;
+    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3) || variant < 0 || (variant & 15) > 5) return APE_EINVAL;
     const ape_conv_params& p = *params;
     if (!supported(p)) return APE_EINVAL;
     if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
@@ -335,6 +361,8 @@ extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const fl
     a.Kp = (K + 7) / 8 * 8;
     a.nk = K / BK;
     a.plane_stride = (long)p.Cout * a.Kp;
+    a.dbg = variant >> 4;
+    variant &= 15;
     const bool pure = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
     hipStream_t st = (hipStream_t)stream;
     if (variant == 0) {
@@ -352,8 +380,10 @@ extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const fl
         if (nsplit == 3) launch<3, 128, 128, 2, 2>(a, pure, st); else launch<1, 128, 128, 2, 2>(a, pure, st);
     } else if (variant == 3) {
         if (nsplit == 3) launch<3, 256, 64, 4, 1>(a, pure, st); else launch<1, 256, 64, 4, 1>(a, pure, st);
-    } else {
+    } else if (variant == 4) {
         if (nsplit == 3) launch<3, 256, 192, 2, 4>(a, pure, st); else launch<1, 256, 192, 2, 4>(a, pure, st);
+    } else {
+        if (nsplit == 3) launch<3, 256, 256, 2, 4, true>(a, pure, st); else launch<1, 256, 256, 2, 4, true>(a, pure, st);
     }
     return ape::check_launch("ape_conv_gemm_bf16");
 }

@@ -22,8 +22,13 @@ class LaunchProfile:
     """Optional per-launch HIP-event timing of the conv kernels on torch's current stream (bench.py's roofline leg).
     Events are recorded on the very stream the kernel is enqueued on; durations are read after the final sync."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []       # (kernel variant, algorithmic flop, start event, end event)
+        self.only = only        # None: time every conv launch; else a set of variant labels (the others run un-timed, without
+                                # the two event packets per launch that cost ~4 us of dispatch gap each)
+
+    def wants(self, label):
+        return self.only is None or label in self.only
 
     def summary(self):
         out = {}
@@ -93,7 +98,7 @@ class Conv:
     def _gemm_variant(self, m):
         """name of the conv_gemm.hip instantiation ape_conv_gemm_bf16 dispatches to (mirrors the C++ rule; profiling label only)"""
         pure = "true" if (self.kh == 1 and self.kw == 1 and self.stride == 1 and self.pad == 0) else "false"
-        v = GEMM_VARIANT
+        v = GEMM_VARIANT & 15
         if v == 0:
             k = self.kh * self.kw * self.cin
             if self.cout <= 64:
@@ -106,7 +111,7 @@ class Conv:
                 v = 4
             else:
                 v = 2
-        return "conv_gemm_kernel<%d,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4"}[v], pure)
+        return "conv_gemm_kernel<%d,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4", 5: "256,256,2,4,pp"}[v], pure)
 
     def out_hw(self, h, w):
         ho = (h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1
@@ -138,22 +143,26 @@ class Conv:
                        dil=self.dil, act=self.act if act is None else act, alpha=self.alpha,
                        bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff,
                        ups=int(bool(upsample2x)))
-        prof = PROFILE
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         # the halo kernel tiles the image in 16x16 pixels: use it only when those tiles are mostly full (crop feature maps of
         # 20x20 / 40x40 would waste 30..60 % of the MFMAs; the flattened-M generic kernel has no such edge effect)
         halo = (self.nsplit and USE_HALO_KERNEL and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256))
                 and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
-        gemm = False
+        gemm = bool(not halo and self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)))
+        prof = PROFILE
+        if prof is not None:
+            label = ("conv3x3_halo_kernel<%d,%d,%d,%s,false>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
+                     if halo else self._gemm_variant(b * ho * wo) if gemm else self._generic_variant(b * ho * wo))
+            if not prof.wants(label):
+                prof = None
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if halo:
             rc = _lib.lib().ape_conv3x3_halo_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                   _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
                                                   self.nsplit, _st())
             _lib.check(rc, "ape_conv3x3_halo_bf16")
-        elif self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)):
-            gemm = True
+        elif gemm:
             rc = _lib.lib().ape_conv_gemm_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
                                                self.nsplit, GEMM_VARIANT, _st())
@@ -169,8 +178,7 @@ class Conv:
             _lib.check(rc, "ape_conv2d_nhwc_f32")
         if prof is not None:
             e1.record()
-            prof.records.append(("conv3x3_halo_kernel<%d,%d,%d,%s,false>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
-                                 if halo else self._gemm_variant(b * ho * wo) if gemm else self._generic_variant(b * ho * wo), 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+            prof.records.append((label, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
 
 
@@ -191,6 +199,9 @@ def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False
     label = torch.empty(b, h, w, dtype=torch.uint8, device=x.device)
     score = torch.empty(b, h, w, dtype=torch.float32, device=x.device)
     prof = PROFILE
+    hlabel = "conv3x3_halo_kernel<%d,1,64,%s,true>" % (conv.nsplit, "true" if upsample2x else "false")
+    if prof is not None and not prof.wants(hlabel):
+        prof = None
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -200,8 +211,7 @@ def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False
     _lib.check(rc, "ape_conv3x3_halo_seghead_bf16")
     if prof is not None:
         e1.record()
-        prof.records.append(("conv3x3_halo_kernel<%d,1,64,%s,true>" % (conv.nsplit, "true" if upsample2x else "false"),
-                             2.0 * b * h * w * conv.cout * 9 * conv.cin_real, e0, e1))
+        prof.records.append((hlabel, 2.0 * b * h * w * conv.cout * 9 * conv.cin_real, e0, e1))
     return label, score
 
 

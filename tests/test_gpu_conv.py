@@ -61,7 +61,7 @@ GEMM_CASES = [  # B, H, W, Cin, Cout, k, stride, pad, dil
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", GEMM_CASES)
 def test_gemm_kernel_every_block_shape(case, variant, precision):
     """conv_gemm.hip with each block shape forced (256x256 / 128x128 / 256x64 / 256x192), against F.conv2d and against the older

@@ -31,7 +31,7 @@ shapes = [
     ("pose heads l2 640->256", 64, 1000, 1, 640, 256, 1, 1, 0, 1),
     ("pose heads l3 256->128", 64, 1000, 1, 256, 128, 1, 1, 0, 1),
 ]
-arms = [("old", False, 0), ("g256", True, 1), ("g128", True, 2), ("g256x64", True, 3), ("g256x192", True, 4), ("auto", True, 0)]
+arms = [("old", False, 0), ("g256", True, 1), ("g128", True, 2), ("g256x64", True, 3), ("g256x192", True, 4), ("g256pp", True, 5)]
 for name, b, h, w, cin, cout, k, s, p, d in shapes:
     x = torch.randn(b, h, w, cin, device="cuda")
     wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
