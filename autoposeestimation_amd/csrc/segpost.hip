@@ -84,10 +84,30 @@ __device__ void uf_union(int* L, int a, int b)
     }
 }
 
-__global__ void ccl_init_kernel(const uint8_t* __restrict__ label, int* __restrict__ L, long npix)
+// Run-based labelling: a wave covers 64 consecutive pixels; inside it every pixel is pointed at the first pixel of its
+// horizontal run straight away (ballot of the run boundaries, no atomics), so the union-find only has to join RUNS:
+//   * a run that continues across the wave's left edge joins the previous wave's run (one union per wave at most);
+//   * a run joins the row above once per overlap with a run there (at the first pixel of the overlap), plus the two diagonal
+//     contacts that no vertical contact implies.
+// A 126 x 126 object costs ~130 unions instead of ~16 000 per-pixel unions all chasing the same root.  Unions link the larger
+// root under the smaller, so the final root of a component is its smallest pixel index whatever the order: identical labels.
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ label, int* __restrict__ L, int W, long npix)
 {
-    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x)
-        L[p] = label[p] ? (int)p : -1;
+    const long nround = (npix + 63) & ~63L;          // whole waves stay converged for the ballot
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < nround; p += (long)gridDim.x * blockDim.x) {
+        const int lane = threadIdx.x & 63;
+        const bool in = p < npix;
+        const int c = in ? label[p] : 0;
+        const int x = in ? (int)(p % W) : 0;
+        const int cl = __shfl_up(c, 1);
+        const bool cont = in && lane > 0 && x > 0 && cl == c;          // continues the run of the lane to the left
+        const unsigned long long starts = __ballot(!cont);
+        if (in) {
+            const unsigned long long below = starts & ((2ULL << lane) - 1ULL);      // lane 63: 2<<63 wraps to 0, -1 = all ones
+            const int start = 63 - __clzll(below);
+            L[p] = c ? (int)(p - (lane - start)) : -1;
+        }
+    }
 }
 
 // L indices are global over the batch (frame b occupies [b*H*W, (b+1)*H*W)), so roots are unique batch-wide.
@@ -98,18 +118,21 @@ __global__ void ccl_merge_kernel(const uint8_t* __restrict__ label, int* __restr
         if (!c) continue;
         const int x = p % W;
         const int y = (p / W) % H;
-        if (x > 0 && label[p - 1] == c) uf_union(L, (int)p, (int)p - 1);
+        const bool left = x > 0 && label[p - 1] == c;
+        if (left && (threadIdx.x & 63) == 0) uf_union(L, (int)p, (int)p - 1);   // in-wave run links were made by ccl_init_kernel
         if (y > 0) {
+            const bool nw = x > 0 && label[p - W - 1] == c;
             if (label[p - W] == c) {
-                uf_union(L, (int)p, (int)(p - W));  // N present: NW and NE are already linked to N by their own W-links
+                // N present (NW and NE hang on N's run): one union per overlap of this run with a run above, at its first pixel
+                if (!left || !nw) uf_union(L, (int)p, (int)(p - W));
             } else {
-                if (x > 0 && label[p - W - 1] == c) uf_union(L, (int)p, (int)(p - W - 1));
-                if (x < W - 1 && label[p - W + 1] == c) uf_union(L, (int)p, (int)(p - W + 1));
+                if (nw && !left) uf_union(L, (int)p, (int)(p - W - 1));        // with a left neighbour, ITS N is this NW
+                if (x < W - 1 && label[p - W + 1] == c && label[p + 1] != c)     // with a right neighbour, ITS N is this NE
+                    uf_union(L, (int)p, (int)(p - W + 1));
             }
         }
     }
 }
-
 __global__ void ccl_compress_kernel(int* __restrict__ L, long npix)
 {
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
@@ -151,18 +174,24 @@ __global__ void seg_stats_kernel(const uint8_t* __restrict__ label, const float*
                 fx = (unsigned long long)(score[p] * 1099511627776.0f);  // 2^40 fixed point, exact for p < 1
             }
         }
-        // wave-level aggregation: a wave is 64 consecutive pixels and mostly sits in ONE component
-        const int root0 = __shfl(root, 0);
-        if (__all(root == root0)) {
-            if (root0 >= 0) {
-                unsigned long long sacc = fx;
-                for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off);
-                if ((threadIdx.x & 63) == 0) {
-                    atomicAdd(&sum[root0], sacc);
-                    atomicAdd(&cnt[root0], 64u);
-                }
+        // wave-level aggregation: a wave is 64 consecutive pixels and sits in ONE component, or in a handful at an object's edge:
+        // one atomic pair per distinct root (every lane of an object used to hit the same two addresses: ~15 000 serialised
+        // atomics per 126 x 126 object); u64 fixed-point sums, so the grouping does not change the result
+        unsigned long long todo = __ballot(root >= 0);
+        for (int rounds = 0; todo && rounds < 6; ++rounds) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int r0 = __shfl(root, leader);
+            const bool mine = root == r0;
+            const unsigned long long grp = __ballot(mine);
+            unsigned long long sacc = mine ? fx : 0ULL;
+            for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
+            if ((threadIdx.x & 63) == leader) {
+                atomicAdd(&sum[r0], sacc);
+                atomicAdd(&cnt[r0], (unsigned int)__popcll(grp));
             }
-        } else if (root >= 0) {
+            todo &= ~grp;
+        }
+        if (root >= 0 && ((todo >> (threadIdx.x & 63)) & 1ULL)) {      // speckle-heavy wave: the rest one by one
             atomicAdd(&sum[root], fx);
             atomicAdd(&cnt[root], 1u);
         }
@@ -533,7 +562,7 @@ extern "C" int ape_seg_components_scored(const uint8_t* label, const float* scor
     const int g = grid_for(npix);
     const int BC = B * C;
     hipLaunchKernelGGL(seg_small_init_kernel, dim3(ape::ceil_div(BC, kT)), dim3(kT), 0, st, hist, best_key, best_root, tight, BC);
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(kT), 0, st, label, L, npix);
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(kT), 0, st, label, L, W, npix);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(kT), 0, st, label, L, H, W, npix);
     hipLaunchKernelGGL(ccl_compress_kernel, dim3(g), dim3(kT), 0, st, L, npix);
     int gx = ape::ceil_div((long)H * W, kT);

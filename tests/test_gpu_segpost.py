@@ -59,6 +59,31 @@ def test_masks_and_bbox_bit_exact_from_injected_logits(seed):
         assert not np.isin(objmap[b], list(set(range(1, n_cls)) - got_classes)).any()
 
 
+@pytest.mark.parametrize("hw", [(61, 77), (64, 128), (37, 200)])
+def test_components_on_speckle_odd_sizes(hw):
+    """Run-based union-find on dense random labels (runs of every length, diagonal-only contacts, widths that are not a
+    multiple of the 64-pixel wave): same best component per class as the oracle's raster-order 8-connectivity labelling."""
+    from autoposeestimation_amd import engine as E
+    h, w = hw
+    n_cls = 5
+    rng = np.random.default_rng(h * 1000 + w)
+    lab = rng.integers(0, n_cls, size=(2, h, w))
+    lab[0, : h // 2] = np.where(rng.random((h // 2, w)) < 0.6, 0, lab[0, : h // 2])        # sparser half: small components
+    conf = rng.uniform(1.0, 5.0, size=(2, h, w)).astype(np.float32)
+    logits = rng.standard_normal((2, n_cls, h, w)).astype(np.float32) * 0.05
+    logits += np.eye(n_cls, dtype=np.float32)[lab].transpose(0, 3, 1, 2) * conf[:, None]
+    logits = torch.from_numpy(logits)
+    label, score = E.seg_argmax(logits.permute(0, 2, 3, 1).contiguous().cuda(), n_cls, double_softmax=True)
+    objmap, det = E.seg_components(label, score, n_cls, 100)
+    objmap, det = objmap.cpu().numpy(), det.cpu().numpy()
+    for b in range(2):
+        pred = F.softmax(F.softmax(logits[b], dim=0), dim=0)
+        want = O.seg_postprocess(pred)
+        assert {c for c in range(1, n_cls) if det[b, c, 0]} == set(want.keys())
+        for c, mask in want.items():
+            assert np.array_equal(np.where(objmap[b] == c, 255, 0).astype(np.uint8), mask), "class %d" % c
+
+
 def test_bbox_golden_rects():
     """get_bbox goldens from the reference (touching every border, exact multiples of 40) through the HIP bbox kernel."""
     from autoposeestimation_amd import engine as E
