@@ -58,22 +58,26 @@ class FramePipeline:
         choose[n,N] i64 cuda) in the order of `objects`."""
         n = len(objects)
         dev = rgb.device
-        pose_all = torch.zeros(n, 7, dtype=torch.float64, device=dev)
-        ncand_all = torch.zeros(n, dtype=torch.int32, device=dev)
-        choose_all = torch.zeros(n, self.num_points, dtype=torch.int64, device=dev)
-        buckets = {}
-        for i, o in enumerate(objects):
-            buckets.setdefault((o[3] - o[2], o[5] - o[4]), []).append(i)
-        for (hc, wc), ids in buckets.items():
-            objs = torch.tensor([objects[i] for i in ids], dtype=torch.int32).to(dev)
-            ids_t = torch.tensor(ids, dtype=torch.int64).to(dev)
+        obj_np = np.asarray(objects, dtype=np.int32).reshape(n, 6)
+        sizes = np.stack([obj_np[:, 3] - obj_np[:, 2], obj_np[:, 5] - obj_np[:, 4]], 1)
+        uniq, inv = np.unique(sizes, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        single = len(uniq) == 1                      # one crop shape (the common case): results are already in object order
+        if not single:
+            pose_all = torch.zeros(n, 7, dtype=torch.float64, device=dev)
+            ncand_all = torch.zeros(n, dtype=torch.int32, device=dev)
+            choose_all = torch.zeros(n, self.num_points, dtype=torch.int64, device=dev)
+        for k, (hc, wc) in enumerate(uniq.tolist()):
+            ids = np.nonzero(inv == k)[0]
+            sub = obj_np[ids]
+            both = torch.from_numpy(np.ascontiguousarray(np.concatenate([sub, sub[:, [0, 2, 4]]], 1))).to(dev)   # one small H2D
+            objs, rects = both[:, :6].contiguous(), both[:, 6:9].contiguous()
             choose, n_cand = E.choose_points(objmap, depth, objs, self.num_points, seed)
             if choose_override is not None:
-                for j, i in enumerate(ids):
+                for j, i in enumerate(ids.tolist()):
                     if choose_override.get(i) is not None:
                         choose[j] = torch.as_tensor(choose_override[i], dtype=torch.int64).to(dev)
             pts4 = E.backproject(depth, objs, choose, meta["intr"], meta["depth_scale"])
-            rects = objs[:, [0, 2, 4]].contiguous()
             img4 = E.preprocess_u8(rgb, rects, hc, wc, div255=False)
             obj_idx = (objs[:, 1].to(torch.int64) - 1).contiguous()         # class_names.index(cls) (pipeline/utils.py:561)
             heads, emb = self.estimator.forward_batch(img4, pts4, choose, obj_idx)
@@ -87,6 +91,9 @@ class FramePipeline:
                 for _ in range(self.iterations):
                     out = self.refiner.forward_batch(E.pose_recentre(pts4, pose), emb, obj_idx)
                     E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+            if single:
+                return pose, n_cand, choose
+            ids_t = torch.from_numpy(ids.astype(np.int64)).to(dev)
             pose_all.index_copy_(0, ids_t, pose)
             ncand_all.index_copy_(0, ids_t, n_cand)
             choose_all.index_copy_(0, ids_t, choose)
@@ -96,8 +103,8 @@ class FramePipeline:
         """Whole batch.  Returns dict(objects=[(frame,cls,rmin,rmax,cmin,cmax)], pose, n_cand, choose, objmap)."""
         objmap, det = self.segment(rgb, inject_logits)
         det_h = det.cpu().numpy()                       # the one host sync of the batch
-        objects = [(int(b), int(c), int(d[1]), int(d[2]), int(d[3]), int(d[4]))
-                   for b in range(det_h.shape[0]) for c, d in enumerate(det_h[b]) if c > 0 and d[0]]
+        fb, fc = np.nonzero(det_h[:, 1:, 0])            # (frame, class - 1) of every detection, frame-major like the reference loop
+        objects = [(int(b), int(c) + 1, *map(int, det_h[b, c + 1, 1:5])) for b, c in zip(fb, fc)]
         if objects:
             if choose_override is not None:             # keyed by (frame, cls) -> keyed by object position
                 choose_override = {i: choose_override.get((o[0], o[1])) for i, o in enumerate(objects)}

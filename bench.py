@@ -156,17 +156,15 @@ def main():
     def step(i):
         out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
         # one result slot per frame: the largest detection (the painted object) wins the slot
-        objs = sorted(range(len(out["objects"])), key=lambda j: -(out["objects"][j][3] - out["objects"][j][2]) *
-                      (out["objects"][j][5] - out["objects"][j][4]))
         poses = torch.zeros(args.batch, 1, 8, dtype=torch.float32, device=device)
-        if objs:
-            keep = {}
-            for j in objs:
-                keep.setdefault(out["objects"][j][0], j)
-            sel = torch.tensor(list(keep.values()), device=device)
-            poses[torch.tensor(list(keep.keys()), device=device), 0, 0] = torch.tensor(
-                [float(out["objects"][j][1]) for j in keep.values()], device=device)
-            poses[torch.tensor(list(keep.keys()), device=device), 0, 1:] = out["pose"][sel].float()
+        if out["objects"]:
+            o = np.asarray(out["objects"], dtype=np.int64)
+            order = np.argsort(-(o[:, 3] - o[:, 2]) * (o[:, 5] - o[:, 4]), kind="stable")
+            frames_u, first = np.unique(o[order, 0], return_index=True)
+            pick = order[first]
+            t = torch.from_numpy(np.stack([frames_u, pick, o[pick, 1]])).to(device)      # one small H2D
+            poses[t[0], 0, 0] = t[2].float()
+            poses[t[0], 0, 1:] = out["pose"][t[1]].float()
         out["gathered"] = gather_results(poses, dist)   # the single RCCL collective of the path: (cls, q, t) per frame
         return out
 
