@@ -26,8 +26,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TS = 16;          // output tile is TS x TS pixels
 constexpr int CK = 32;          // channels per chunk
-constexpr int LDH = CK;         // bf16 per LDS row: 64 B, UNPADDED; the four 16-B chunks of a row are XOR-swizzled with (row>>2)&3
-                                // (a padded 80-B stride made every ds_write 2-way bank-conflicted: 38 % of the LDS cycles)
+constexpr int LDH = CK;         // bf16 per LDS row of a WEIGHT tile: 64 B, unpadded, 16-B chunks XOR-swizzled (swz below)
+// Halo image: ONE row per pixel holding the hi plane (64 B), the lo plane (64 B) and 32 B of padding: a 160-B pitch (96 B
+// = hi + padding for plain bf16).  With these pitches the 16 lanes of every ds_read_b128 lane group (rows r..r+3 / r+12..r+15
+// of one chunk, rows r+4..r+11 of the next) fall on 16 distinct 16-B bank slots (10 r + k, resp. 6 r + k, mod 16), exactly
+// like the XOR swizzle used before, but the address is LINEAR in the pixel: a tap shift is a compile-time byte offset folded
+// into the ds_read immediate instead of ~7 VALU operations per fragment read (the kernel spent 2 VALU instructions per MFMA).
+constexpr int halo_lda(int npl) { return npl == 2 ? 2 * CK + 16 : CK + 16; }     // bf16 elements per halo pixel
 // 16x16x32 fragments: lane l reads chunk l>>4 of row l&15; the ds_read_b128 lane groups then mix two chunks, and the chunk
 // permutation that keeps all 16 lanes on distinct bank slots is chunk ^ ((-(row>>2)) & 3)
 __device__ __forceinline__ int swz(int row, int chunk16) { return row * LDH + ((chunk16 ^ ((0 - (row >> 2)) & 3)) << 3); }
@@ -36,7 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // BN = 64:  4 waves along the pixel axis, each 64 px x 64 cout, halo single-buffered so that TWO workgroups share a CU
 //           (57 KB LDS each): one's prologue / chunk refill / epilogue is covered by the other's MFMAs.
 constexpr int halo_threads(int bnh) { return bnh == 64 ? 256 : 512; }
-constexpr bool halo_a_double(int npl, int hp, int bnh) { return bnh != 64 && (2 * npl * hp * LDH * 2 + 2 * npl * bnh * LDH * 2) <= 160 * 1024; }
+constexpr bool halo_a_double(int npl, int hp, int bnh) { return bnh != 64 && (2 * hp * halo_lda(npl) * 2 + 2 * npl * bnh * LDH * 2) <= 160 * 1024; }
 
 struct HaloArgs {
     const float* x;
@@ -82,8 +87,9 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     constexpr int NA = A_DOUBLE ? 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
-    __bf16* As = smem;                                         // [NA][NPL][HP*LDH]
-    __bf16* Bs = smem + (size_t)NA * NPL * HP * LDH;           // [2][NPL][BNH*LDH]
+    constexpr int LDA = halo_lda(NPL);
+    __bf16* As = smem;                                         // [NA][HP][LDA]: hi at +0, lo at +CK of every pixel row
+    __bf16* Bs = smem + (size_t)NA * HP * LDA;                 // [2][NPL][BNH*LDH]
 
     const ape_conv_params& p = a.p;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -183,12 +189,12 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             const float4 v = (a_okmask >> j) & 1u ? areg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
             bf16x4 hi, lo;
             hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-            __bf16* dst = As + ((size_t)buf * NPL) * HP * LDH + swz(px, c4 >> 1) + (c4 & 1) * 4;
+            __bf16* dst = As + (size_t)buf * HP * LDA + px * LDA + c4 * 4;
             *reinterpret_cast<bf16x4*>(dst) = hi;
             if (NPL == 2) {
                 lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
                 lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-                *reinterpret_cast<bf16x4*>(dst + HP * LDH) = lo;
+                *reinterpret_cast<bf16x4*>(dst + CK) = lo;
             }
         }
     };
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int pidx = wm * (32 * TMW) + i * 16 + r16;
-        a_pix16[i] = (pidx >> 4) * HW_ + (pidx & 15);
+        a_pix16[i] = ((pidx >> 4) * HW_ + (pidx & 15)) * LDA + kq * 8;     // element offset of this lane's fragment chunk at tap (0, 0)
     }
 
     const int nchunks = p.Cin / CK;
@@ -250,12 +256,9 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     auto read_a = [&](const __bf16* Ah, int shift, bf16x8 (&h)[TI], bf16x8 (&l)[TI]) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            int px = a_pix16[i];
-            if (BNH == 128) asm volatile("" : "+v"(px));   // opaque: with the taps unrolled hipcc hoists all 9 x TI swizzled addresses
-                                                           // (8-wave kernels only: the 4-wave ones have the registers and lose 7 %)
-            const int ao = swz(px + shift, kq);
+            const int ao = a_pix16[i] + shift * LDA;        // shift is a compile-time constant: folded into the ds_read offset
             h[i] = *reinterpret_cast<const bf16x8*>(Ah + ao);
-            if (NPL == 2) l[i] = *reinterpret_cast<const bf16x8*>(Ah + HP * LDH + ao);
+            if (NPL == 2) l[i] = *reinterpret_cast<const bf16x8*>(Ah + CK + ao);
         }
     };
     auto tap_body = [&](auto tapc, const int c, const __bf16* Ah) {
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
 #pragma unroll 1
     for (int c = 0; c < nchunks; ++c) {
         const int abuf = A_DOUBLE ? (c & 1) : 0;
-        const __bf16* Ah = As + ((size_t)abuf * NPL) * HP * LDH;
+        const __bf16* Ah = As + (size_t)abuf * HP * LDA;
         if (APF) read_a(Ah, 0, afh[0], afl[0]);
         tap_body(std::integral_constant<int, 0>{}, c, Ah);
         tap_body(std::integral_constant<int, 1>{}, c, Ah);
@@ -459,7 +462,7 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
     constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
-    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * NPL * HP * LDH + 2 * NPL * BNH * LDH) * 2;
+    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2;
     constexpr size_t lds_stage = (size_t)128 * (BNH + 4) * 4;      // epilogue staging rows
     constexpr size_t lds = lds_ops > lds_stage ? lds_ops : lds_stage;
     static_assert(lds <= 160 * 1024, "LDS budget");
