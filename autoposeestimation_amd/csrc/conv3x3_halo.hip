@@ -410,8 +410,25 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     constexpr int RPP = 128;                              // pixels staged per pass
     float* stage = reinterpret_cast<float*>(smem);
     const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
+    constexpr int EIT = RPP * (BNH / 4) / NTH;          // float4 items per thread per pass (8)
+    static_assert(RPP * (BNH / 4) % NTH == 0, "epilogue items");
 #pragma unroll 1
     for (int pass = 0; pass < 256 / RPP; ++pass) {
+        // the residual float4s of this pass are requested up front and fly while the accumulators go through LDS (inside the store
+        // loop each load sat between the previous store and its own add)
+        float4 rres[EIT];
+        if (a.res && vec_ok) {
+#pragma unroll
+            for (int e = 0; e < EIT; ++e) {
+                const int it = tid + e * NTH;
+                const int row = it / (BNH / 4), c4 = it - row * (BNH / 4);
+                const int pidx = pass * RPP + row;
+                const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
+                const int n = n0 + c4 * 4;
+                if (gy < p.Ho && gx < p.Wo && n + 4 <= p.Cout)
+                    rres[e] = *reinterpret_cast<const float4*>(a.res + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.ldr + p.roff + n);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int p0 = wm * (32 * TMW) + i * 16;
@@ -423,7 +440,9 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
                     stage[(p0 - pass * RPP + kq * 4 + e) * ELD + wn * 64 + j * 16 + r16] = acc[i][j][e];
         }
         __syncthreads();
-        for (int it = tid; it < RPP * (BNH / 4); it += NTH) {
+#pragma unroll
+        for (int e8 = 0; e8 < EIT; ++e8) {
+            const int it = tid + e8 * NTH;
             const int row = it / (BNH / 4), c4 = it - row * (BNH / 4);
             const int pidx = pass * RPP + row;
             const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
@@ -436,10 +455,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             const float* bptr = a.bias ? a.bias + (p.bias_bstride ? (size_t)b * p.bias_bstride : 0) + n : nullptr;
             if (vec_ok && nvalid == 4) {
                 if (bptr) { vv[0] += bptr[0]; vv[1] += bptr[1]; vv[2] += bptr[2]; vv[3] += bptr[3]; }
-                if (a.res) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(a.res + m * p.ldr + p.roff + n);
-                    vv[0] += r4.x; vv[1] += r4.y; vv[2] += r4.z; vv[3] += r4.w;
-                }
+                if (a.res) { vv[0] += rres[e8].x; vv[1] += rres[e8].y; vv[2] += rres[e8].z; vv[3] += rres[e8].w; }
                 *reinterpret_cast<float4*>(a.y + m * p.ldy + p.yoff + n) =
                     make_float4(activate_h(vv[0], p.act, p.alpha), activate_h(vv[1], p.act, p.alpha),
                                 activate_h(vv[2], p.act, p.alpha), activate_h(vv[3], p.act, p.alpha));

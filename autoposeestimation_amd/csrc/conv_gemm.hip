@@ -71,7 +71,7 @@ __device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^
 // then all eight on the matrix pipes.  The LDS stage protocol is unchanged (tile t+1 is written >= 2 barriers after the last
 // read of tile t-1 and >= 2 barriers before the first read of tile t+1 by either group).
 template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP>
-__global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs a)
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a)
 {
     static_assert(!PP || WM == 2, "the ping-pong schedule pairs the two row halves of an 8-wave block");
     constexpr int NT = WM * WN * 64;
@@ -269,9 +269,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
     // with bias / residual / activation applied on float4s
     float* stage = reinterpret_cast<float*>(smem_raw);
     const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
+    constexpr int EIT = (64 * (BN / 4) + NT - 1) / NT;      // float4 items per thread per 64-row pass
 #pragma unroll 1
     for (int pass = 0; pass < BM / 64; ++pass) {
         if (pass) __syncthreads();
+        // residual float4s of this pass: all issued up front, so they fly while the accumulators go through LDS (fetched one by one
+        // inside the store loop, each load sat between the previous store and its own add: ~8 serialised HBM round trips per pass)
+        float4 rres[EIT];
+        if (a.res && vec_ok) {
+#pragma unroll
+            for (int e = 0; e < EIT; ++e) {
+                const int it = tid + e * NT;
+                const int row = it / (BN / 4), c4 = it - row * (BN / 4);
+                const int m = m0 + pass * 64 + row, n = n0 + c4 * 4;
+                if (it < 64 * (BN / 4) && m < a.M && n + 4 <= p.Cout)
+                    rres[e] = *reinterpret_cast<const float4*>(a.res + (size_t)m * p.ldr + p.roff + n);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int rbase = wm * WTM + i * 16;
@@ -283,7 +297,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
                     stage[(rbase - pass * 64 + fc * 4 + e) * ELD + wn * WTN + j * 16 + frow] = acc[i][j][e];
         }
         __syncthreads();
-        for (int it = tid; it < 64 * (BN / 4); it += NT) {
+#pragma unroll
+        for (int e = 0; e < EIT; ++e) {
+            const int it = tid + e * NT;
+            if (it >= 64 * (BN / 4)) continue;
             const int row = it / (BN / 4), c4 = it - row * (BN / 4);
             const int m = m0 + pass * 64 + row, n = n0 + c4 * 4;
             if (m >= a.M || n >= p.Cout) continue;
@@ -293,10 +310,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm_kernel(const GemmArgs 
             const float* bptr = a.bias ? a.bias + (p.bias_bstride ? (size_t)(m / HoWo) * p.bias_bstride : 0) + n : nullptr;
             if (vec_ok && nvalid == 4) {
                 if (bptr) { vv[0] += bptr[0]; vv[1] += bptr[1]; vv[2] += bptr[2]; vv[3] += bptr[3]; }
-                if (a.res) {
-                    const float4 rr = *reinterpret_cast<const float4*>(a.res + (size_t)m * p.ldr + p.roff + n);
-                    vv[0] += rr.x; vv[1] += rr.y; vv[2] += rr.z; vv[3] += rr.w;
-                }
+                if (a.res) { vv[0] += rres[e].x; vv[1] += rres[e].y; vv[2] += rres[e].z; vv[3] += rres[e].w; }
                 const float4 o = make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha),
                                              activate(vv[2], p.act, p.alpha), activate(vv[3], p.act, p.alpha));
                 *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o;
