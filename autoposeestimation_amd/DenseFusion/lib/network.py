@@ -143,7 +143,7 @@ class _PSPPlan:
 
     def features(self, x, taps=None, stop_before_up3=False):
         """x[B,H,W,4] (RGB + zero pad) -> up_3 activation [B,H,W,64]"""
-        y = E.maxpool3x3s2(self.stem(x))
+        y = E.stem_pool(self.stem, x)
         for c1, c2, down in self.blocks:
             res = y if down is None else down(y)
             y = c2(c1(y), residual=res)

@@ -362,7 +362,7 @@ extern "C" int ape_conv_gemm_supported(const ape_conv_params* params) { return p
 extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                                   const ape_conv_params* params, int nsplit, int variant, void* stream)
 {
-    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3) || variant < 0 || (variant & 15) > 5) return APE_EINVAL;
+    if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3) || variant < 0 || (variant & 15) > 6) return APE_EINVAL;
     const ape_conv_params& p = *params;
     if (!supported(p)) return APE_EINVAL;
     if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
@@ -396,8 +396,10 @@ extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const fl
         if (nsplit == 3) launch<3, 256, 64, 4, 1>(a, pure, st); else launch<1, 256, 64, 4, 1>(a, pure, st);
     } else if (variant == 4) {
         if (nsplit == 3) launch<3, 256, 192, 2, 4>(a, pure, st); else launch<1, 256, 192, 2, 4>(a, pure, st);
-    } else {
+    } else if (variant == 5) {
         if (nsplit == 3) launch<3, 256, 256, 2, 4, true>(a, pure, st); else launch<1, 256, 256, 2, 4, true>(a, pure, st);
+    } else {
+        if (nsplit == 3) launch<3, 128, 192, 2, 2>(a, pure, st); else launch<1, 128, 192, 2, 2>(a, pure, st);
     }
     return ape::check_launch("ape_conv_gemm_bf16");
 }

@@ -1,0 +1,188 @@
+// ResNet stem fused: Conv2d(3(4) -> 64, 7x7, stride 2, pad 3, no bias) + ReLU + MaxPool2d(3, 2, 1)   (extractors.py:82-85,
+// 111-117) in ONE kernel on the bf16 matrix cores (split-bf16 x3 or plain bf16 operands, fp32 accumulate).
+//
+// Why: as two launches the stem wrote its 64-channel half-resolution activation (1.26 GB for 64 frames) and the pool read it
+// back -- 0.8 + 0.34 ms for 0.12 TFLOP.  Here a workgroup owns a 4 x 8 tile of POOLED pixels: it stages the 23 x 40-pixel
+// input patch under the 9 x 17 conv outputs the tile needs (split to bf16 hi/lo once, 16 B per pixel), multiplies straight
+// out of the patch, pools in LDS and writes only the pooled tile (0.31 GB).
+//
+// GEMM view: M = 153 conv pixels (10 row blocks of 16), N = 64 (one 16-channel block per wave), K = 7 kernel rows x 8 kernel
+// columns (column 7 has zero weights) x 4 channels = 7 k-steps of 32.  A lane's 8 consecutive k of a k-step are two
+// ADJACENT input pixels of one patch row, i.e. 16 contiguous bytes of the patch: the A fragments are ds_read_b128s of the
+// patch itself (no im2col image), and lanes that share a pixel pair read the same address (broadcast, conflict-free).
+// The 7 x 2 weight fragments of a wave's 16 output channels stay in registers for the whole (persistent) kernel.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PTY = 4, PTX = 8;                 // pooled tile
+constexpr int CR = 2 * PTY + 1, CC = 2 * PTX + 1;   // conv outputs under it: 9 x 17
+constexpr int NCV = CR * CC;                    // 153
+constexpr int NRB = (NCV + 15) / 16;            // 10 row blocks
+constexpr int PR = 2 * CR + 5, PC = 2 * CC + 5 + 1; // input patch 23 x 40 (one extra column for the zero-weight kernel column 7)
+constexpr int NPATCH = PR * PC;                 // 920 pixels
+constexpr int ELD = 68;                         // floats per staged conv pixel (64 channels + pad)
+constexpr int PITEMS = (NPATCH + 255) / 256;    // patch pixels per thread (4)
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float4* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
+                                                           int Ho, int Wo, int Hp, int Wp, int tiles_y, int tiles_x)
+{
+    constexpr int NPL = NSPLIT == 3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char smem[NPL * NPATCH * 8 + NCV * ELD * 4];
+    __bf16* const patch = reinterpret_cast<__bf16*>(smem);                 // [NPL][NPATCH][4]
+    float* const stage = reinterpret_cast<float*>(smem + NPL * NPATCH * 8);   // [NCV][ELD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // ---- this wave's weights: 16 output channels x (7 kernel rows x [8 columns x 4 channels]) as MFMA B fragments -----------
+    bf16x8 bh[7], bl[7];
+    {
+        const int co = wave * 16 + r16;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kx = 2 * kq + (j >> 2), ch = j & 3;
+                const float v = kx < 7 ? w[((co * 7 + ky) * 7 + kx) * 4 + ch] : 0.f;
+                bh[ky][j] = (__bf16)v;
+                bl[ky][j] = (__bf16)(v - (float)bh[ky][j]);
+            }
+    }
+    // ---- this lane's A fragment origin per row block: element offset of patch pixel (2 cy, 2 cx + 2 kq) ----------------------
+    int abase[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        int m = rb * 16 + r16;
+        m = m < NCV ? m : NCV - 1;
+        const int cy = m / CC, cx = m - cy * CC;
+        abase[rb] = ((2 * cy) * PC + 2 * cx + 2 * kq) * 4;
+    }
+    const float cbias = bias ? bias[wave * 16 + r16] : 0.f;
+
+    const int ntiles = B * tiles_y * tiles_x;
+    float4 preg[PITEMS];
+    auto load_patch = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int iy0 = 4 * ty * PTY - 5, ix0 = 4 * tx * PTX - 5;
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i) {
+            const int e = tid + 256 * i;
+            const int pr = e / PC, pc = e - pr * PC;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = e < NPATCH && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int cyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cxc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            const float4 v = x[((long)b * H + cyc) * W + cxc];              // unconditional (clamped), zeroed below: conv zero padding
+            preg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < PITEMS; ++i) {
+            const int e = tid + 256 * i;
+            if (e >= NPATCH) continue;
+            const float4 v = preg[i];
+            bf16x4 hi, lo;
+            hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(patch + e * 4) = hi;
+            if (NPL == 2) {
+                lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+                lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+                *reinterpret_cast<bf16x4*>(patch + NPATCH * 4 + e * 4) = lo;
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_patch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        store_patch();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_patch(next);                 // flies under the MFMAs and the pooling of this tile
+
+        f32x4 acc[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[rb][e] = cbias;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const int o = abase[rb] + ky * PC * 4;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(patch + o);
+                if (NPL == 2) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(patch + NPATCH * 4 + o);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ky], acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ky], acc[rb], 0, 0, 0);
+                }
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ky], acc[rb], 0, 0, 0);
+            }
+        // ReLU'd conv outputs -> LDS [conv pixel][channel]   (C/D map: row = 4 kq + e is the pixel, column = r16 the channel)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = rb * 16 + kq * 4 + e;
+                if (m < NCV) stage[m * ELD + wave * 16 + r16] = fmaxf(acc[rb][e], 0.f);
+            }
+        __syncthreads();
+        // 3x3 / stride 2 / pad 1 max-pool over the staged conv tile; conv pixels outside the conv image do not take part
+        {
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+            const int py0 = ty * PTY, px0 = tx * PTX;
+            for (int it = tid; it < PTY * PTX * 16; it += 256) {
+                const int c4 = it & 15, pp = it >> 4;
+                const int ly = pp / PTX, lx = pp - ly * PTX;
+                const int py = py0 + ly, px = px0 + lx;
+                if (py >= Hp || px >= Wp) continue;
+                float4 m4 = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int oy = 2 * py - 1 + dy;
+                    if ((unsigned)oy >= (unsigned)Ho) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int ox = 2 * px - 1 + dx;
+                        if ((unsigned)ox >= (unsigned)Wo) continue;
+                        const float4 v = *reinterpret_cast<const float4*>(&stage[((2 * ly + dy) * CC + 2 * lx + dx) * ELD + c4 * 4]);
+                        m4.x = fmaxf(m4.x, v.x); m4.y = fmaxf(m4.y, v.y); m4.z = fmaxf(m4.z, v.z); m4.w = fmaxf(m4.w, v.w);
+                    }
+                }
+                *reinterpret_cast<float4*>(y + (((long)b * Hp + py) * Wp + px) * 64 + c4 * 4) = m4;
+            }
+        }
+        __syncthreads();      // the patch and the staging rows are free for the next tile
+    }
+}
+
+}  // namespace
+
+/* x[B][H][W][4] f32 (RGB + zero pad), w[64][7][7][4] f32, bias[64] or NULL -> y[B][Hp][Wp][64],
+ * Hp = ((H + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1 (the 7x7/s2/p3 conv followed by ReLU and the 3x3/s2/p1 max-pool) */
+extern "C" int ape_stem_conv_pool_bf16(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int nsplit,
+                                       void* stream)
+{
+    if (!x || !w || !y || B < 0 || H < 1 || W < 1 || (nsplit != 1 && nsplit != 3)) return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    const int Hp = (Ho + 2 - 3) / 2 + 1, Wp = (Wo + 2 - 3) / 2 + 1;
+    if (Ho < 1 || Wo < 1) return APE_EINVAL;
+    const int tiles_y = ape::ceil_div(Hp, PTY), tiles_x = ape::ceil_div(Wp, PTX);
+    const long ntiles = (long)B * tiles_y * tiles_x;
+    if (ntiles >= (1L << 31) || (long)B * H * W >= (1L << 31)) return APE_EINVAL;
+    const int grid = (int)(ntiles < 512 ? ntiles : 512);        // persistent: two workgroups per CU walk the tiles
+    if (nsplit == 3)
+        hipLaunchKernelGGL(stem_pool_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)x, w, bias, y, B, H, W, Ho,
+                           Wo, Hp, Wp, tiles_y, tiles_x);
+    else
+        hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)x, w, bias, y, B, H, W, Ho,
+                           Wo, Hp, Wp, tiles_y, tiles_x);
+    return ape::check_launch("ape_stem_conv_pool_bf16");
+}

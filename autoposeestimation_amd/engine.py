@@ -111,7 +111,7 @@ class Conv:
                 v = 4
             else:
                 v = 2
-        return "conv_gemm_kernel<%d,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4", 5: "256,256,2,4,pp"}[v], pure)
+        return "conv_gemm_kernel<%d,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4", 5: "256,256,2,4,pp", 6: "128,192,2,2"}[v], pure)
 
     def out_hw(self, h, w):
         ho = (h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1
@@ -213,6 +213,25 @@ def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False
         e1.record()
         prof.records.append((hlabel, 2.0 * b * h * w * conv.cout * 9 * conv.cin_real, e0, e1))
     return label, score
+
+
+USE_FUSED_STEM = os.environ.get("APE_USE_FUSED_STEM", "1") != "0"
+
+
+def stem_pool(conv, x):
+    """maxpool3x3s2(conv(x)) for the ResNet stem (7x7 / stride 2 / pad 3, 4 -> 64 channels, ReLU): one fused kernel on the bf16
+    paths (the half-resolution activation is never stored), the two calls otherwise."""
+    b, h, w, ldx = x.shape
+    fusable = (USE_FUSED_STEM and conv.nsplit and conv.cout == 64 and conv.cin == 4 and ldx == 4 and conv.kh == 7 and conv.kw == 7
+               and conv.stride == 2 and conv.pad == 3 and conv.dil == 1 and conv.act == ACT_RELU)
+    if not fusable:
+        return maxpool3x3s2(conv(x))
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty(b, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 64, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().ape_stem_conv_pool_bf16(_lib.dptr(x, torch.float32), _lib.dptr(conv.w, torch.float32), _lib.dptr(conv.bias),
+                                            _lib.dptr(y), b, h, w, conv.nsplit, _st())
+    _lib.check(rc, "ape_stem_conv_pool_bf16")
+    return y
 
 
 def maxpool3x3s2(x):

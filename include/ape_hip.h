@@ -88,6 +88,13 @@ int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const float* bias
 int ape_conv_gemm_supported(const ape_conv_params* params_host);
 int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                        const ape_conv_params* params_host, int nsplit, int variant, void* stream);
+/* The ResNet stem in one kernel: Conv2d(3 -> 64, 7x7, stride 2, pad 3) + ReLU + MaxPool2d(3, 2, 1)  (extractors.py:82-85, 111-117).
+ * x[B][H][W][4] f32 (RGB + a zero channel), w[64][7][7][4] f32 (the UNPACKED ape_conv2d_nhwc_f32 layout: the kernel splits its
+ * own weight fragments), bias[64] or NULL -> y[B][Hp][Wp][64] with Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1 (same for W).
+ * Operands as in ape_conv2d_nhwc_bf16 (nsplit 3 = split-bf16, 1 = plain bf16); the half-resolution 64-channel activation
+ * between the convolution and the pool is never written. */
+int ape_stem_conv_pool_bf16(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int nsplit,
+                            void* stream);
 /* 3x3 / stride 1 / pad == dilation in {1,2,4} / Cin % 32 == 0 specialisation of ape_conv2d_nhwc_bf16: the input halo of
  * a 16x16-pixel tile is staged once per 32-channel chunk in LDS and shared by the nine taps (3x less operand traffic).
  * Same arguments, packed weights, numerics and epilogue; ape_conv3x3_halo_supported(params) says whether it applies. */

@@ -59,3 +59,32 @@ def test_upconv_matches_torch_and_tile_form_equals_row_form(shape):
                                                   ctypes.c_float(0.25), _lib.stream_ptr())
     assert rc == 0
     assert torch.equal(rows, got)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 50, 70), (3, 160, 160), (1, 17, 9), (1, 480, 640)])
+def test_fused_stem_conv_pool(shape, precision):
+    """Conv2d(3->64, 7x7, s2, p3) + ReLU + MaxPool2d(3, 2, 1) in one kernel (extractors.py:82-85,111-117) against torch and
+    against the two-launch path it replaces."""
+    from autoposeestimation_amd import engine as E
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(b, 3, h, w, generator=g) * 2
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    want = F.max_pool2d(F.relu(F.conv2d(x, wt, None, 2, 3)), 3, 2, 1)
+    conv = E.Conv(wt, None, 2, 3, 1, E.ACT_RELU, device="cuda", precision=precision)
+    x4 = torch.zeros(b, h, w, 4, device="cuda")
+    x4[..., :3] = x.permute(0, 2, 3, 1).cuda()
+    old = E.USE_FUSED_STEM
+    try:
+        E.USE_FUSED_STEM = True
+        got = E.stem_pool(conv, x4)
+        E.USE_FUSED_STEM = False
+        two = E.stem_pool(conv, x4)
+    finally:
+        E.USE_FUSED_STEM = old
+    assert got.shape == two.shape == (b,) + tuple(want.shape[2:]) + (64,)
+    tol = {"bf16x3": 5e-5, "bf16": 2e-2}[precision]
+    scale = max(1.0, want.abs().max().item())
+    assert (got.cpu().permute(0, 3, 1, 2) - want).abs().max().item() / scale <= tol
+    assert (got - two).abs().max().item() / scale <= (2e-6 if precision == "bf16x3" else 2e-2)
