@@ -111,7 +111,10 @@ class Conv:
                 v = 4
             else:
                 v = 2
-        return "conv_gemm_kernel<%d,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4", 5: "256,256,2,4,pp", 6: "128,192,2,2"}[v], pure)
+        # the same spelling as rocprofv3's kernel name (template arguments NSPLIT, BM, BN, WM, WN, PURE, PP), so that bench.py finds
+        # this kernel's HBM traffic in profiles/*_pmc_traffic.json
+        return "conv_gemm_kernel<%d,%s,%s,%s>" % (self.nsplit, {1: "256,256,2,4", 2: "128,128,2,2", 3: "256,64,4,1", 4: "256,192,2,4",
+                                                               5: "256,256,2,4", 6: "128,192,2,2"}[v], pure, "true" if v == 5 else "false")
 
     def out_hw(self, h, w):
         ho = (h + 2 * self.pad - self.dil * (self.kh - 1) - 1) // self.stride + 1
