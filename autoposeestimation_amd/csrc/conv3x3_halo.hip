@@ -127,27 +127,47 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         gy = y0 - D + hy; gx = x0 - D + hx;
         return e < HP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     };
+    // UPS: the per-pixel part of the bilinear sample -- corner offset, +1 steps, blend weights, in-image bit -- is the same for the
+    // eight channel items of a halo pixel and for every chunk: it is computed ONCE per tile into a 16-B LDS table entry per halo
+    // pixel (the per-item form spent ~100 VALU operations per item, fetch and blend together, 2.2 k per wave and tile in a kernel
+    // that is VALU-issue-bound).  Same expressions, so the blend weights and the result are bit-identical.
+    uint4* const ups_tbl = reinterpret_cast<uint4*>(Bs + (size_t)2 * NPL * BNH * LDH);      // [HP] behind the weight tiles
+    if (UPS) {
+        for (int px = tid; px < HP; px += NTH) {
+            const int hy = px / HW_, hx = px - hy * HW_;
+            const int gy = y0 - D + hy, gx = x0 - D + hx;
+            const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+            const float fy = ups_sh * (float)cy, fx = ups_sw * (float)cx;
+            const int iy0 = (int)fy, ix0 = (int)fx;
+            const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0;
+            uint4 ent;
+            ent.x = (unsigned)(((b * hl + iy0) * wl + ix0) * p.ldx + p.xoff);
+            ent.y = (ix0 < wl - 1 ? 1u : 0u) | (iy0 < hl - 1 ? 2u : 0u) | (ok ? 4u : 0u);
+            ent.z = __float_as_uint(lx1);
+            ent.w = __float_as_uint(ly1);
+            ups_tbl[px] = ent;
+        }
+        __syncthreads();
+    }
     auto ups_fetch = [&](int j, int ci0, float4 (&r)[4]) {
-        int c4, gy, gx;
-        item_coords(j, c4, gy, gx);
-        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-        const float fy = ups_sh * (float)cy, fx = ups_sw * (float)cx;
-        const int iy0 = (int)fy, ix0 = (int)fx;
-        const int iy1 = iy0 + (iy0 < hl - 1 ? 1 : 0), ix1 = ix0 + (ix0 < wl - 1 ? 1 : 0);
-        const unsigned cofs = (unsigned)(p.xoff + ci0 + c4 * 4);
-        r[0] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix0) * p.ldx) + cofs);
-        r[1] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy0) * wl + ix1) * p.ldx) + cofs);
-        r[2] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix0) * p.ldx) + cofs);
-        r[3] = *reinterpret_cast<const float4*>(a.x + (unsigned)(((b * hl + iy1) * wl + ix1) * p.ldx) + cofs);
+        const int e = tid + NTH * j;
+        const int px = e < HP * 8 ? e >> 3 : HP - 1;
+        const uint4 ent = ups_tbl[px];
+        const unsigned base = ent.x + (unsigned)(ci0 + (e & 7) * 4);
+        const unsigned dxo = (ent.y & 1u) ? (unsigned)p.ldx : 0u, dyo = (ent.y & 2u) ? (unsigned)(wl * p.ldx) : 0u;
+        r[0] = *reinterpret_cast<const float4*>(a.x + base);
+        r[1] = *reinterpret_cast<const float4*>(a.x + base + dxo);
+        r[2] = *reinterpret_cast<const float4*>(a.x + base + dyo);
+        r[3] = *reinterpret_cast<const float4*>(a.x + base + dyo + dxo);
     };
     auto ups_lerp = [&](int j, const float4 (&r)[4]) {
-        int c4, gy, gx;
-        const bool ok = item_coords(j, c4, gy, gx);
+        const int e = tid + NTH * j;
+        const int px = e < HP * 8 ? e >> 3 : HP - 1;
+        const uint4 ent = ups_tbl[px];
+        const bool ok = e < HP * 8 && (ent.y & 4u);
         a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
-        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-        const float fy = ups_sh * (float)cy, fx = ups_sw * (float)cx;
-        const int iy0 = (int)fy, ix0 = (int)fx;
-        const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float lx1 = __uint_as_float(ent.z), ly1 = __uint_as_float(ent.w), ly0 = 1.f - ly1, lx0 = 1.f - lx1;
         float4 o;
         o.x = ly0 * (lx0 * r[0].x + lx1 * r[1].x) + ly1 * (lx0 * r[2].x + lx1 * r[3].x);
         o.y = ly0 * (lx0 * r[0].y + lx1 * r[1].y) + ly1 * (lx0 * r[2].y + lx1 * r[3].y);
@@ -478,7 +498,7 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
     constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
-    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2;
+    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2 + (UPS ? HP * 16 : 0);
     constexpr size_t lds_stage = (size_t)128 * (BNH + 4) * 4;      // epilogue staging rows
     constexpr size_t lds = lds_ops > lds_stage ? lds_ops : lds_stage;
     static_assert(lds <= 160 * 1024, "LDS budget");

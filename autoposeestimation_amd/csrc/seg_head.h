@@ -53,15 +53,19 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
         const int oa = __shfl_xor(am, off);
         if (om > m || (om == m && oa < am)) { m = om; am = oa; }  // first maximum overall (torch.argmax on the CPU)
     }
+    // v_exp_f32-based exponentials and ONE reciprocal per softmax (a few ulp from expf / a true division, far inside the 1e-5
+    // the score is compared at): the precise forms cost ~400 VALU instructions per 16-pixel group, 1.6 k per wave and tile of the
+    // fused up_3 kernel, which is VALU-issue-bound
     float e[4], s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? expf(acc[r] - m) : 0.f; s += e[r]; }
+    for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? __expf(acc[r] - m) : 0.f; s += e[r]; }
     s = quad_sum(s);
     float pm = 1.f / s;
     if (double_softmax) {
+        const float inv = pm;
         float s2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? expf(e[r] / s - pm) : 0.f;
+        for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? __expf(e[r] * inv - pm) : 0.f;
         pm = 1.f / quad_sum(s2);
     }
     am_out = am;
