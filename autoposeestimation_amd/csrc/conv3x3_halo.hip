@@ -131,7 +131,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     // eight channel items of a halo pixel and for every chunk: it is computed ONCE per tile into a 16-B LDS table entry per halo
     // pixel (the per-item form spent ~100 VALU operations per item, fetch and blend together, 2.2 k per wave and tile in a kernel
     // that is VALU-issue-bound).  Same expressions, so the blend weights and the result are bit-identical.
-    uint4* const ups_tbl = reinterpret_cast<uint4*>(Bs + (size_t)2 * NPL * BNH * LDH);      // [HP] behind the weight tiles
+    __shared__ uint4 ups_tbl[UPS ? HP : 1];
     if (UPS) {
         for (int px = tid; px < HP; px += NTH) {
             const int hy = px / HW_, hx = px - hy * HW_;
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         }
         __syncthreads();
     }
-    auto ups_fetch = [&](int j, int ci0, float4 (&r)[4]) {
+    // (the blend weights and the in-image bit travel from ups_fetch to ups_lerp in registers: a second read of the table entry at
+    // the end of the tap returned wrong weights under load -- large grids only, never found why -- the first read does not)
+    auto ups_fetch = [&](int j, int ci0, float4 (&r)[4], float (&wgt)[3]) {
         const int e = tid + NTH * j;
         const int px = e < HP * 8 ? e >> 3 : HP - 1;
         const uint4 ent = ups_tbl[px];
@@ -160,14 +162,14 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         r[1] = *reinterpret_cast<const float4*>(a.x + base + dxo);
         r[2] = *reinterpret_cast<const float4*>(a.x + base + dyo);
         r[3] = *reinterpret_cast<const float4*>(a.x + base + dyo + dxo);
+        wgt[0] = __uint_as_float(ent.z);
+        wgt[1] = __uint_as_float(ent.w);
+        wgt[2] = (e < HP * 8 && (ent.y & 4u)) ? 1.f : 0.f;
     };
-    auto ups_lerp = [&](int j, const float4 (&r)[4]) {
-        const int e = tid + NTH * j;
-        const int px = e < HP * 8 ? e >> 3 : HP - 1;
-        const uint4 ent = ups_tbl[px];
-        const bool ok = e < HP * 8 && (ent.y & 4u);
+    auto ups_lerp = [&](int j, const float4 (&r)[4], const float (&wgt)[3]) {
+        const bool ok = wgt[2] != 0.f;
         a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
-        const float lx1 = __uint_as_float(ent.z), ly1 = __uint_as_float(ent.w), ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float lx1 = wgt[0], ly1 = wgt[1], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
         float4 o;
         o.x = ly0 * (lx0 * r[0].x + lx1 * r[1].x) + ly1 * (lx0 * r[2].x + lx1 * r[3].x);
         o.y = ly0 * (lx0 * r[0].y + lx1 * r[1].y) + ly1 * (lx0 * r[2].y + lx1 * r[3].y);
@@ -192,10 +194,11 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
 #pragma unroll
             for (int j0 = 0; j0 < A_ITEMS; j0 += 4) {
                 float4 r[4][4];
+                float wg[4][3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (j0 + q < A_ITEMS) ups_fetch(j0 + q, ci0, r[q]);
+                for (int q = 0; q < 4; ++q) if (j0 + q < A_ITEMS) ups_fetch(j0 + q, ci0, r[q], wg[q]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (j0 + q < A_ITEMS) ups_lerp(j0 + q, r[q]);
+                for (int q = 0; q < 4; ++q) if (j0 + q < A_ITEMS) ups_lerp(j0 + q, r[q], wg[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         if (more) load_b(last ? 0 : tap + 1, last ? (c + 1) * CK : c * CK);
         constexpr int IPT = (A_ITEMS + 8) / 9;          // UPS: halo items fetched per tap
         float4 raw[IPT][4];
+        float rwg[IPT][3];
         const bool nxt = c + 1 < nchunks;
         if (nxt) {   // single-buffered: the registers hold the next halo until the chunk ends
             if (!UPS) {
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
                 for (int q = 0; q < IPT; ++q)
 #pragma unroll
                     for (int j = q; j < A_ITEMS; j += IPT)
-                        if (tap == j / IPT) ups_fetch(j, (c + 1) * CK, raw[q]);
+                        if (tap == j / IPT) ups_fetch(j, (c + 1) * CK, raw[q], rwg[q]);
             }
         }
         // keep the global prefetches at the top of the tap: with the taps unrolled (no branch around them) hipcc sinks the loads
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             for (int q = 0; q < IPT; ++q)
 #pragma unroll
                 for (int j = q; j < A_ITEMS; j += IPT)
-                    if (tap == j / IPT) ups_lerp(j, raw[q]);
+                    if (tap == j / IPT) ups_lerp(j, raw[q], rwg[q]);
         }
         if (A_DOUBLE && last && nxt) store_a((c + 1) & 1);
         __syncthreads();
@@ -498,7 +502,7 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
     constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
-    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2 + (UPS ? HP * 16 : 0);
+    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2;
     constexpr size_t lds_stage = (size_t)128 * (BNH + 4) * 4;      // epilogue staging rows
     constexpr size_t lds = lds_ops > lds_stage ? lds_ops : lds_stage;
     static_assert(lds <= 160 * 1024, "LDS budget");
