@@ -329,8 +329,16 @@ class PoseNet(_HipModule):
             _need_cuda(t, name)
         b, hc, wc, _ = img4.shape
         n = points4.shape[1]
-        up3 = pl.cnn.features(img4, taps)
-        g = E.gather_rows(up3.view(b, hc * wc, 64), choose)                 # [B,N,64]
+        if taps is None and hc % 2 == 0 and wc % 2 == 0:
+            # only N of the crop's Hc*Wc embedding pixels are kept (network.py:100-102): up_3 is evaluated at those alone, as
+            # one contraction over the 3x3 patches of the (virtual) up-sampled up_2 output gathered at the chosen pixels
+            p2 = pl.cnn.features(img4, stop_before_up3=True)
+            if getattr(pl, "up3_matrix", None) is None:
+                pl.up3_matrix = E.conv3x3_as_matrix(pl.cnn.up3)
+            g = pl.up3_matrix(E.ups_patch_gather(p2, choose)).view(b, n, 64)
+        else:
+            up3 = pl.cnn.features(img4, taps)
+            g = E.gather_rows(up3.view(b, hc * wc, 64), choose)             # [B,N,64]
         emb = E.log_softmax_rows(pl.cnn.final(g.view(b, n, 1, 64)).view(b, n, 32))
         pf, ap = pl.feat(points4, emb)
         gb = pl.l1_global(ap.view(b, 1, 1, 1024)).view(b, 1920)            # W[:, 384:] . ap_x + b

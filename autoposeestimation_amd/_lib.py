@@ -34,6 +34,7 @@ SIGNATURES = {
     "ape_upconv3x3_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ape_upconv3x3_gather_rows_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ape_gather_rows_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ape_ups_patch_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ape_log_softmax_rows_f32": [_P, _P, _c.c_long, _I, _P],
     "ape_mean_rows_f32": [_P, _P, _I, _I, _I, _P],
     "ape_pad3to4_f32": [_P, _P, _c.c_long, _P],

@@ -128,6 +128,42 @@ __global__ void gather_rows_kernel(const float4* __restrict__ x, const int64_t* 
     }
 }
 
+// 3x3 patches of the bilinear x2 (align_corners=True) up-sampling of x[B][h][w][C], gathered ONLY at chosen pixels:
+// out[(b*n + i)][tap*C + c] = up(x)[b][y + ky - 1][x + kx - 1][c] (0 outside the 2h x 2w image, the conv's zero padding) for the
+// pixel index[b][i] = y * 2w + x of the up-sampled image.  PoseNet keeps 1000 of a crop's 25 600 embedding pixels
+// (network.py:100-102), so its last 3x3 conv (up_3, pspnet.py:30-33) only has to be evaluated there: this gather + one
+// [B*n, 9C] x [9C, Cout] GEMM replaces the full-resolution convolution.  Interpolation op order as bilinear_kernel.
+__global__ void ups_patch_gather_kernel(const float4* __restrict__ x, const int64_t* __restrict__ index, float4* __restrict__ out,
+                                        int B, int h, int w, int C4, int n, float sh, float sw)
+{
+    const int Ho = 2 * h, Wo = 2 * w;
+    const long total = (long)B * n * 9 * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        long t = i / C4;
+        const int tap = t % 9;
+        const long bn = t / 9;
+        const int b = bn / n;
+        long pix = index[bn];
+        pix = pix < 0 ? 0 : (pix >= (long)Ho * Wo ? (long)Ho * Wo - 1 : pix);      // never read out of bounds on a bad index
+        const int qy = (int)(pix / Wo) + tap / 3 - 1, qx = (int)(pix % Wo) + tap % 3 - 1;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)qy < (unsigned)Ho && (unsigned)qx < (unsigned)Wo) {
+            const float fy = sh * (float)qy, fx = sw * (float)qx;
+            const int iy0 = (int)fy, ix0 = (int)fx;
+            const int iy1 = iy0 + (iy0 < h - 1 ? 1 : 0), ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+            const float ly1 = fy - (float)iy0, lx1 = fx - (float)ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float4 v00 = x[((long)(b * h + iy0) * w + ix0) * C4 + c], v01 = x[((long)(b * h + iy0) * w + ix1) * C4 + c];
+            const float4 v10 = x[((long)(b * h + iy1) * w + ix0) * C4 + c], v11 = x[((long)(b * h + iy1) * w + ix1) * C4 + c];
+            o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+            o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+            o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+            o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        }
+        out[i] = o;
+    }
+}
+
 // log-softmax over C <= 64 channels of each row; one lane per row (rows are short: 32 channels on this path)
 __global__ void log_softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C)
 {
@@ -541,6 +577,18 @@ extern "C" int ape_gather_rows_f32(const float* x, const int64_t* index, float* 
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)x,
                        index, (float4*)y, B, rows_in, n, C / 4);
     return ape::check_launch("ape_gather_rows_f32");
+}
+
+extern "C" int ape_ups_patch_gather_f32(const float* x, const int64_t* index, float* out, int B, int h, int w, int C, int n, void* stream)
+{
+    if (!x || !index || !out || B < 0 || h < 1 || w < 1 || C < 4 || C % 4 || n < 0) return APE_EINVAL;
+    const long total = (long)B * n * 9 * (C / 4);
+    if (total == 0) return APE_OK;
+    const float sh = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    const float sw = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    hipLaunchKernelGGL(ups_patch_gather_kernel, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)x, index,
+                       (float4*)out, B, h, w, C / 4, n, sh, sw);
+    return ape::check_launch("ape_ups_patch_gather_f32");
 }
 
 extern "C" int ape_log_softmax_rows_f32(const float* x, float* y, long rows, int C, void* stream)

@@ -305,6 +305,29 @@ def gather_rows(x, index):
     return y
 
 
+def ups_patch_gather(x, index):
+    """x[B,h,w,C], index[B,n] i64 (pixel of the x2 up-sampled image) -> [B*n, 1, 1, 9*C] patches of the up-sampled image"""
+    b, h, w, c = x.shape
+    n = index.shape[1]
+    out = torch.empty(b * n, 1, 1, 9 * c, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().ape_ups_patch_gather_f32(_lib.dptr(x, torch.float32), _lib.dptr(index, torch.int64), _lib.dptr(out), b, h, w, c, n, _st())
+    _lib.check(rc, "ape_ups_patch_gather_f32")
+    return out
+
+
+def conv3x3_as_matrix(conv):
+    """A 3x3 Conv viewed as the 1x1 contraction over its 9*Cin patch columns: shares the (already [Cout][KH][KW][Cin]) weights."""
+    assert conv.kh == 3 and conv.kw == 3 and conv.cin == conv.cin_real
+    m = object.__new__(Conv)
+    m.__dict__.update(conv.__dict__)
+    m.kh = m.kw = 1
+    m.cin = m.cin_real = 9 * conv.cin
+    m.stride, m.pad, m.dil = 1, 0, 1
+    if conv.nsplit == 0:
+        m.w = conv.w.view(conv.cout, 1, 1, 9 * conv.cin)
+    return m
+
+
 def log_softmax_rows(x):
     c = x.shape[-1]
     rows = x.numel() // c

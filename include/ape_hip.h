@@ -128,6 +128,11 @@ int ape_upconv3x3_gather_rows_f32(const float* z, const float* bias, float* out,
                                   void* stream);
 /* torch.gather(emb, 2, choose)               DenseFusion/lib/network.py:100-102.     y[b][i][:] = x[b][index[b][i]][:] */
 int ape_gather_rows_f32(const float* x, const int64_t* index, float* y, int B, int rows_in, int n, int C, void* stream);
+/* 3x3 patches of nn.Upsample(x2, align_corners=True)(x) at chosen pixels only: x[B][h][w][C] (C % 4 == 0), index[B][n] i64 = pixel
+ * y * 2w + x of the up-sampled image -> out[B*n][9*C], column = (ky*3+kx)*C + c, zero where the tap falls outside the 2h x 2w
+ * image.  With the up_3 weights read as a [Cout][9*C] matrix (their packed layout already is one) a single 1x1 contraction
+ * then evaluates pspnet.py:30-33 at the N points network.py:100-102 keeps, instead of at all Hc*Wc pixels of the crop. */
+int ape_ups_patch_gather_f32(const float* x, const int64_t* index, float* out, int B, int h, int w, int C, int n, void* stream);
 /* nn.LogSoftmax() over the channel run       DenseFusion/lib/pspnet.py:55.           rows x C, C contiguous */
 int ape_log_softmax_rows_f32(const float* x, float* y, long rows, int C, void* stream);
 /* nn.AvgPool1d(num_points)                   DenseFusion/lib/network.py:51,65,149,166.  x[B][n][C] -> y[B][C] */

@@ -88,3 +88,29 @@ def test_fused_stem_conv_pool(shape, precision):
     scale = max(1.0, want.abs().max().item())
     assert (got.cpu().permute(0, 3, 1, 2) - want).abs().max().item() / scale <= tol
     assert (got - two).abs().max().item() / scale <= (2e-6 if precision == "bf16x3" else 2e-2)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_up3_at_chosen_pixels_equals_full_conv_gather(precision):
+    """Upsample(x2, align_corners=True) + Conv2d 3x3 + PReLU evaluated only at chosen pixels (patch gather + one contraction)
+    == the full-resolution convolution gathered at those pixels (pspnet.py:30-33 + network.py:100-102)."""
+    from autoposeestimation_amd import engine as E
+    b, h, w, c, n = 3, 20, 24, 64, 333
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(64, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    bias = torch.randn(64, generator=g)
+    choose = torch.stack([torch.randperm(4 * h * w, generator=g)[:n] for _ in range(b)])
+    choose[0, :4] = torch.tensor([0, 2 * w - 1, (2 * h - 1) * 2 * w, 4 * h * w - 1])          # the four image corners
+    full = F.prelu(F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), wt, bias, padding=1), torch.tensor([0.25]))
+    want = torch.gather(full.reshape(b, 64, -1), 2, choose[:, None, :].expand(b, 64, n)).permute(0, 2, 1)
+    conv = E.Conv(wt, bias, 1, 1, 1, E.ACT_PRELU, alpha=0.25, device="cuda", precision=precision)
+    patches = E.ups_patch_gather(x.permute(0, 2, 3, 1).contiguous().cuda(), choose.cuda())
+    assert patches.shape == (b * n, 1, 1, 9 * c)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    cols = F.unfold(up, 3, padding=1).view(b, c, 9, -1)                    # [b, c, tap, pixel]
+    wantp = torch.gather(cols, 3, choose[:, None, None, :].expand(b, c, 9, n)).permute(0, 3, 2, 1).reshape(b * n, 9 * c)
+    assert (patches.view(b * n, -1).cpu() - wantp).abs().max().item() <= 2e-6 * wantp.abs().max().item()
+    got = E.conv3x3_as_matrix(conv)(patches).view(b, n, 64).cpu()
+    tol = {"f32": 2e-6, "bf16x3": 5e-5}[precision]
+    assert (got - want).abs().max().item() / want.abs().max().item() <= tol
