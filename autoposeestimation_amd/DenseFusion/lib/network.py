@@ -125,8 +125,13 @@ class _PSPPlan:
                 self.blocks.append((c1, c2, down))
             inplanes = planes
         wb = g("psp.bottleneck.weight")           # [1024, 2560, 1, 1] = [prior_1 | prior_2 | prior_3 | prior_6 | feats]
-        self.stage = [_Conv(g(f"psp.stages.{i}.1.weight"), None, device=dev) for i in range(4)]
-        self.bott_prior = [_Conv(wb[:, i * 512:(i + 1) * 512], None, device=dev) for i in range(4)]
+        # prior branch i: bottleneck columns i applied to stage conv i applied to the pooled map -- two 1x1 convs with nothing
+        # between them (pspnet.py:15-16,22-24), i.e. ONE 512 -> 1024 map whose matrix is their product (formed once, in fp64)
+        self.prior = []
+        for i in range(4):
+            ws = g(f"psp.stages.{i}.1.weight").detach().double().reshape(512, 512)
+            wbi = wb[:, i * 512:(i + 1) * 512].detach().double().reshape(-1, 512)
+            self.prior.append(_Conv((wbi @ ws).float(), None, device=dev))
         self.bott_feats = _Conv(wb[:, 2048:2560], g("psp.bottleneck.bias"), act=E.ACT_RELU, device=dev)
         # up_1 / up_2: channel mixing at low resolution + tap gather (4x fewer flops, no upsampled tensor); up_3 (64 -> 64 at
         # full resolution) would write a 9 x 64-channel half-resolution tensor larger than what it saves, so it stays direct
@@ -152,7 +157,7 @@ class _PSPPlan:
         pools = {s: E.adaptive_avgpool(f, s) for s in (2, 3, 6)}
         # the 1x1 pool is the mean of the four 2x2 bins when they tile the map evenly (one workgroup per frame otherwise)
         pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f, 1)
-        zs = [self.bott_prior[i](self.stage[i](pools[s])) for i, s in enumerate((1, 2, 3, 6))]
+        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]
         p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w))
         if taps is not None:
             taps["feats"], taps["psp"] = f, p
