@@ -154,7 +154,7 @@ class _PSPPlan:
             y = c2(c1(y), residual=res)
         f = y
         b, h, w, _ = f.shape
-        pools = {s: E.adaptive_avgpool(f, s) for s in (2, 3, 6)}
+        pools = E.adaptive_avgpool_multi(f, (2, 3, 6))
         # the 1x1 pool is the mean of the four 2x2 bins when they tile the map evenly (one workgroup per frame otherwise)
         pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f, 1)
         zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]

@@ -29,6 +29,8 @@ SIGNATURES = {
     "ape_conv3x3_halo_bf16": [_P, _P, _P, _P, _P, _P, _I, _P],
     "ape_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
     "ape_adaptive_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ape_adaptive_avgpool_multi_workspace_bytes": [_I, _I],
+    "ape_adaptive_avgpool_multi_nhwc_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_bilinear_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ape_psp_prior_sum_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ape_upconv3x3_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
@@ -93,7 +95,7 @@ class ConvParams(_c.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
-_RESTYPES = {"ape_last_error": _c.c_char_p, "ape_seg_components_workspace_bytes": _c.c_size_t,
+_RESTYPES = {"ape_last_error": _c.c_char_p, "ape_adaptive_avgpool_multi_workspace_bytes": _c.c_size_t, "ape_seg_components_workspace_bytes": _c.c_size_t,
              "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t,
              "ape_conv2d_wgrad_workspace_bytes": _c.c_size_t}
 

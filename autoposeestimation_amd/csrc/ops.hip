@@ -72,6 +72,84 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float4* __r
     }
 }
 
+// Several AdaptiveAvgPool2d sizes of ONE map in one pass over it (the PSP module pools the same 512-channel map to 2x2, 3x3 and
+// 6x6, pspnet.py:15: three passes over 0.63 GB as separate launches).  The bin edges of all sizes cut each axis into "atoms"
+// (60 x 80 with sizes 2, 3, 6: rows 0|10|20|..|60, columns 0|13|14|26|27|40|53|54|66|67|80); pass 1 sums every atom once,
+// pass 2 adds up the atoms of each bin and divides by its area.
+constexpr int kPoolMaxAtoms = 12, kPoolMaxSizes = 4, kPoolMaxS = 8;
+struct PoolPlan {
+    int ny, nx;
+    int ye[kPoolMaxAtoms + 1], xe[kPoolMaxAtoms + 1];          // atom edges
+    int nsizes, S[kPoolMaxSizes];
+    int ya[kPoolMaxSizes][kPoolMaxS + 1], xa[kPoolMaxSizes][kPoolMaxS + 1];   // bin o of size i covers atoms [a[i][2o'] ..): see host
+    int yb[kPoolMaxSizes][kPoolMaxS], xb[kPoolMaxSizes][kPoolMaxS];           // first / one-past-last atom of bin o: ya = first, yb = end
+    float* out[kPoolMaxSizes];
+};
+
+// grid (B * ny, C4 / 64): one atom ROW per workgroup; the 4 waves split its pixel rows, a lane owns one float4 of channels and
+// keeps one accumulator per atom column
+__global__ __launch_bounds__(256) void avgpool_atoms_kernel(const float4* __restrict__ x, float4* __restrict__ atoms, const PoolPlan pl,
+                                                            int H, int W, int C4)
+{
+    __shared__ float4 part[3][kPoolMaxAtoms][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int ay = blockIdx.x % pl.ny, b = blockIdx.x / pl.ny;
+    const int c = blockIdx.y * 64 + lane;
+    float4 acc[kPoolMaxAtoms];
+#pragma unroll
+    for (int a = 0; a < kPoolMaxAtoms; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C4) {
+        for (int y = pl.ye[ay] + g; y < pl.ye[ay + 1]; y += 4) {
+            const float4* row = x + ((long)(b * H + y) * W) * C4 + c;
+#pragma unroll
+            for (int a = 0; a < kPoolMaxAtoms; ++a) {
+                if (a >= pl.nx) break;
+                for (int xx = pl.xe[a]; xx < pl.xe[a + 1]; ++xx) {
+                    const float4 v = row[(long)xx * C4];
+                    acc[a].x += v.x; acc[a].y += v.y; acc[a].z += v.z; acc[a].w += v.w;
+                }
+            }
+        }
+    }
+    if (g > 0) {
+#pragma unroll
+        for (int a = 0; a < kPoolMaxAtoms; ++a) part[g - 1][a][lane] = acc[a];
+    }
+    __syncthreads();
+    if (g == 0 && c < C4) {
+#pragma unroll
+        for (int a = 0; a < kPoolMaxAtoms; ++a) {
+            if (a >= pl.nx) break;
+            float4 t = acc[a];
+            for (int k = 0; k < 3; ++k) { t.x += part[k][a][lane].x; t.y += part[k][a][lane].y; t.z += part[k][a][lane].z; t.w += part[k][a][lane].w; }
+            atoms[(((long)b * pl.ny + ay) * pl.nx + a) * C4 + c] = t;
+        }
+    }
+}
+
+// one thread per (image, size, bin, float4 of channels)
+__global__ void avgpool_bins_kernel(const float4* __restrict__ atoms, const PoolPlan pl, int B, int H, int W, int C4, int bins_total)
+{
+    const long total = (long)B * bins_total * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % C4;
+        long t = i / C4;
+        int bin = t % bins_total;
+        const int b = t / bins_total;
+        int si = 0;
+        while (bin >= pl.S[si] * pl.S[si]) { bin -= pl.S[si] * pl.S[si]; ++si; }
+        const int S = pl.S[si], oy = bin / S, ox = bin - oy * S;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ay = pl.ya[si][oy]; ay < pl.yb[si][oy]; ++ay)
+            for (int ax = pl.xa[si][ox]; ax < pl.xb[si][ox]; ++ax) {
+                const float4 v = atoms[(((long)b * pl.ny + ay) * pl.nx + ax) * C4 + c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        const float inv = 1.f / (float)((pl.ye[pl.yb[si][oy]] - pl.ye[pl.ya[si][oy]]) * (pl.xe[pl.xb[si][ox]] - pl.xe[pl.xa[si][ox]]));
+        reinterpret_cast<float4*>(pl.out[si])[((long)(b * S + oy) * S + ox) * C4 + c] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
 __device__ __forceinline__ float src_index(int dst, float scale, bool align_corners)
 {
     if (align_corners) return scale * (float)dst;
@@ -546,6 +624,73 @@ extern "C" int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, in
     hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(B * S * S, ape::ceil_div(C / 4, 64)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, (float4*)y, H, W, C / 4, S);
     return ape::check_launch("ape_adaptive_avgpool_nhwc_f32");
+}
+
+// atom edges of one axis for the given pool sizes; returns the atom count or -1 when it exceeds kPoolMaxAtoms
+static int pool_axis_plan(int L, const int* sizes, int nsizes, int* edges, int (*first)[kPoolMaxS + 1], int (*end)[kPoolMaxS])
+{
+    int cuts[2 * kPoolMaxSizes * kPoolMaxS + 2], n = 0;
+    for (int i = 0; i < nsizes; ++i)
+        for (int o = 0; o < sizes[i]; ++o) {
+            cuts[n++] = (o * L) / sizes[i];
+            cuts[n++] = ((o + 1) * L + sizes[i] - 1) / sizes[i];
+        }
+    for (int i = 1; i < n; ++i)                         // insertion sort + unique
+        for (int j = i; j > 0 && cuts[j - 1] > cuts[j]; --j) { const int t = cuts[j]; cuts[j] = cuts[j - 1]; cuts[j - 1] = t; }
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (m == 0 || cuts[i] != edges[m - 1]) {
+            if (m > kPoolMaxAtoms) return -1;
+            edges[m++] = cuts[i];
+        }
+    const int atoms = m - 1;
+    if (atoms < 1 || atoms > kPoolMaxAtoms) return -1;
+    for (int i = 0; i < nsizes; ++i)
+        for (int o = 0; o < sizes[i]; ++o) {
+            const int lo = (o * L) / sizes[i], hi = ((o + 1) * L + sizes[i] - 1) / sizes[i];
+            int a0 = 0, a1 = 0;
+            while (edges[a0] != lo) ++a0;
+            while (edges[a1] != hi) ++a1;
+            first[i][o] = a0;
+            end[i][o] = a1;
+        }
+    return atoms;
+}
+
+extern "C" size_t ape_adaptive_avgpool_multi_workspace_bytes(int B, int C)
+{
+    return (size_t)(B < 0 ? 0 : B) * kPoolMaxAtoms * kPoolMaxAtoms * (size_t)(C < 0 ? 0 : C) * sizeof(float);
+}
+
+/* nn.AdaptiveAvgPool2d((S_i, S_i)) for nsizes <= 4 sizes S_i <= 8 of the same map in one pass: x[B][H][W][C] -> ys[i][B][S_i][S_i][C].
+ * Returns APE_EINVAL when the bin edges give more than 12 atoms per axis (call ape_adaptive_avgpool_nhwc_f32 per size then). */
+extern "C" int ape_adaptive_avgpool_multi_nhwc_f32(const float* x, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H,
+                                                   int W, int C, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!x || !ys_host || !sizes_host || !workspace || nsizes < 1 || nsizes > kPoolMaxSizes || B < 0 || H < 1 || W < 1 || C < 4 || C % 4)
+        return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    PoolPlan pl;
+    pl.nsizes = nsizes;
+    int bins_total = 0;
+    for (int i = 0; i < nsizes; ++i) {
+        if (sizes_host[i] < 1 || sizes_host[i] > kPoolMaxS || !ys_host[i]) return APE_EINVAL;
+        pl.S[i] = sizes_host[i];
+        pl.out[i] = ys_host[i];
+        bins_total += sizes_host[i] * sizes_host[i];
+    }
+    for (int i = nsizes; i < kPoolMaxSizes; ++i) { pl.S[i] = 1 << 20; pl.out[i] = nullptr; }
+    pl.ny = pool_axis_plan(H, sizes_host, nsizes, pl.ye, pl.ya, pl.yb);
+    pl.nx = pool_axis_plan(W, sizes_host, nsizes, pl.xe, pl.xa, pl.xb);
+    if (pl.ny < 0 || pl.nx < 0) return APE_EINVAL;
+    if (workspace_bytes < (size_t)B * pl.ny * pl.nx * C * sizeof(float)) return APE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(avgpool_atoms_kernel, dim3(B * pl.ny, ape::ceil_div(C / 4, 64)), dim3(256), 0, st, (const float4*)x,
+                       (float4*)workspace, pl, H, W, C / 4);
+    const long total = (long)B * bins_total * (C / 4);
+    hipLaunchKernelGGL(avgpool_bins_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, (const float4*)workspace, pl, B, H, W, C / 4,
+                       bins_total);
+    return ape::check_launch("ape_adaptive_avgpool_multi_nhwc_f32");
 }
 
 extern "C" int ape_bilinear_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,

@@ -253,6 +253,23 @@ def adaptive_avgpool(x, s):
     return y
 
 
+def adaptive_avgpool_multi(x, sizes):
+    """{s: AdaptiveAvgPool2d((s, s))(x)} for several sizes in one pass over x[B,H,W,C]; per-size launches when the bin edges of
+    the sizes cut an axis into more than 12 atoms."""
+    b, h, w, c = x.shape
+    sizes = list(sizes)
+    ys = [torch.empty(b, s, s, c, dtype=torch.float32, device=x.device) for s in sizes]
+    ws = _workspace(_lib.lib().ape_adaptive_avgpool_multi_workspace_bytes(b, c), x.device)
+    ptrs = (ctypes.c_void_p * len(sizes))(*[y.data_ptr() for y in ys])
+    szs = (ctypes.c_int * len(sizes))(*sizes)
+    rc = _lib.lib().ape_adaptive_avgpool_multi_nhwc_f32(_lib.dptr(x, torch.float32), ptrs, szs, len(sizes), b, h, w, c, _lib.dptr(ws),
+                                                        ws.numel() * ws.element_size(), _st())
+    if rc == -1:      # APE_EINVAL: too many atoms for this geometry
+        return {s: adaptive_avgpool(x, s) for s in sizes}
+    _lib.check(rc, "ape_adaptive_avgpool_multi_nhwc_f32")
+    return dict(zip(sizes, ys))
+
+
 def bilinear(x, ho, wo, align_corners, out=None, yoff=0, accumulate=False):
     b, h, w, c = x.shape
     if out is None:

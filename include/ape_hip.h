@@ -107,6 +107,13 @@ int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const float* bia
 int ape_maxpool3x3s2_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);
 /* nn.AdaptiveAvgPool2d((S,S))                DenseFusion/lib/pspnet.py:15.           y[B][S][S][C] */
 int ape_adaptive_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int S, void* stream);
+/* The PSP module's pools (pspnet.py:15: sizes 2, 3, 6 of one map) in ONE pass over the map: the bin edges of all sizes cut each axis
+ * into at most 12 "atoms" (APE_EINVAL otherwise: use the per-size entry point); every atom is summed once into `workspace`
+ * (ape_adaptive_avgpool_multi_workspace_bytes(B, C)), then each bin adds up its atoms.  ys_host / sizes_host: host arrays of nsizes
+ * <= 4 device output pointers y_i[B][S_i][S_i][C] and sizes S_i <= 8. */
+size_t ape_adaptive_avgpool_multi_workspace_bytes(int B, int C);
+int ape_adaptive_avgpool_multi_nhwc_f32(const float* x, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H, int W,
+                                        int C, void* workspace, size_t workspace_bytes, void* stream);
 /* F.upsample(size=(Ho,Wo), 'bilinear') / nn.Upsample(x2, align_corners=True)   pspnet.py:22,31.
  * Reads x[B][H][W][ldx] channels 0..C-1, writes y[B][Ho][Wo][ldy] channels yoff..yoff+C-1 (a slice of the PSP
  * concat buffer, pspnet.py:22-23); accumulate != 0 adds into y instead of overwriting. */

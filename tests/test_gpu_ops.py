@@ -114,3 +114,17 @@ def test_up3_at_chosen_pixels_equals_full_conv_gather(precision):
     got = E.conv3x3_as_matrix(conv)(patches).view(b, n, 64).cpu()
     tol = {"f32": 2e-6, "bf16x3": 5e-5}[precision]
     assert (got - want).abs().max().item() / want.abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("shape", [(2, 60, 80, 64), (3, 20, 20, 32), (1, 7, 13, 8), (2, 30, 40, 512), (1, 97, 131, 16)])
+def test_adaptive_avgpool_multi(shape):
+    """nn.AdaptiveAvgPool2d for the PSP sizes 2, 3, 6 (pspnet.py:15) in one pass (atom sums) against torch, including geometries
+    whose bin edges overlap and ones that fall back to the per-size kernel."""
+    from autoposeestimation_amd import engine as E
+    b, h, w, c = shape
+    x = torch.randn(b, c, h, w, generator=torch.Generator().manual_seed(h * w))
+    got = E.adaptive_avgpool_multi(x.permute(0, 2, 3, 1).contiguous().cuda(), (2, 3, 6))
+    for s in (2, 3, 6):
+        want = F.adaptive_avg_pool2d(x, s).permute(0, 2, 3, 1)
+        assert got[s].shape == want.shape
+        assert (got[s].cpu() - want).abs().max().item() <= 2e-6
