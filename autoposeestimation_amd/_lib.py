@@ -34,7 +34,6 @@ SIGNATURES = {
     "ape_bilinear_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ape_psp_prior_sum_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ape_upconv3x3_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
-    "ape_upconv3x3_gather_rows_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ape_gather_rows_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ape_ups_patch_gather_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ape_log_softmax_rows_f32": [_P, _P, _c.c_long, _I, _P],

@@ -393,24 +393,49 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
     int ix_hi = (int)(sw * (float)qx_hi);
     ix_hi = ix_hi + (ix_hi < w - 1 ? 1 : 0);
     const int ni = ix_hi - ix_lo + 1;                   // <= kUpCols (host checks)
-    for (int item = threadIdx.x; item < 3 * ni * C4; item += 256) {
-        const int c = item % C4;
-        const int ii = (item / C4) % ni;
-        const int kx = item / (C4 * ni);
-        const int ix = ix_lo + ii;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // two items per thread and round, all twelve loads issued before the first use (four per round was slower) (rows outside the image are clamped and
+    // carry zero weights): the kernel is latency x occupancy bound, not bandwidth bound
+    const int nitems = 3 * ni * C4;
+    constexpr int U = 2;
+    for (int item0 = threadIdx.x; item0 < nitems; item0 += 256 * U) {
+        float4 v0[U][3], v1[U][3];
+        int sidx[U];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            if (!yok[ky]) continue;
-            const int tc = (ky * 3 + kx) * C4 + c;
-            const float4 v0 = z[((long)(b * h + iy0[ky]) * w + ix) * (9 * C4) + tc];
-            const float4 v1 = z[((long)(b * h + iy1[ky]) * w + ix) * (9 * C4) + tc];
-            acc.x += ly0[ky] * v0.x + ly1[ky] * v1.x;
-            acc.y += ly0[ky] * v0.y + ly1[ky] * v1.y;
-            acc.z += ly0[ky] * v0.z + ly1[ky] * v1.z;
-            acc.w += ly0[ky] * v0.w + ly1[ky] * v1.w;
+        for (int u = 0; u < U; ++u) {
+            int item = item0 + 256 * u;
+            sidx[u] = -1;
+            if (item < nitems) {
+                const int c = item % C4;
+                const int ii = (item / C4) % ni;
+                const int kx = item / (C4 * ni);
+                sidx[u] = (kx * kUpCols + ii) * C4 + c;
+            } else {
+                item = item0;
+            }
+            const int c = item % C4;
+            const int ii = (item / C4) % ni;
+            const int kx = item / (C4 * ni);
+            const int ix = ix_lo + ii;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int tc = (ky * 3 + kx) * C4 + c;
+                v0[u][ky] = z[((long)(b * h + iy0[ky]) * w + ix) * (9 * C4) + tc];
+                v1[u][ky] = z[((long)(b * h + iy1[ky]) * w + ix) * (9 * C4) + tc];
+            }
         }
-        S[(kx * kUpCols + ii) * C4 + c] = acc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if (!yok[ky]) continue;
+                acc.x += ly0[ky] * v0[u][ky].x + ly1[ky] * v1[u][ky].x;
+                acc.y += ly0[ky] * v0[u][ky].y + ly1[ky] * v1[u][ky].y;
+                acc.z += ly0[ky] * v0[u][ky].z + ly1[ky] * v1[u][ky].z;
+                acc.w += ly0[ky] * v0[u][ky].w + ly1[ky] * v1[u][ky].w;
+            }
+            if (sidx[u] >= 0) S[sidx[u]] = acc;
+        }
     }
     __syncthreads();
     for (int item = threadIdx.x; item < 16 * C4; item += 256) {
@@ -438,108 +463,6 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
             acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
         }
         out[((long)(b * Ho + Y) * Wo + X) * C4 + c] = acc;
-    }
-}
-
-// Tile form of the same gather for C % 32 == 0: one workgroup = 8 output rows x 16 output columns x 32 channels.  In phase 1
-// a thread owns one (kx, low-resolution column, float4 of channels) and walks DOWN the <= 7 low-resolution rows under the tile
-// once per ky, keeping the previous row in registers: 21 loads feed the S values of all eight output rows (2.6 per value; the
-// row form above spends 6 per value and was bound by the L1/L2 request rate, ~37 TB/s of cache traffic on up_1).  Same
-// products, same summation order as the row form: bit-identical results.  34 KB of LDS: four workgroups per CU.
-constexpr int kUpTY = 8, kUpCH = 8, kUpZR = 7, kUpZC = 11;
-
-__global__ __launch_bounds__(256) void upconv_gather_tile_kernel(const float4* __restrict__ z, const float* __restrict__ bias,
-                                                                 float4* __restrict__ out, int B, int h, int w, int C4, float sh, float sw,
-                                                                 int act, float alpha)
-{
-    __shared__ float4 S[kUpTY * 3 * kUpZC * kUpCH];             // [row][kx][column][channel float4]
-    const int Ho = 2 * h, Wo = 2 * w;
-    const int xt_n = (Wo + 15) / 16, yt_n = (Ho + kUpTY - 1) / kUpTY, cc_n = C4 / kUpCH;
-    const int nwg = gridDim.x;
-    const int orig = blockIdx.x;
-    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
-    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-    const int cc = logical % cc_n; logical /= cc_n;
-    const int xt = logical % xt_n; logical /= xt_n;
-    const int yt = logical % yt_n;
-    const int b = logical / yt_n;
-    const int X0 = xt * 16, Y0 = yt * kUpTY, c0 = cc * kUpCH;
-    const int qy_lo = Y0 - 1 < 0 ? 0 : Y0 - 1, qy_hi = Y0 + kUpTY > Ho - 1 ? Ho - 1 : Y0 + kUpTY;
-    const int iy_lo = (int)(sh * (float)qy_lo);
-    int iy_hi = (int)(sh * (float)qy_hi);
-    iy_hi = iy_hi + (iy_hi < h - 1 ? 1 : 0);
-    const int nr = iy_hi - iy_lo + 1;                   // <= kUpZR: the scale is < 1/2 and the tile spans 10 rows
-    const int qx_lo = X0 - 1 < 0 ? 0 : X0 - 1, qx_hi = X0 + 16 > Wo - 1 ? Wo - 1 : X0 + 16;
-    const int ix_lo = (int)(sw * (float)qx_lo);
-    int ix_hi = (int)(sw * (float)qx_hi);
-    ix_hi = ix_hi + (ix_hi < w - 1 ? 1 : 0);
-    const int ni = ix_hi - ix_lo + 1;                   // <= kUpZC
-    // phase 1: S(row, kx, ix) = sum_ky lerp_y( z_{ky,kx}(., ix), Y + ky - 1 )   (all row coefficients are wave-uniform)
-    for (int item = threadIdx.x; item < 3 * ni * kUpCH; item += 256) {
-        const int c = item % kUpCH;
-        const int ii = (item / kUpCH) % ni;
-        const int kx = item / (kUpCH * ni);
-        float4 acc[kUpTY];
-#pragma unroll
-        for (int ry = 0; ry < kUpTY; ++ry) acc[ry] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4* zc = z + ((long)(b * h + iy_lo) * w + ix_lo + ii) * (9 * C4) + kx * C4 + c0 + c;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int rr = 0; rr < kUpZR; ++rr) {
-                if (rr >= nr) break;
-                const float4 cur = zc[(long)rr * w * (9 * C4) + ky * 3 * C4];
-#pragma unroll
-                for (int ry = 0; ry < kUpTY; ++ry) {
-                    const int qy = Y0 + ry + ky - 1;
-                    if (Y0 + ry >= Ho || (unsigned)qy >= (unsigned)Ho) continue;
-                    const float fy = sh * (float)qy;
-                    const int iy0 = (int)fy, iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
-                    if (iy1 - iy_lo != rr) continue;
-                    const float ly1 = fy - (float)iy0, ly0 = 1.f - ly1;
-                    const float4 v0 = iy0 == iy1 ? cur : prev;
-                    acc[ry].x += ly0 * v0.x + ly1 * cur.x;
-                    acc[ry].y += ly0 * v0.y + ly1 * cur.y;
-                    acc[ry].z += ly0 * v0.z + ly1 * cur.z;
-                    acc[ry].w += ly0 * v0.w + ly1 * cur.w;
-                }
-                prev = cur;
-            }
-        }
-#pragma unroll
-        for (int ry = 0; ry < kUpTY; ++ry) S[((ry * 3 + kx) * kUpZC + ii) * kUpCH + c] = acc[ry];
-    }
-    __syncthreads();
-    // phase 2: out(Y, X) = act( bias + sum_kx lerp_x( S(Y, kx, .), X + kx - 1 ) )
-    for (int item = threadIdx.x; item < kUpTY * 16 * kUpCH; item += 256) {
-        const int c = item % kUpCH;
-        const int X = X0 + (item / kUpCH) % 16;
-        const int ry = item / (kUpCH * 16);
-        const int Y = Y0 + ry;
-        if (X >= Wo || Y >= Ho) continue;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int qx = X + kx - 1;
-            if ((unsigned)qx >= (unsigned)Wo) continue;
-            const float fx = sw * (float)qx;
-            const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
-            const float lx1 = fx - (float)ix0, lx0 = 1.f - lx1;
-            const float4 s0 = S[((ry * 3 + kx) * kUpZC + ix0 - ix_lo) * kUpCH + c], s1 = S[((ry * 3 + kx) * kUpZC + ix1 - ix_lo) * kUpCH + c];
-            acc.x += lx0 * s0.x + lx1 * s1.x;
-            acc.y += lx0 * s0.y + lx1 * s1.y;
-            acc.z += lx0 * s0.z + lx1 * s1.z;
-            acc.w += lx0 * s0.w + lx1 * s1.w;
-        }
-        const int cg = c0 + c;
-        if (bias) { acc.x += bias[cg * 4]; acc.y += bias[cg * 4 + 1]; acc.z += bias[cg * 4 + 2]; acc.w += bias[cg * 4 + 3]; }
-        if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        else if (act == APE_ACT_PRELU) {
-            acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;
-            acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
-        }
-        out[((long)(b * Ho + Y) * Wo + X) * C4 + cg] = acc;
     }
 }
 
@@ -776,23 +699,14 @@ extern "C" int ape_head_select_f32(const float* h, int ldh, int off_r, int off_t
     return ape::check_launch("ape_head_select_f32");
 }
 
-static int upconv_gather_launch(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
-                                bool allow_tile, void* stream)
+extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
+                                        void* stream)
 {
     if (!z || !out || B < 0 || h < 1 || w < 1 || C < 4 || C % 4 || act < APE_ACT_NONE || act > APE_ACT_PRELU) return APE_EINVAL;
     const long total = (long)B * 4 * h * w * (C / 4);
     if (total == 0) return APE_OK;
     const float sh = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sw = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    // the tile form pays on wide layers (up_1, C = 256: -7 %); at C = 64 (up_2) the row form is 13 % faster
-    if (allow_tile && C >= 128 && C % (4 * kUpCH) == 0 && h >= 4 && w >= 8) {
-        const long gt = (long)B * ((2 * h + kUpTY - 1) / kUpTY) * ((2 * w + 15) / 16) * (C / 4 / kUpCH);
-        if (gt < (1L << 31)) {
-            hipLaunchKernelGGL(upconv_gather_tile_kernel, dim3((unsigned)gt), dim3(256), 0, (hipStream_t)stream, (const float4*)z, bias,
-                               (float4*)out, B, h, w, C / 4, sh, sw, act, alpha);
-            return ape::check_launch("ape_upconv3x3_gather_f32");
-        }
-    }
     const long g = (long)B * 2 * h * ((2 * w + 15) / 16);
     if (g >= (1L << 31)) return APE_EINVAL;
     const size_t lds = (size_t)3 * kUpCols * (C / 4) * sizeof(float4);
@@ -800,19 +714,6 @@ static int upconv_gather_launch(const float* z, const float* bias, float* out, i
     hipLaunchKernelGGL(upconv_gather_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
                        h, w, C / 4, sh, sw, act, alpha);
     return ape::check_launch("ape_upconv3x3_gather_f32");
-}
-
-extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
-                                        void* stream)
-{
-    return upconv_gather_launch(z, bias, out, B, h, w, C, act, alpha, true, stream);
-}
-
-/* the row form only (any C % 4 == 0): what ape_upconv3x3_gather_f32 falls back to; bit-identical to the tile form */
-extern "C" int ape_upconv3x3_gather_rows_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act,
-                                             float alpha, void* stream)
-{
-    return upconv_gather_launch(z, bias, out, B, h, w, C, act, alpha, false, stream);
 }
 
 extern "C" int ape_psp_prior_sum_f32(const float* z1, const float* z2, const float* z3, const float* z6, float* out, int B, int h,

@@ -129,10 +129,6 @@ int ape_psp_prior_sum_f32(const float* z1, const float* z2, const float* z3, con
  * applies the activation: out[B][2h][2w][C].  Exact up to fp32 rounding (conv and bilinear resize are both linear). */
 int ape_upconv3x3_gather_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
                              void* stream);
-/* the same operator restricted to its row-per-workgroup form (any C % 4 == 0), which ape_upconv3x3_gather_f32 uses when the
- * 8 x 16-pixel x 32-channel tile form does not apply; the two forms are bit-identical (tests/test_gpu_ops.py) */
-int ape_upconv3x3_gather_rows_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
-                                  void* stream);
 /* torch.gather(emb, 2, choose)               DenseFusion/lib/network.py:100-102.     y[b][i][:] = x[b][index[b][i]][:] */
 int ape_gather_rows_f32(const float* x, const int64_t* index, float* y, int B, int rows_in, int n, int C, void* stream);
 /* 3x3 patches of nn.Upsample(x2, align_corners=True)(x) at chosen pixels only: x[B][h][w][C] (C % 4 == 0), index[B][n] i64 = pixel

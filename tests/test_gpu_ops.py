@@ -36,11 +36,10 @@ def test_mean_rows(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 20, 64, 128), (1, 9, 13, 32, 160), (2, 6, 50, 32, 256), (1, 5, 9, 16, 8), (2, 20, 20, 64, 32)])
-def test_upconv_matches_torch_and_tile_form_equals_row_form(shape):
+def test_upconv_matches_torch(shape):
     """PSPUpsample (pspnet.py:27-37: Upsample x2 align_corners=True -> Conv2d 3x3 pad 1 -> PReLU) as low-resolution channel
-    mixing + tap gather: against torch, and the tile form of the gather against the row form bit for bit."""
-    import ctypes
-    from autoposeestimation_amd import _lib, engine as E
+    mixing + tap gather, against torch."""
+    from autoposeestimation_amd import engine as E
     b, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(h * 10 + w)
     x = torch.randn(b, cin, h, w, generator=g)
@@ -49,16 +48,9 @@ def test_upconv_matches_torch_and_tile_form_equals_row_form(shape):
     up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
     want = F.prelu(F.conv2d(up, wt, bias, padding=1), torch.tensor([0.25]))
     op = E.UpConv(wt, bias, 0.25, device="cuda", precision="f32")
-    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
-    got = op(xd)
+    got = op(x.permute(0, 2, 3, 1).contiguous().cuda())
     err = (got.cpu().permute(0, 3, 1, 2) - want).abs().max().item() / max(1.0, want.abs().max().item())
     assert err <= 5e-6, err
-    z = op.mix(xd)
-    rows = torch.empty_like(got)
-    rc = _lib.lib().ape_upconv3x3_gather_rows_f32(_lib.dptr(z), _lib.dptr(op.bias), _lib.dptr(rows), b, h, w, cout, E.ACT_PRELU,
-                                                  ctypes.c_float(0.25), _lib.stream_ptr())
-    assert rc == 0
-    assert torch.equal(rows, got)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
