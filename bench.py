@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="pose stage on the same stream as the segmentation (no cross-step overlap)")
     ap.add_argument("--seg-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--pose-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
@@ -150,22 +151,26 @@ def main():
     seg.set_precision(args.seg_precision)
     est.set_precision(args.pose_precision)
     ref.set_precision(args.pose_precision)
-    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat")
+    # pose_stream: the pose stage of step i runs on a second HIP stream beside the segmentation of step i+1 (the timed region
+    # ends with torch.cuda.synchronize(), which waits for both streams; every step still does all of its work)
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=not args.no_overlap)
     from autoposeestimation_amd.sharding import gather_results
 
     def step(i):
         out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
         # one result slot per frame: the largest detection (the painted object) wins the slot
-        poses = torch.zeros(args.batch, 1, 8, dtype=torch.float32, device=device)
-        if out["objects"]:
-            o = np.asarray(out["objects"], dtype=np.int64)
-            order = np.argsort(-(o[:, 3] - o[:, 2]) * (o[:, 5] - o[:, 4]), kind="stable")
-            frames_u, first = np.unique(o[order, 0], return_index=True)
-            pick = order[first]
-            t = torch.from_numpy(np.stack([frames_u, pick, o[pick, 1]])).to(device)      # one small H2D
-            poses[t[0], 0, 0] = t[2].float()
-            poses[t[0], 0, 1:] = out["pose"][t[1]].float()
-        out["gathered"] = gather_results(poses, dist)   # the single RCCL collective of the path: (cls, q, t) per frame
+        with torch.cuda.stream(out.get("stream") or torch.cuda.current_stream()):     # the pose results live on the pose stream
+            poses = torch.zeros(args.batch, 1, 8, dtype=torch.float32, device=device)
+            if out["objects"]:
+                o = np.asarray(out["objects"], dtype=np.int64)
+                order = np.argsort(-(o[:, 3] - o[:, 2]) * (o[:, 5] - o[:, 4]), kind="stable")
+                frames_u, first = np.unique(o[order, 0], return_index=True)
+                pick = order[first]
+                # one small H2D from pinned memory, non-blocking: a pageable copy would park the host behind the whole pose stage
+                t = torch.from_numpy(np.stack([frames_u, pick, o[pick, 1]])).pin_memory().to(device, non_blocking=True)
+                poses[t[0], 0, 0] = t[2].float()
+                poses[t[0], 0, 1:] = out["pose"][t[1]].float()
+            out["gathered"] = gather_results(poses, dist)   # the single RCCL collective of the path: (cls, q, t) per frame
         return out
 
     def fence():

@@ -129,5 +129,12 @@ def test_pipeline_is_bitwise_deterministic():
     assert a["objects"] == b["objects"] and len(a["objects"]) >= 6
     assert torch.equal(a["objmap"], b["objmap"]) and torch.equal(a["choose"], b["choose"]) and torch.equal(a["pose"], b["pose"])
     assert torch.isfinite(a["pose"]).all()
+    # pose stage on a second stream (bench.py's cross-step overlap): same results, consumer waits for the returned stream
+    side = FramePipeline(seg, est, ref, CLASSES, pose_stream=True)
+    for _ in range(2):
+        c = side.run(rgb, depth, S.REALSENSE_META, seed=11)
+    c["stream"].synchronize()
+    assert c["objects"] == a["objects"] and torch.equal(c["objmap"], a["objmap"])
+    assert torch.equal(c["choose"], a["choose"]) and torch.equal(c["pose"], a["pose"])
     q = a["pose"][:, :4]
     assert torch.allclose(q.norm(dim=1), torch.ones(len(q), dtype=torch.float64, device=q.device), atol=1e-9) and (q[:, 0] >= 0).all()
