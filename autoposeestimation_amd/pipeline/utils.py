@@ -104,17 +104,28 @@ class FramePipeline:
             choose_all.index_copy_(0, ids_t, choose)
         return pose_all, ncand_all, choose_all
 
-    def run(self, rgb, depth, meta, inject_logits=None, choose_override=None, seed=0):
-        """Whole batch.  Returns dict(objects=[(frame,cls,rmin,rmax,cmin,cmax)], pose, n_cand, choose, objmap)."""
+    def begin(self, rgb, inject_logits=None):
+        """Enqueue the segmentation stage of a batch and the (pinned, non-blocking) copy of its detections; returns a handle for
+        finish().  Nothing here waits for the GPU, so the next batch can be begun before this one is finished."""
         objmap, det = self.segment(rgb, inject_logits)
-        det_h = det.cpu().numpy()                       # the one host sync of the batch
+        det_h = torch.empty(det.shape, dtype=det.dtype, pin_memory=True)
+        det_h.copy_(det, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {"objmap": objmap, "det": det, "det_h": det_h, "event": ev}
+
+    def finish(self, handle, rgb, depth, meta, choose_override=None, seed=0):
+        """Wait for the batch's detections (the one host sync of the batch -- an event, not the stream, so segmentation work
+        queued behind it keeps running), then enqueue its pose stage (on the pose stream when the pipeline has one)."""
+        handle["event"].synchronize()
+        objmap, det_h = handle["objmap"], handle["det_h"].numpy()
         fb, fc = np.nonzero(det_h[:, 1:, 0])            # (frame, class - 1) of every detection, frame-major like the reference loop
         objects = [(int(b), int(c) + 1, *map(int, det_h[b, c + 1, 1:5])) for b, c in zip(fb, fc)]
         if objects:
             if choose_override is not None:             # keyed by (frame, cls) -> keyed by object position
                 choose_override = {i: choose_override.get((o[0], o[1])) for i, o in enumerate(objects)}
             if self.side is not None:
-                self.side.wait_stream(torch.cuda.current_stream())
+                self.side.wait_event(handle["event"])
                 objmap.record_stream(self.side)         # allocated on the caller's stream, read by the pose stage on the side stream
                 with torch.cuda.stream(self.side):
                     pose, n_cand, choose = self.poses(rgb, depth, objmap, objects, meta, choose_override, seed)
@@ -125,6 +136,10 @@ class FramePipeline:
             n_cand = torch.zeros(0, dtype=torch.int32, device=rgb.device)
             choose = torch.zeros(0, self.num_points, dtype=torch.int64, device=rgb.device)
         return {"objects": objects, "pose": pose, "n_cand": n_cand, "choose": choose, "objmap": objmap}
+
+    def run(self, rgb, depth, meta, inject_logits=None, choose_override=None, seed=0):
+        """Whole batch.  Returns dict(objects=[(frame,cls,rmin,rmax,cmin,cmax)], pose, n_cand, choose, objmap)."""
+        return self.finish(self.begin(rgb, inject_logits), rgb, depth, meta, choose_override, seed)
 
 
 def _as_u8_frame(image):
