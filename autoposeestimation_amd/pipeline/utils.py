@@ -104,10 +104,12 @@ class FramePipeline:
             choose_all.index_copy_(0, ids_t, choose)
         return pose_all, ncand_all, choose_all
 
-    def begin(self, rgb, inject_logits=None):
+    def begin(self, rgb, inject_logits=None, asynchronous=True):
         """Enqueue the segmentation stage of a batch and the (pinned, non-blocking) copy of its detections; returns a handle for
         finish().  Nothing here waits for the GPU, so the next batch can be begun before this one is finished."""
         objmap, det = self.segment(rgb, inject_logits)
+        if not asynchronous:
+            return {"objmap": objmap, "det": det, "det_h": None, "event": None}
         det_h = torch.empty(det.shape, dtype=det.dtype, pin_memory=True)
         det_h.copy_(det, non_blocking=True)
         ev = torch.cuda.Event()
@@ -117,15 +119,22 @@ class FramePipeline:
     def finish(self, handle, rgb, depth, meta, choose_override=None, seed=0):
         """Wait for the batch's detections (the one host sync of the batch -- an event, not the stream, so segmentation work
         queued behind it keeps running), then enqueue its pose stage (on the pose stream when the pipeline has one)."""
-        handle["event"].synchronize()
-        objmap, det_h = handle["objmap"], handle["det_h"].numpy()
+        if handle["event"] is not None:
+            handle["event"].synchronize()
+            det_h = handle["det_h"].numpy()
+        else:
+            det_h = handle["det"].cpu().numpy()         # plain blocking copy (run(): nothing is queued behind it)
+        objmap = handle["objmap"]
         fb, fc = np.nonzero(det_h[:, 1:, 0])            # (frame, class - 1) of every detection, frame-major like the reference loop
         objects = [(int(b), int(c) + 1, *map(int, det_h[b, c + 1, 1:5])) for b, c in zip(fb, fc)]
         if objects:
             if choose_override is not None:             # keyed by (frame, cls) -> keyed by object position
                 choose_override = {i: choose_override.get((o[0], o[1])) for i, o in enumerate(objects)}
             if self.side is not None:
-                self.side.wait_event(handle["event"])
+                if handle["event"] is not None:
+                    self.side.wait_event(handle["event"])
+                else:
+                    self.side.wait_stream(torch.cuda.current_stream())
                 objmap.record_stream(self.side)         # allocated on the caller's stream, read by the pose stage on the side stream
                 with torch.cuda.stream(self.side):
                     pose, n_cand, choose = self.poses(rgb, depth, objmap, objects, meta, choose_override, seed)
@@ -139,7 +148,7 @@ class FramePipeline:
 
     def run(self, rgb, depth, meta, inject_logits=None, choose_override=None, seed=0):
         """Whole batch.  Returns dict(objects=[(frame,cls,rmin,rmax,cmin,cmax)], pose, n_cand, choose, objmap)."""
-        return self.finish(self.begin(rgb, inject_logits), rgb, depth, meta, choose_override, seed)
+        return self.finish(self.begin(rgb, inject_logits, asynchronous=False), rgb, depth, meta, choose_override, seed)
 
 
 def _as_u8_frame(image):

@@ -118,7 +118,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="pose stage on the same stream as the segmentation (no cross-step overlap)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="pose stage of step i on a second HIP stream beside the segmentation of step i+1 (software-pipelined loop): "
+                         "+2 %% frames/s, but the per-kernel event timings of the roofline leg then include the co-running pose kernels")
     ap.add_argument("--seg-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--pose-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
@@ -151,9 +153,10 @@ def main():
     seg.set_precision(args.seg_precision)
     est.set_precision(args.pose_precision)
     ref.set_precision(args.pose_precision)
-    # pose_stream: the pose stage of step i runs on a second HIP stream beside the segmentation of step i+1 (the timed region
-    # ends with torch.cuda.synchronize(), which waits for both streams; every step still does all of its work)
-    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=not args.no_overlap)
+    # --overlap: the pose stage of step i runs on a second HIP stream beside the segmentation of step i+1 (the timed region ends
+    # with torch.cuda.synchronize(), which waits for both streams; every step still does all of its work).  Off by default: the
+    # live per-kernel timings of the roofline leg should be the kernels' own.
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap)
     from autoposeestimation_amd.sharding import gather_results
 
     def tail(out):
@@ -178,7 +181,7 @@ def main():
         waits for step i's detections, so the main stream never idles while the host enqueues step i's ~100 pose launches.
         Exactly `count` segmentation stages and `count` pose stages are enqueued, all inside the caller's fences."""
         out = None
-        if args.no_overlap:
+        if not args.overlap:
             for i in range(first, first + count):
                 out = tail(pipe.run(rgb, depth, S.REALSENSE_META, seed=i))
             return out
