@@ -7,6 +7,8 @@ A "step" is one pass of the whole live path (FramePipeline.run: u8 RGB + u16 dep
 segmentation at 480x640 -> masks / CCL / bbox -> 160x160 crop -> PoseNet(N=1000) -> 2x PoseRefineNet -> float64 pose)
 over one batch of synthetic frames (BASELINE config 3: batch=64 640x480 frames per GPU).  Frames shard across ranks
 (weak scaling, no data-path collective); each step ends with the single RCCL all_gather of the poses (config 4).
+`--overlap` software-pipelines the loop (pose stage of step i on a second HIP stream beside the segmentation of step i+1):
+about +2 % frames/s, off by default so that the roofline leg's event timings are the kernels' own.
 Prints ONE JSON line on rank 0.
 """
 import argparse
