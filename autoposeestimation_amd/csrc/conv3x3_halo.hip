@@ -326,11 +326,13 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             for (int i = i0; i < i1; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    // WEIGHTS as the row operand: D[row = channel 4 kq + e][col = pixel r16] -- a lane ends up with four CONSECUTIVE
+                    // output channels of one pixel (same products, same k order as with the operands the other way round)
                     if (NPL == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[S][i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[S][i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], afl[S][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], afh[S][i], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afh[S][i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], afh[S][i], acc[i][j], 0, 0, 0);
                 }
         };
         if (APF && !last && BNH == 64) {
@@ -379,120 +381,88 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         }
     }
 
+    // C/D map with the weights as the row operand: lane (r16, kq) holds, for every (i, j), channels 16 j + 4 kq .. + 3 of pixel
+    // 16 i + r16 of its wave's 64 pixels.
     if constexpr (HEAD) {
-        // ---- fused head epilogue (Cout == 64, one channel tile): bias + activation on the accumulators, the 256 x 64 tile goes
-        // through the same LDS staging rows, then every wave runs the 64 -> C head + softmax(+softmax) + arg-max of seg_head.h on
-        // 16-pixel groups (one tile row each): the 64-channel activation never reaches HBM.
+        // ---- fused head epilogue (Cout == 64, one channel tile).  That register layout IS the input layout of seg_head_group
+        // (lane = (pixel, channel quad), x[j] = channels 16 j + 4 kq .. + 3), so bias + activation are applied in place and every
+        // 16-pixel row block goes straight into the 64 -> C head + softmax(+softmax) + arg-max: no LDS pass, no barrier, and the
+        // 64-channel activation never reaches HBM.
         static_assert(BNH == 64, "the fused head needs the whole 64-channel pixel in one workgroup");
-        constexpr int ELD = BNH + 4;          // 272-B rows: the eight lanes of a ds_read_b128 phase land on distinct banks
-        constexpr int RPP = 128;
-        float* stage = reinterpret_cast<float*>(smem);
         float wreg[16], hbias[4];
         ape_seg::seg_head_load_weights(a.head_w, a.head_b, a.head_c, lane, wreg, hbias);
-        float cb[4];
+        float4 cb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = j * 16 + r16;
-            cb[j] = (a.bias && n < p.Cout) ? a.bias[(p.bias_bstride ? (size_t)b * p.bias_bstride : 0) + n] : 0.f;
-        }
-#pragma unroll 1
-        for (int pass = 0; pass < 256 / RPP; ++pass) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int p0 = wm * (32 * TMW) + i * 16;
-                if (p0 / RPP != pass) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        stage[(p0 - pass * RPP + kq * 4 + e) * ELD + j * 16 + r16] = activate_h(acc[i][j][e] + cb[j], p.act, p.alpha);
-            }
-            __syncthreads();
-            for (int gi = wave; gi < RPP / 16; gi += NTH / 64) {
-                const int pidx = pass * RPP + gi * 16 + r16;
-                const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
-                float4 xv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] = *reinterpret_cast<const float4*>(&stage[(gi * 16 + r16) * ELD + (4 * j + kq) * 4]);
-                int am;
-                float pm;
-                ape_seg::seg_head_group(xv, wreg, hbias, a.head_c, lane, a.head_dsm, am, pm);
-                if (kq == 0 && gy < p.Ho && gx < p.Wo) {
-                    const size_t m = ((size_t)b * p.Ho + gy) * p.Wo + gx;
-                    a.label[m] = (uint8_t)am;
-                    a.score[m] = pm;
-                }
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // ---- epilogue: accumulators -> LDS staging rows (fp32) -> 16-byte stores, 64 consecutive lanes covering whole 256/512-B
-    // pixel rows (4 dword stores per lane straight from the 16x16 C/D layout would touch 64-B segments only; with K = 576 the
-    // up_3 launch spent more time storing than multiplying).  C/D map: col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel).
-    constexpr int ELD = BNH + 4;                          // floats per staged pixel row
-    constexpr int RPP = 128;                              // pixels staged per pass
-    float* stage = reinterpret_cast<float*>(smem);
-    const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
-    constexpr int EIT = RPP * (BNH / 4) / NTH;          // float4 items per thread per pass (8)
-    static_assert(RPP * (BNH / 4) % NTH == 0, "epilogue items");
-#pragma unroll 1
-    for (int pass = 0; pass < 256 / RPP; ++pass) {
-        // the residual float4s of this pass are requested up front and fly while the accumulators go through LDS (inside the store
-        // loop each load sat between the previous store and its own add)
-        float4 rres[EIT];
-        if (a.res && vec_ok) {
-#pragma unroll
-            for (int e = 0; e < EIT; ++e) {
-                const int it = tid + e * NTH;
-                const int row = it / (BNH / 4), c4 = it - row * (BNH / 4);
-                const int pidx = pass * RPP + row;
-                const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
-                const int n = n0 + c4 * 4;
-                if (gy < p.Ho && gx < p.Wo && n + 4 <= p.Cout)
-                    rres[e] = *reinterpret_cast<const float4*>(a.res + (((size_t)b * p.Ho + gy) * p.Wo + gx) * p.ldr + p.roff + n);
-            }
+            const int n = j * 16 + kq * 4;
+            const float* bp = a.bias ? a.bias + (p.bias_bstride ? (size_t)b * p.bias_bstride : 0) : nullptr;
+            cb[j] = make_float4(bp && n < p.Cout ? bp[n] : 0.f, bp && n + 1 < p.Cout ? bp[n + 1] : 0.f, bp && n + 2 < p.Cout ? bp[n + 2] : 0.f,
+                                bp && n + 3 < p.Cout ? bp[n + 3] : 0.f);
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int p0 = wm * (32 * TMW) + i * 16;
-            if (p0 / RPP != pass) continue;
+            const int pidx = wm * (32 * TMW) + i * 16 + r16;
+            const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
+            float4 xv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    stage[(p0 - pass * RPP + kq * 4 + e) * ELD + wn * 64 + j * 16 + r16] = acc[i][j][e];
+                xv[j] = make_float4(activate_h(acc[i][j][0] + cb[j].x, p.act, p.alpha), activate_h(acc[i][j][1] + cb[j].y, p.act, p.alpha),
+                                    activate_h(acc[i][j][2] + cb[j].z, p.act, p.alpha), activate_h(acc[i][j][3] + cb[j].w, p.act, p.alpha));
+            int am;
+            float pm;
+            ape_seg::seg_head_group(xv, wreg, hbias, a.head_c, lane, a.head_dsm, am, pm);
+            if (kq == 0 && gy < p.Ho && gx < p.Wo) {
+                const size_t m = ((size_t)b * p.Ho + gy) * p.Wo + gx;
+                a.label[m] = (uint8_t)am;
+                a.score[m] = pm;
+            }
         }
-        __syncthreads();
+        return;
+    }
+    // ---- epilogue straight from the registers: the four lanes of a pixel write 64 contiguous bytes per (i, j), neighbouring j
+    // blocks complete the 128-B lines in L2; no LDS pass, no barrier (the staged form cost two passes of stage -> barrier -> store
+    // -> barrier per tile, which with K = 576 was a large part of a tile)
+    const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
+    const int nq = n0 + wn * 64 + kq * 4;               // + 16 j
+    const float* bp = a.bias ? a.bias + (p.bias_bstride ? (size_t)b * p.bias_bstride : 0) : nullptr;
+    float4 b4[4];
 #pragma unroll
-        for (int e8 = 0; e8 < EIT; ++e8) {
-            const int it = tid + e8 * NTH;
-            const int row = it / (BNH / 4), c4 = it - row * (BNH / 4);
-            const int pidx = pass * RPP + row;
-            const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
-            const int n = n0 + c4 * 4;
-            if (gy >= p.Ho || gx >= p.Wo || n >= p.Cout) continue;
-            const size_t m = ((size_t)b * p.Ho + gy) * p.Wo + gx;
-            const float4 v = *reinterpret_cast<const float4*>(&stage[row * ELD + c4 * 4]);
-            float vv[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 4; ++j) {
+        const int n = nq + j * 16;
+        b4[j] = make_float4(bp && n < p.Cout ? bp[n] : 0.f, bp && n + 1 < p.Cout ? bp[n + 1] : 0.f, bp && n + 2 < p.Cout ? bp[n + 2] : 0.f,
+                            bp && n + 3 < p.Cout ? bp[n + 3] : 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int pidx = wm * (32 * TMW) + i * 16 + r16;
+        const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
+        const bool pok = gy < p.Ho && gx < p.Wo;
+        const size_t m = ((size_t)b * p.Ho + (pok ? gy : 0)) * p.Wo + (pok ? gx : 0);
+        float4 rr[4];
+        if (a.res && vec_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (nq + j * 16 + 4 <= p.Cout) rr[j] = *reinterpret_cast<const float4*>(a.res + m * p.ldr + p.roff + nq + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nq + j * 16;
+            if (!pok || n >= p.Cout) continue;
+            float vv[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
             const int nvalid = min(4, p.Cout - n);
-            const float* bptr = a.bias ? a.bias + (p.bias_bstride ? (size_t)b * p.bias_bstride : 0) + n : nullptr;
             if (vec_ok && nvalid == 4) {
-                if (bptr) { vv[0] += bptr[0]; vv[1] += bptr[1]; vv[2] += bptr[2]; vv[3] += bptr[3]; }
-                if (a.res) { vv[0] += rres[e8].x; vv[1] += rres[e8].y; vv[2] += rres[e8].z; vv[3] += rres[e8].w; }
+                if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
                 *reinterpret_cast<float4*>(a.y + m * p.ldy + p.yoff + n) =
-                    make_float4(activate_h(vv[0], p.act, p.alpha), activate_h(vv[1], p.act, p.alpha),
-                                activate_h(vv[2], p.act, p.alpha), activate_h(vv[3], p.act, p.alpha));
+                    make_float4(activate_h(vv[0], p.act, p.alpha), activate_h(vv[1], p.act, p.alpha), activate_h(vv[2], p.act, p.alpha),
+                                activate_h(vv[3], p.act, p.alpha));
             } else {
                 for (int k = 0; k < nvalid; ++k) {
                     float t = vv[k];
-                    if (bptr) t += bptr[k];
                     if (a.res) t += a.res[m * p.ldr + p.roff + n + k];
                     a.y[m * p.ldy + p.yoff + n + k] = activate_h(t, p.act, p.alpha);
                 }
             }
         }
-        __syncthreads();
     }
 }
 

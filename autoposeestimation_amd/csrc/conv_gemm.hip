@@ -84,10 +84,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     static_assert(BM * 4 % NT == 0 && A_IT >= 1 && B_IT >= 1, "staging shape");
     static_assert(WTM % 32 == 0 && WTN % 16 == 0 && BM % 64 == 0, "wave tile");
 
-    constexpr int ELD = BN + 4;                  // floats per staged epilogue row
     constexpr size_t kStageElems = (size_t)NPL * (BM + BN) * BK;             // bf16 per pipeline stage
-    constexpr size_t kOperandBytes = 2 * kStageElems * 2, kEpiBytes = (size_t)64 * ELD * 4;
-    __shared__ __attribute__((aligned(16))) char smem_raw[kOperandBytes > kEpiBytes ? kOperandBytes : kEpiBytes];
+    __shared__ __attribute__((aligned(16))) char smem_raw[2 * kStageElems * 2];
     __bf16* const S0 = reinterpret_cast<__bf16*>(smem_raw);
     auto a_tile = [&](int stage, int pl) { return S0 + stage * kStageElems + (size_t)pl * BM * BK; };
     auto b_tile = [&](int stage, int pl) { return S0 + stage * kStageElems + (size_t)NPL * BM * BK + (size_t)pl * BN * BK; };
@@ -224,11 +222,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
         for (int i = 0; i < TMH; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                // WEIGHTS as the row operand: D[row = channel 4 fc + e][col = pixel frow], i.e. a lane ends up with four CONSECUTIVE
+                // output channels of one pixel -- a float4 it can store straight from its registers (same products, same k order)
                 if (NPL == 2) {
-                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i0 + i][j], 0, 0, 0);
-                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i0 + i][j], 0, 0, 0);
+                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i0 + i][j], 0, 0, 0);
+                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i0 + i][j], 0, 0, 0);
                 }
-                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i0 + i][j], 0, 0, 0);
+                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i0 + i][j], 0, 0, 0);
+
             }
     };
 
@@ -265,61 +266,54 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     }
     if (PP && !behind) __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time, reusing the operand stages) -> 16-byte coalesced stores
-    // with bias / residual / activation applied on float4s
-    float* stage = reinterpret_cast<float*>(smem_raw);
     const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
-    constexpr int EIT = (64 * (BN / 4) + NT - 1) / NT;      // float4 items per thread per 64-row pass
-#pragma unroll 1
-    for (int pass = 0; pass < BM / 64; ++pass) {
-        if (pass) __syncthreads();
-        // residual float4s of this pass: all issued up front, so they fly while the accumulators go through LDS (fetched one by one
-        // inside the store loop, each load sat between the previous store and its own add: ~8 serialised HBM round trips per pass)
-        float4 rres[EIT];
-        if (a.res && vec_ok) {
+    // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel 16 i + frow for every
+    // (i, j); the four lanes of a pixel write 64 contiguous bytes, two neighbouring j blocks complete the 128-B line in L2.  No
+    // LDS pass, no barrier: the stores start behind the last MFMA (the staged form spent 8 barriers and ~10 us per 256 x 192 tile,
+    // as long as the whole k-loop of a K = 256 layer).
+    {
+        const int nq = n0 + wn * WTN + fc * 4;          // + 16 j
+        float4 b4[TN];
+        if (a.bias && !p.bias_bstride) {
 #pragma unroll
-            for (int e = 0; e < EIT; ++e) {
-                const int it = tid + e * NT;
-                const int row = it / (BN / 4), c4 = it - row * (BN / 4);
-                const int m = m0 + pass * 64 + row, n = n0 + c4 * 4;
-                if (it < 64 * (BN / 4) && m < a.M && n + 4 <= p.Cout)
-                    rres[e] = *reinterpret_cast<const float4*>(a.res + (size_t)m * p.ldr + p.roff + n);
+            for (int j = 0; j < TN; ++j) {
+                const int n = nq + j * 16;
+                b4[j] = make_float4(n < p.Cout ? a.bias[n] : 0.f, n + 1 < p.Cout ? a.bias[n + 1] : 0.f, n + 2 < p.Cout ? a.bias[n + 2] : 0.f,
+                                    n + 3 < p.Cout ? a.bias[n + 3] : 0.f);
             }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int rbase = wm * WTM + i * 16;
-            if (rbase / 64 != pass) continue;
+            const int m = m0 + wm * WTM + i * 16 + frow;
+            const bool mok = m < a.M;
+            const int mc = mok ? m : a.M - 1;
+            float4 rr[TN];
+            if (a.res && vec_ok) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
+                    if (nq + j * 16 + 4 <= p.Cout) rr[j] = *reinterpret_cast<const float4*>(a.res + (size_t)mc * p.ldr + p.roff + nq + j * 16);
+            }
+            const float* brow = (a.bias && p.bias_bstride) ? a.bias + (size_t)(mc / HoWo) * p.bias_bstride : nullptr;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    stage[(rbase - pass * 64 + fc * 4 + e) * ELD + wn * WTN + j * 16 + frow] = acc[i][j][e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EIT; ++e) {
-            const int it = tid + e * NT;
-            if (it >= 64 * (BN / 4)) continue;
-            const int row = it / (BN / 4), c4 = it - row * (BN / 4);
-            const int m = m0 + pass * 64 + row, n = n0 + c4 * 4;
-            if (m >= a.M || n >= p.Cout) continue;
-            const float4 v = *reinterpret_cast<const float4*>(&stage[row * ELD + c4 * 4]);
-            float vv[4] = {v.x, v.y, v.z, v.w};
-            const int nvalid = min(4, p.Cout - n);
-            const float* bptr = a.bias ? a.bias + (p.bias_bstride ? (size_t)(m / HoWo) * p.bias_bstride : 0) + n : nullptr;
-            if (vec_ok && nvalid == 4) {
-                if (bptr) { vv[0] += bptr[0]; vv[1] += bptr[1]; vv[2] += bptr[2]; vv[3] += bptr[3]; }
-                if (a.res) { vv[0] += rres[e].x; vv[1] += rres[e].y; vv[2] += rres[e].z; vv[3] += rres[e].w; }
-                const float4 o = make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha),
-                                             activate(vv[2], p.act, p.alpha), activate(vv[3], p.act, p.alpha));
-                *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o;
-            } else {
-                for (int k = 0; k < nvalid; ++k) {
-                    float t = vv[k];
-                    if (bptr) t += bptr[k];
-                    if (a.res) t += a.res[(size_t)m * p.ldr + p.roff + n + k];
-                    a.y[(size_t)m * p.ldy + p.yoff + n + k] = activate(t, p.act, p.alpha);
+            for (int j = 0; j < TN; ++j) {
+                const int n = nq + j * 16;
+                if (!mok || n >= p.Cout) continue;
+                float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const int nvalid = min(4, p.Cout - n);
+                if (vec_ok && nvalid == 4) {
+                    if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
+                    else if (a.bias) { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
+                    if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
+                    *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) =
+                        make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha), activate(vv[2], p.act, p.alpha),
+                                    activate(vv[3], p.act, p.alpha));
+                } else {
+                    for (int k = 0; k < nvalid; ++k) {
+                        float t = vv[k];
+                        if (a.bias) t += (brow ? brow : a.bias)[n + k];
+                        if (a.res) t += a.res[(size_t)m * p.ldr + p.roff + n + k];
+                        a.y[(size_t)m * p.ldy + p.yoff + n + k] = activate(t, p.act, p.alpha);
+                    }
                 }
             }
         }
