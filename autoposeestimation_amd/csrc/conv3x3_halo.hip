@@ -473,8 +473,7 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
     constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
     constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2;
-    constexpr size_t lds_stage = (size_t)128 * (BNH + 4) * 4;      // epilogue staging rows
-    constexpr size_t lds = lds_ops > lds_stage ? lds_ops : lds_stage;
+    constexpr size_t lds = lds_ops;      // (the epilogues work from the registers: no staging rows)
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!UPS || D == 1, "fused up-sampling is built for the d = 1 kernel");
     auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH, UPS, HEAD>;

@@ -11,7 +11,9 @@
 //     is multiplied; at the top of iteration t it is split into hi/lo planes and written to the other stage (that stage
 //     was last read in iteration t-1, before the barrier), and the global loads of tile t+2 are issued immediately, so a
 //     load has a whole iteration of MFMAs (~3000 cycles) to land and the split + ds_write pass runs under the MFMAs
-//     instead of in front of the barrier; ONE barrier per k-tile.
+//     instead of in front of the barrier; ONE barrier per k-tile;
+//   * the weights are the MFMA's ROW operand (D[channel][pixel]): a lane ends up with four consecutive output channels of
+//     one pixel and the epilogue stores float4s straight from the registers -- no LDS staging pass, no barrier after the k-loop.
 // Loads are unconditional (coordinates clamped into the tensor); out-of-image taps are zeroed when the registers are
 // written to LDS, rows >= M and columns >= Cout are computed on clamped data and dropped by the epilogue.
 #include "common.h"
