@@ -11,7 +11,24 @@ namespace ape_seg {
 
 typedef float f32x4h __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; }
+// Value of lane ^ 16 / lane ^ 32 (the other channel quads of the same pixel) through gfx950's v_permlane16_swap / v_permlane32_swap:
+// with both operands the same register, the swap leaves the even rows (low half) of the value in one result and the odd rows
+// (high half) in the other, so the partner's value is a select away -- two VALU operations instead of a ds_bpermute_b32 round
+// trip through the LDS crossbar (eight dependent ones per 16-pixel group made the head latency-bound).
+__device__ __forceinline__ unsigned lane_xor16_u(unsigned u, int lane)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);    // r[0] = {row0,row0,row2,row2}, r[1] = {row1,row1,row3,row3}
+    return (lane & 16) ? r[0] : r[1];
+}
+__device__ __forceinline__ unsigned lane_xor32_u(unsigned u, int lane)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);    // r[0] = {lo,lo}, r[1] = {hi,hi}
+    return (lane & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ float lane_xor16(float v, int lane) { return __uint_as_float(lane_xor16_u(__float_as_uint(v), lane)); }
+__device__ __forceinline__ float lane_xor32(float v, int lane) { return __uint_as_float(lane_xor32_u(__float_as_uint(v), lane)); }
+
+__device__ __forceinline__ float quad_sum(float v, int lane) { v += lane_xor16(v, lane); v += lane_xor32(v, lane); return v; }
 
 __device__ __forceinline__ void seg_head_load_weights(const float* __restrict__ w, const float* __restrict__ bias, int C, int lane,
                                                       float (&wreg)[16], float (&breg)[4])
@@ -47,11 +64,15 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
         const int c = kq * 4 + r;
         if (c < C && acc[r] > m) { m = acc[r]; am = c; }      // ascending c: first maximum of this lane's four
     }
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        const float om = __shfl_xor(m, off);
-        const int oa = __shfl_xor(am, off);
+    {
+        const float om = lane_xor16(m, lane);
+        const int oa = (int)lane_xor16_u((unsigned)am, lane);
         if (om > m || (om == m && oa < am)) { m = om; am = oa; }  // first maximum overall (torch.argmax on the CPU)
+    }
+    {
+        const float om = lane_xor32(m, lane);
+        const int oa = (int)lane_xor32_u((unsigned)am, lane);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
     }
     // v_exp_f32-based exponentials and ONE reciprocal per softmax (a few ulp from expf / a true division, far inside the 1e-5
     // the score is compared at): the precise forms cost ~400 VALU instructions per 16-pixel group, 1.6 k per wave and tile of the
@@ -59,14 +80,14 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
     float e[4], s = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? __expf(acc[r] - m) : 0.f; s += e[r]; }
-    s = quad_sum(s);
+    s = quad_sum(s, lane);
     float pm = 1.f / s;
     if (double_softmax) {
         const float inv = pm;
         float s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? __expf(e[r] * inv - pm) : 0.f;
-        pm = 1.f / quad_sum(s2);
+        pm = 1.f / quad_sum(s2, lane);
     }
     am_out = am;
     pm_out = pm;
