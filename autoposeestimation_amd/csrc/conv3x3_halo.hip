@@ -19,6 +19,22 @@
 #include "common.h"
 #include "seg_head.h"
 
+#ifdef APE_UPS_DEBUG
+// Diagnostic build only (make dbgups -> libape_hip_dbgups.so, tools/dbg_ups.py): ups_lerp re-reads its table entry at the end of
+// the tap -- the form that round 1 saw fail on grids larger than the chip -- and records every disagreement with the
+// register-carried copy.  word 0 = mismatch count, then 16-word records.
+__device__ unsigned ape_ups_dbg[1 + 16 * 64];
+extern "C" int ape_ups_debug_read(unsigned* host_out, int reset)
+{
+    if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ape_ups_dbg), sizeof(unsigned) * (1 + 16 * 64)) != hipSuccess) return -2;
+    if (reset) {
+        static unsigned zeros[1 + 16 * 64];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ape_ups_dbg), zeros, sizeof(zeros)) != hipSuccess) return -2;
+    }
+    return 0;
+}
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -167,6 +183,26 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         wgt[2] = (e < HP * 8 && (ent.y & 4u)) ? 1.f : 0.f;
     };
     auto ups_lerp = [&](int j, const float4 (&r)[4], const float (&wgt)[3]) {
+#ifdef APE_UPS_DEBUG
+        {
+            const int e = tid + NTH * j;
+            int px = e < HP * 8 ? e >> 3 : HP - 1;
+            asm volatile("" : "+v"(px));                 // opaque: a real second ds_read, not the first one's registers
+            const uint4 ent = ups_tbl[px];
+            const float w2 = (e < HP * 8 && (ent.y & 4u)) ? 1.f : 0.f;
+            if (__float_as_uint(wgt[0]) != ent.z || __float_as_uint(wgt[1]) != ent.w || w2 != wgt[2]) {
+                const unsigned slot = atomicAdd(&ape_ups_dbg[0], 1u);
+                if (slot < 64) {
+                    unsigned* d = &ape_ups_dbg[1 + 16 * slot];
+                    d[0] = blockIdx.x; d[1] = tid; d[2] = j; d[3] = px; d[4] = ent.x; d[5] = ent.y; d[6] = ent.z; d[7] = ent.w;
+                    d[8] = __float_as_uint(wgt[0]); d[9] = __float_as_uint(wgt[1]); d[10] = __float_as_uint(wgt[2]);
+                    d[11] = (unsigned)y0; d[12] = (unsigned)x0; d[13] = (unsigned)b;
+                    d[14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+                    d[15] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+                }
+            }
+        }
+#endif
         const bool ok = wgt[2] != 0.f;
         a_okmask = ok ? (a_okmask | (1u << j)) : (a_okmask & ~(1u << j));
         const float lx1 = wgt[0], ly1 = wgt[1], ly0 = 1.f - ly1, lx0 = 1.f - lx1;

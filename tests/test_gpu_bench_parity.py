@@ -1,0 +1,103 @@
+"""Parity at the BENCHMARKED configuration (BASELINE configs[2]): bench.py's exact 64 synthetic 640x480 frames, its exact
+models (frozen random PSPNet-r18 + least-squares read-out, PoseNet / PoseRefineNet with synthetic weights), split-bf16
+operands, one FramePipeline.run over the whole batch -- the run bench.py times.
+
+  * frames spread over the batch (first, two mid, last): masks bit-exact and R / t <= 1e-4 against the CPU oracle
+    (oracle.full_prediction restates pipeline/utils.py:410-641) with the GPU's `choose` injected on the oracle side;
+  * all 64 frames: the batch-64 result equals 64 independent batch-1 runs (objects, masks, `choose` bit for bit; poses to 1e-6,
+    the bound of test_batched_pipeline_equals_single_frames: batch 1 takes other GEMM block shapes for the small layers).
+"""
+import numpy as np
+import pytest
+import torch
+
+from autoposeestimation_amd import synthetic as S
+from oracle import densefusion_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bench_setup():
+    import bench
+    from autoposeestimation_amd.pipeline.utils import FramePipeline
+    dev = torch.device("cuda:0")
+    frames = bench.make_frames(64, 0)
+    fit_frames = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 + 60 * c + 90 * k), size=(126, 126))
+                  for c in range(1, 4) for k in range(2)]
+    seg, est, ref, seg_sd, est_sd, ref_sd = bench.build_models(dev, fit_frames)
+    for m in (seg, est, ref):
+        m.set_precision("bf16x3")
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(dev)
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(dev)
+    pipe = FramePipeline(seg, est, ref, bench.CLASSES, num_points=bench.N_POINTS, refine_mode="live_compat")
+    out = pipe.run(rgb, depth, S.REALSENSE_META, seed=0)
+    torch.cuda.synchronize()
+    return dict(bench=bench, frames=frames, pipe=pipe, rgb=rgb, depth=depth, out=out, sds=(seg_sd, est_sd, ref_sd))
+
+
+def test_bench_batch_matches_oracle_on_spread_frames(bench_setup):
+    s = bench_setup
+    out, classes = s["out"], s["bench"].CLASSES
+    objmap = out["objmap"].cpu().numpy()
+    pose = out["pose"].cpu().numpy()
+    choose = out["choose"].cpu().numpy()
+    assert len(out["objects"]) >= 64
+    for fidx in (0, 21, 42, 63):
+        mine = {classes[o[1] - 1]: i for i, o in enumerate(out["objects"]) if o[0] == fidx}
+
+        def choose_fn(name, nz, n):
+            return choose[mine[name]]
+
+        rgb, depth, _ = s["frames"][fidx]
+        want = O.full_prediction(rgb, depth, S.REALSENSE_META, *s["sds"], classes, choose_fn=choose_fn)
+        assert set(want) == set(mine) and len(want) >= 1, (fidx, sorted(want), sorted(mine))
+        for name, w in want.items():
+            i = mine[name]
+            cls = out["objects"][i][1]
+            diff = int(((objmap[fidx] == cls) != (w["mask"] == 255)).sum())
+            assert diff == 0, "frame %d %s: mask differs in %d pixels" % (fidx, name, diff)
+            assert tuple(out["objects"][i][2:]) == tuple(w["bbox"])
+            q = pose[i, :4] if np.dot(pose[i, :4], w["rotation"]) >= 0 else -pose[i, :4]
+            dq, dt = np.abs(q - w["rotation"]).max(), np.abs(pose[i, 4:] - w["position"]).max()
+            assert dq <= 1e-4 and dt <= 1e-4, (fidx, name, dq, dt)
+
+
+def test_bench_batch_equals_64_single_frame_runs(bench_setup):
+    s = bench_setup
+    out, pipe = s["out"], s["pipe"]
+    objmap = out["objmap"]
+    worst = 0.0
+    n_bit_equal = 0
+    for fidx in range(64):
+        ids = [i for i, o in enumerate(out["objects"]) if o[0] == fidx]
+        override = {(0, out["objects"][i][1]): out["choose"][i].cpu().numpy() for i in ids}
+        one = pipe.run(s["rgb"][fidx:fidx + 1], s["depth"][fidx:fidx + 1], S.REALSENSE_META, choose_override=override, seed=0)
+        assert [o[1:] for o in one["objects"]] == [out["objects"][i][1:] for i in ids], fidx
+        assert torch.equal(one["objmap"][0], objmap[fidx]), "frame %d: batch-1 mask differs from the batch-64 mask" % fidx
+        assert torch.equal(one["choose"], out["choose"][ids])
+        d = (one["pose"] - out["pose"][ids]).abs().max().item() if ids else 0.0
+        worst = max(worst, d)
+        n_bit_equal += int(torch.equal(one["pose"], out["pose"][ids]))
+    print("batch-64 vs batch-1 poses: max |diff| %.3g, bit-equal on %d / 64 frames" % (worst, n_bit_equal))
+    assert worst <= 1e-6
+
+
+def test_bench_segmentor_fused_head_equals_unfused_at_batch_64(bench_setup):
+    """label_score_nhwc (up_3 with the x2 up-sampling fused into its halo load and the head in its epilogue: 19 200 workgroups per
+    frame, 1.2 M for the batch) == materialised features -> ape_seg_head_f32, labels and scores bit for bit, at B = 64, 480x640."""
+    from autoposeestimation_amd import engine as E
+    s = bench_setup
+    seg = s["pipe"].segmentor
+    b = 64
+    rects = torch.zeros(b, 3, dtype=torch.int32)
+    rects[:, 0] = torch.arange(b, dtype=torch.int32)
+    x4 = E.preprocess_u8(s["rgb"], rects.cuda(), 480, 640, div255=True)
+    label, score = seg.label_score_nhwc(x4, double_softmax=True)
+    pl = seg.plan()
+    low = pl.features(x4, stop_before_up3=True)
+    for lo, hi in ((0, 32), (32, 64)):           # the unfused side in two halves (a 5 GB activation each)
+        feat = pl.up3(E.bilinear(low[lo:hi], 480, 640, True))
+        want_label, want_score = E.seg_head(feat, seg._head_w, seg._head_b, True)
+        assert torch.equal(label[lo:hi], want_label) and torch.equal(score[lo:hi], want_score)
+        del feat

@@ -126,8 +126,13 @@ def test_conv_rejects_bad_geometry():
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
-# (1, 120, 160, ...): more workgroups than the chip holds at once -- a table-read bug of the fused up-sampling only showed there
-@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 64), (1, 17, 9, 32, 160), (1, 120, 160, 64, 64)])
+# Grids larger than the chip (256 CUs x 2 workgroups): round 1 saw a table-read fault of the fused up-sampling only there.  Per
+# instantiation (BNH = 64 for Cout <= 64, else 128; NSPLIT from the precision) at least three such grids, ragged tile counts included:
+# (2,120,160,64,64) 600 workgroups, (1,200,168,64,64) 525, (3,136,104,64,64) 663 | (1,200,168,32,160) 1050, (2,120,160,64,128) 600,
+# (3,136,104,32,128) 663
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 64), (1, 17, 9, 32, 160), (1, 120, 160, 64, 64), (2, 120, 160, 64, 64),
+                                   (1, 200, 168, 64, 64), (3, 136, 104, 64, 64), (1, 200, 168, 32, 160), (2, 120, 160, 64, 128),
+                                   (3, 136, 104, 32, 128)])
 def test_fused_upsample_conv_equals_materialised(shape, precision):
     """nn.Upsample(x2, align_corners=True) + 3x3 conv (pspnet.py:30-32): the up-sampling fused into the LDS-halo kernel's
     load must equal bilinear kernel -> same conv, bit for bit (same interpolation op order, same products)."""
@@ -151,7 +156,9 @@ def test_fused_upsample_conv_equals_materialised(shape, precision):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("ups,h,w", [(True, 24, 40), (False, 48, 80), (True, 21, 33)])
+# b = 3 below; the larger cases launch 900 / 663 / 1575 workgroups (more than 256 CUs x 2) for every UPS x HEAD instantiation
+@pytest.mark.parametrize("ups,h,w", [(True, 24, 40), (False, 48, 80), (True, 21, 33), (True, 120, 160), (True, 136, 104), (True, 200, 168),
+                                     (False, 240, 320), (False, 272, 208), (False, 400, 336)])
 def test_halo_conv_with_fused_seg_head_is_bit_identical_to_the_unfused_pair(precision, ups, h, w):
     """ape_conv3x3_halo_seghead_bf16 == ape_conv3x3_halo_bf16 followed by ape_seg_head_f32 (labels and scores bit for bit),
     incl. ragged tiles and the fused x2 up-sampling"""
