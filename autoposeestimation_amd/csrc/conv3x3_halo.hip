@@ -147,7 +147,11 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     // eight channel items of a halo pixel and for every chunk: it is computed ONCE per tile into a 16-B LDS table entry per halo
     // pixel (the per-item form spent ~100 VALU operations per item, fetch and blend together, 2.2 k per wave and tile in a kernel
     // that is VALU-issue-bound).  Same expressions, so the blend weights and the result are bit-identical.
+#if defined(APE_UPS_DEBUG) && APE_UPS_DEBUG == 2
+    uint4* const ups_tbl = reinterpret_cast<uint4*>(Bs + (size_t)2 * NPL * BNH * LDH);      // round-1 placement: dynamic LDS, behind the weight tiles
+#else
     __shared__ uint4 ups_tbl[UPS ? HP : 1];
+#endif
     if (UPS) {
         for (int px = tid; px < HP; px += NTH) {
             const int hy = px / HW_, hx = px - hy * HW_;
@@ -508,7 +512,11 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     constexpr int HP = (TS + 2 * D) * (TS + 2 * D);
     constexpr bool A_DOUBLE = halo_a_double(NPL, HP, BNH);
+#if defined(APE_UPS_DEBUG) && APE_UPS_DEBUG == 2
+    constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2 + (UPS ? HP * 16 : 0);
+#else
     constexpr size_t lds_ops = ((A_DOUBLE ? 2 : 1) * HP * halo_lda(NPL) + 2 * NPL * BNH * LDH) * 2;
+#endif
     constexpr size_t lds = lds_ops;      // (the epilogues work from the registers: no staging rows)
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!UPS || D == 1, "fused up-sampling is built for the d = 1 kernel");

@@ -2,7 +2,8 @@
 models (frozen random PSPNet-r18 + least-squares read-out, PoseNet / PoseRefineNet with synthetic weights), split-bf16
 operands, one FramePipeline.run over the whole batch -- the run bench.py times.
 
-  * frames spread over the batch (first, two mid, last): masks bit-exact and R / t <= 1e-4 against the CPU oracle
+  * frames spread over the batch (first, two mid, last): masks bit-exact -- except pixels that are arg-max near-ties in the oracle's
+    own probabilities (top-2 margin < 1e-4; one such pixel exists in these four frames) -- and R / t <= 1e-4 against the CPU oracle
     (oracle.full_prediction restates pipeline/utils.py:410-641) with the GPU's `choose` injected on the oracle side;
   * all 64 frames: the batch-64 result equals 64 independent batch-1 runs (objects, masks, `choose` bit for bit; poses to 1e-6,
     the bound of test_batched_pipeline_equals_single_frames: batch 1 takes other GEMM block shapes for the small layers).
@@ -55,8 +56,22 @@ def test_bench_batch_matches_oracle_on_spread_frames(bench_setup):
         for name, w in want.items():
             i = mine[name]
             cls = out["objects"][i][1]
-            diff = int(((objmap[fidx] == cls) != (w["mask"] == 255)).sum())
-            assert diff == 0, "frame %d %s: mask differs in %d pixels" % (fidx, name, diff)
+            differs = (objmap[fidx] == cls) != (w["mask"] == 255)
+            if differs.any():
+                # The class map is an arg-max over fp32 (oracle) / split-bf16 (GPU) logits: along an object's border a pixel whose two
+                # best classes are closer than the numerical noise of either side may flip.  Admitted ONLY there: every differing
+                # pixel must be a near tie in the ORACLE's own probabilities (top-2 margin < 1e-4, north_star's floating-point
+                # tolerance), and there may be at most a handful.  (Given identical class maps the masks are bit-exact:
+                # tests/test_gpu_segpost.py from injected logits.)
+                import torch.nn.functional as F
+                with torch.no_grad():
+                    pr = F.softmax(O.segmentor_predict(s["sds"][0], O.seg_input(rgb), len(classes) + 1), dim=1)[0]
+                ys, xs = np.nonzero(differs)
+                top = torch.topk(pr[:, ys, xs], 2, dim=0).values
+                margins = (top[0] - top[1]).tolist()
+                print("frame %d %s: %d differing pixel(s) at %s, oracle top-2 probability margins %s" %
+                      (fidx, name, len(ys), list(zip(ys.tolist(), xs.tolist())), margins))
+                assert len(ys) <= 4 and max(margins) < 1e-4, "frame %d %s: mask differs outside the tie band" % (fidx, name)
             assert tuple(out["objects"][i][2:]) == tuple(w["bbox"])
             q = pose[i, :4] if np.dot(pose[i, :4], w["rotation"]) >= 0 else -pose[i, :4]
             dq, dt = np.abs(q - w["rotation"]).max(), np.abs(pose[i, 4:] - w["position"]).max()
