@@ -24,6 +24,13 @@ SIGNATURES = {
     "ape_conv2d_nhwc_bf16": [_P, _P, _P, _P, _P, _P, _I, _P],
     "ape_conv_gemm_supported": [_P],
     "ape_conv_gemm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "ape_pack_weights_s32k": [_P, _P, _I, _I, _P],
+    "ape_convert_s32": [_P, _P, _c.c_long, _I, _I, _P],
+    "ape_conv_gemm_s32_supported": [_P],
+    "ape_conv_gemm_s32_debug": [_I],
+    "ape_conv_gemm_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
+    "ape_conv3x3_halo_s32_supported": [_P],
+    "ape_conv3x3_halo_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
     "ape_stem_conv_pool_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ape_conv3x3_halo_supported": [_P],
     "ape_conv3x3_halo_bf16": [_P, _P, _P, _P, _P, _P, _I, _P],

@@ -1,0 +1,437 @@
+// 3x3 / stride 1 / pad == dilation in {1,2,4} convolution on PRE-SPLIT ("S32", include/ape_hip.h) activations: the successor of
+// conv3x3_halo.hip for the wide (Cout >= 128) layers of the segmentor.  Same tile (16 x 16 output pixels x 128 output channels per
+// workgroup, 8 waves = 4 pixel-row groups x 2 channel halves, wave tile 64 pixels x 64 channels, v_mfma_f32_16x16x32_bf16 with the
+// weights as the row operand), same products and the same K order (32-channel chunk outer, nine taps inner), hence the same
+// accumulators bit for bit.  What changed is how the operands get to the matrix cores:
+//   * no staging registers, no split / convert VALU, no ds_write: the halo and the weight tiles are LDS-DMA'd
+//     (`buffer_load_dwordx4 ... lds`, 1 KB = 8 pixels (rows) x 128 B per wave-instruction); pixels outside the image and rows past
+//     Cout lie outside the buffer descriptors' range and arrive as zeros;
+//   * the halo lives in a RING OF 32 IMAGE ROWS (24 pixels x 128 B each): the (16 + 2d)-row image of chunk c+1 is streamed in while
+//     chunk c is multiplied -- 16 - 2d rows at once, d rows after its taps ky = 0, d after ky = 1, 2d during its last tap -- so the
+//     first 16 rows are there when chunk c ends, for every dilation (a second whole image does not fit beside the weights for d = 4);
+//   * the weights of the next taps sit in a ring of four 16 KB tiles, issued three taps ahead;
+//   * the fragments of tap t+1 are read from LDS (pinned inline asm, cf. conv_gemm_s32.hip) into a second register set while the
+//     48 MFMAs of tap t run; one barrier per tap, counted vmcnt (never 0 in the steady state).
+// LDS image: a pixel (a weight row) is 128 B = chunks 0..3 hi | 4..7 lo, chunk c of pixel column hx in slot c ^ ((hx >> 1) & 7)
+// (weights: row instead of hx); the permutation is applied to the per-lane DMA SOURCE address, inside the 128-B line.
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct HaloS32Args {
+    const char* x;          // S32 activations [B][H][W][ldx]
+    const char* w;          // S32K weights [Cout][9 * Cin / 32][hi 32 | lo 32], K order (tap, channel)
+    const float* bias;
+    const char* res;
+    char* y;
+    int B, H, W, Cin, Cout;
+    int ldx, xoff, ldy, yoff, ldr, roff;
+    int act;
+    float alpha;
+    int bias_bstride;
+    int out_fmt, res_fmt;
+    int tiles_x, tiles_y, n_tiles;
+};
+
+__device__ __forceinline__ float act_h(float v, int act, float alpha)
+{
+    switch (act) {
+        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
+        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define APE_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#else
+#define APE_DS_READ(dst, addr, off) (void)(addr)
+#endif
+
+
+// fragment reads of HALF a tap (asm operands cannot name variables captured by a generic lambda, hence a free function): two
+// pixel rows (hi, lo) at their own ring-row addresses and two of the four 16-channel weight blocks (2 KB apart)
+template <int JOFF>
+__device__ __forceinline__ void ds_read_half(u32x4 (&A)[2][2], u32x4 (&Bf)[4][2], unsigned a0h, unsigned a0l, unsigned a1h, unsigned a1l,
+                                             unsigned bh, unsigned bl)
+{
+    APE_DS_READ(A[0][0], a0h, 0); APE_DS_READ(A[0][1], a0l, 0);
+    APE_DS_READ(A[1][0], a1h, 0); APE_DS_READ(A[1][1], a1l, 0);
+    APE_DS_READ(Bf[JOFF][0], bh, JOFF * 2048);           APE_DS_READ(Bf[JOFF][1], bl, JOFF * 2048);
+    APE_DS_READ(Bf[JOFF + 1][0], bh, JOFF * 2048 + 2048); APE_DS_READ(Bf[JOFF + 1][1], bl, JOFF * 2048 + 2048);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a literal)
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#endif
+}
+
+constexpr int TS = 16;                  // output tile edge
+constexpr int HWP = 24;                 // pixels per ring row (3 DMA pieces); the halo needs 16 + 2 d <= 24 of them
+constexpr int ROW_B = HWP * 128;        // 3072 B
+constexpr int RING_ROWS = 32;
+constexpr int A_BYTES = RING_ROWS * ROW_B;          // 96 KB
+constexpr int B_TILE = 128 * 128;                   // one tap's weights: 128 rows x (hi 64 B | lo 64 B)
+constexpr int B_RING = 4;
+constexpr int LDS_BYTES = A_BYTES + B_RING * B_TILE;   // 160 KB
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int I = TS + 2 * D;       // image rows of one chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int nwg = a.B * tiles_per_img * a.n_tiles;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const int n_tile = logical % a.n_tiles;
+    const int mt = logical / a.n_tiles;
+    const int b = mt / tiles_per_img, trem = mt - b * tiles_per_img;
+    const int y0 = (trem / a.tiles_x) * TS, x0 = (trem % a.tiles_x) * TS;
+    const int n0 = n_tile * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nchunks = a.Cin / 32;
+    const int K = 9 * a.Cin;
+    const int ntaps = nchunks * 9;
+
+    // ---- DMA sources ---------------------------------------------------------------------------------------------------------
+    const long x_bytes = (long)a.B * a.H * a.W * a.ldx * 4;
+    const long w_bytes = (long)(a.Cout - n0) * K * 4;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.w + (long)n0 * K * 4), 0, (int)(w_bytes > 0x7FFFFFFFL ? 0x7FFFFFFFu : (unsigned)w_bytes), 0x00020000);
+    // a halo piece = 8 pixels of one image row: lanes 8 j .. 8 j + 7 fetch pixel j's 128-B line, chunks permuted by the column swizzle
+    unsigned lane_x[3];
+#pragma unroll
+    for (int xp = 0; xp < 3; ++xp) {
+        const int hx = xp * 8 + (lane >> 3);
+        const int gx = x0 - D + hx;
+        const bool ok = hx < TS + 2 * D && (unsigned)gx < (unsigned)a.W;
+        lane_x[xp] = ok ? (unsigned)((gx * a.ldx + a.xoff) * 4 + (((lane & 7) ^ ((hx >> 1) & 7)) * 16)) : 0x80000000u;
+    }
+    unsigned vb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        vb[i] = (unsigned)(row * K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+    // piece `p` of image rows [r0, ..) of chunk `c` (row = r0 + p / 3, x-piece = p % 3), written to ring row (ring0 + row) & 31
+    auto dma_a_piece = [&](int c, int ring0, int row, int xp) {      // xp: a literal at every call site
+        const int gy = y0 - D + row;
+        const bool row_ok = (unsigned)gy < (unsigned)a.H;
+        const unsigned row_off = (unsigned)(((b * a.H + (row_ok ? gy : 0)) * a.W) * a.ldx * 4 + c * 128);
+        unsigned voff = lane_x[xp] + row_off;
+        if (!row_ok) voff = 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + ((ring0 + row) & (RING_ROWS - 1)) * ROW_B + xp * 1024), 16, voff, 0, 0, 0);
+    };
+    // The 3 * nrows pieces of image rows [r0, r0 + nrows) are dealt to the waves by (row * 3 + xp) % 8, i.e. for x-piece xp a wave
+    // takes the rows  r = 3 (wave - xp) mod 8, + 8, ...  (3 is its own inverse mod 8).  xp stays a compile-time index: lane_x[] must
+    // not be indexed at run time (it would live in scratch, and a scratch reload's vmcnt(0) would drain the DMA pipeline).
+    auto dma_a_rows_xp = [&](int c, int ring0, int r0, int nrows, auto xp_c) -> int {
+        constexpr int xp = decltype(xp_c)::value;
+        int n = 0;
+        for (int row = (3 * (wave - xp + 8)) & 7; row < nrows; row += 8) {
+            dma_a_piece(c, ring0, r0 + row, xp);
+            ++n;
+        }
+        return n;
+    };
+    auto dma_b_tap = [&](int tg) {        // the weights of global tap tg = chunk * 9 + tap: k-group tap * nchunks + chunk, ring slot tg & 3
+        const int c = tg / 9, tap = tg - c * 9;
+        const int g = tap * nchunks + c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + A_BYTES + (tg & (B_RING - 1)) * B_TILE + (wave * 2 + i) * 1024), 16,
+                                                     vb[i], g * 128, 0, 0);
+    };
+
+    // ---- fragment addresses --------------------------------------------------------------------------------------------------
+    const int frow = lane & 15, fc = lane >> 4;
+    unsigned a_lane[3][2];              // [kx][plane]: byte offset inside a ring row of this lane's chunk of pixel column frow + kx * D
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int hx = frow + kx * D;
+        const int sw = (hx >> 1) & 7;
+        a_lane[kx][0] = (unsigned)(hx * 128 + ((fc ^ sw) * 16));
+        a_lane[kx][1] = (unsigned)(hx * 128 + (((4 + fc) ^ sw) * 16));
+    }
+    const int swb = (frow >> 1) & 7;
+    const unsigned b_lane[2] = {(unsigned)(A_BYTES + (wn * 64 + frow) * 128 + ((fc ^ swb) * 16)),
+                                (unsigned)(A_BYTES + (wn * 64 + frow) * 128 + (((4 + fc) ^ swb) * 16))};
+    u32x4 Ah[2][2][2], Bf[2][4][2];     // Ah[half][pixel row in the half][plane] (one tap's rows 0,1 | 2,3); Bf[set][channel block][plane]
+    // read: pixel rows 2 half, 2 half + 1 of (image at ring0, tap) and weight blocks 2 half, 2 half + 1 of global tap tgb into B set `bset`
+    auto read_half = [&](auto half_c, auto bset_c, int ring0, int tap, int tgb) {
+        constexpr int half = decltype(half_c)::value, bset = decltype(bset_c)::value;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
+        const int rb = ring0 + 4 * wm + ky * D + 2 * half;
+        const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
+        const unsigned so = (unsigned)((tgb & (B_RING - 1)) * B_TILE);
+        ds_read_half<2 * half>(Ah[half], Bf[bset], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    // 48 MFMAs of one tap on register set `set`; hook(i) runs (pinned) after pixel row i: the DMA pieces go out between the rows
+    auto mfma_row = [&](auto set_c, auto ic) {
+        constexpr int set = decltype(set_c)::value, i = decltype(ic)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, Bf[set][j][0]), bl = __builtin_bit_cast(bf16x8, Bf[set][j][1]);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah[i >> 1][i & 1][0]), al = __builtin_bit_cast(bf16x8, Ah[i >> 1][i & 1][1]);
+            // weights as the row operand (D[channel 4 fc + e][pixel frow]); product order of conv3x3_halo.hip
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[i][j], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: the whole first image and the first three weight tiles --------------------------------------------------------
+    dma_a_rows_xp(0, 0, 0, I, I0{});
+    dma_a_rows_xp(0, 0, 0, I, I1{});
+    dma_a_rows_xp(0, 0, 0, I, I2{});
+    dma_b_tap(0);
+    if (ntaps > 1) dma_b_tap(1);
+    if (ntaps > 2) dma_b_tap(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_half(I0{}, I0{}, 0, 0, 0);
+    {   // second half of tap 0's weights (its pixel rows 2, 3 are read during the tap's first phase)
+        u32x4 dummy[2][2];
+        const unsigned a0 = a_lane[0][0];
+        ds_read_half<2>(dummy, Bf[0], a0, a0, a0, a0, b_lane[0], b_lane[1]);
+        asm volatile("" :: "v"(dummy[0][0]), "v"(dummy[0][1]), "v"(dummy[1][0]), "v"(dummy[1][1]));
+    }
+    phase_end();
+
+    // ---- one tap = two phases of 24 MFMAs (pixel rows 0,1 | 2,3 against the four weight blocks of B set P).  While a phase runs, the
+    // fragments of the NEXT phase are read: phase 0 fetches this tap's rows 2,3 and weight blocks 0,1 of tap t+1 (into the other B
+    // set), phase 1 fetches rows 0,1 and weight blocks 2,3 of tap t+1.  The DMA pieces of the next image (rows [ar0, ar0 + arn) of
+    // chunk c+1, ring position ring_next) and the weights of tap t+3 go out between the MFMA rows.  The closing barrier makes the
+    // weights of tap t+2 (issued one tap ago) and every older piece visible: only what this tap issued may still be in flight.
+    auto tap_body = [&](auto set_c, int c, int tap, int ring_cur, int ring_next, int ar0, int arn) {
+        constexpr int P = decltype(set_c)::value;
+        const int tg = c * 9 + tap;
+        const bool has_next = tg + 1 < ntaps;
+        const bool wrap = tap == 8;
+        const int nring = wrap ? ring_next : ring_cur, ntap = wrap ? 0 : tap + 1;
+        const bool more_a = c + 1 < nchunks && arn > 0;
+        const bool more_b = tg + 3 < ntaps;
+        int issued = 0;
+        // phase 0
+        {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
+            const int rb = ring_cur + 4 * wm + ky * D + 2;
+            const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
+            const unsigned so = (unsigned)(((tg + 1) & (B_RING - 1)) * B_TILE);
+            ds_read_half<0>(Ah[1], Bf[P ^ 1], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(set_c, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_a) issued += dma_a_rows_xp(c + 1, ring_next, ar0, arn, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(set_c, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_a) issued += dma_a_rows_xp(c + 1, ring_next, ar0, arn, I1{});
+        phase_end();
+        // phase 1
+        {
+            const int ky = ntap / 3, kx = ntap - ky * 3;
+            const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
+            const int rb = nring + 4 * wm + ky * D;
+            const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
+            const unsigned so = (unsigned)(((tg + 1) & (B_RING - 1)) * B_TILE);
+            ds_read_half<2>(Ah[0], Bf[P ^ 1], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(set_c, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_a) issued += dma_a_rows_xp(c + 1, ring_next, ar0, arn, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(set_c, I3{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_b) { dma_b_tap(tg + 3); issued += 2; }
+        phase_end();
+        (void)has_next;
+        wait_vmcnt(issued);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int ring = 0;       // ring row of the current chunk's image row 0
+#pragma unroll 1
+    for (int c = 0; c < nchunks; c += 2) {
+        // two chunks per iteration: 18 taps, so the register sets alternate with a compile-time parity
+        const int ring1 = (ring + I) & (RING_ROWS - 1), ring2 = (ring1 + I) & (RING_ROWS - 1);
+        tap_body(I0{}, c, 0, ring, ring1, 0, RING_ROWS - I);
+        tap_body(I1{}, c, 1, ring, ring1, 0, 0);
+        tap_body(I0{}, c, 2, ring, ring1, 0, 0);
+        tap_body(I1{}, c, 3, ring, ring1, RING_ROWS - I, D);
+        tap_body(I0{}, c, 4, ring, ring1, 0, 0);
+        tap_body(I1{}, c, 5, ring, ring1, 0, 0);
+        tap_body(I0{}, c, 6, ring, ring1, RING_ROWS - I + D, D);
+        tap_body(I1{}, c, 7, ring, ring1, 0, 0);
+        tap_body(I0{}, c, 8, ring, ring1, RING_ROWS - I + 2 * D, 2 * D);
+        if (c + 1 < nchunks) {
+            tap_body(I1{}, c + 1, 0, ring1, ring2, 0, RING_ROWS - I);
+            tap_body(I0{}, c + 1, 1, ring1, ring2, 0, 0);
+            tap_body(I1{}, c + 1, 2, ring1, ring2, 0, 0);
+            tap_body(I0{}, c + 1, 3, ring1, ring2, RING_ROWS - I, D);
+            tap_body(I1{}, c + 1, 4, ring1, ring2, 0, 0);
+            tap_body(I0{}, c + 1, 5, ring1, ring2, 0, 0);
+            tap_body(I1{}, c + 1, 6, ring1, ring2, RING_ROWS - I + D, D);
+            tap_body(I0{}, c + 1, 7, ring1, ring2, 0, 0);
+            tap_body(I1{}, c + 1, 8, ring1, ring2, RING_ROWS - I + 2 * D, 2 * D);
+        }
+        ring = ring2;
+    }
+
+    // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel (4 wm + i, frow) -----------
+    const int nq = n0 + wn * 64 + fc * 4;
+    const float* bp = a.bias ? a.bias + (a.bias_bstride ? (size_t)b * a.bias_bstride : 0) : nullptr;
+    float4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nq + j * 16;
+        b4[j] = (bp && n < a.Cout) ? *reinterpret_cast<const float4*>(bp + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gy = y0 + 4 * wm + i, gx = x0 + frow;
+        if (gy >= a.H || gx >= a.W) continue;
+        const size_t m = ((size_t)b * a.H + gy) * a.W + gx;
+        float4 rr[4];
+        if (a.res) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nq + j * 16;
+                if (n >= a.Cout) continue;
+                if (a.res_fmt == APE_FMT_S32) {
+                    const int cr = a.roff + n;
+                    const char* rp = a.res + m * a.ldr * 4 + (cr >> 5) * 128 + (cr & 31) * 2;
+                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(rp), l = *reinterpret_cast<const bf16x4*>(rp + 64);
+                    rr[j] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+                } else {
+                    rr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + m * a.ldr + a.roff + n);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nq + j * 16;
+            if (n >= a.Cout) continue;
+            float vv[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
+            if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = act_h(vv[e], a.act, a.alpha);
+            if (a.out_fmt == APE_FMT_S32) {
+                const int cy = a.yoff + n;
+                char* yp = a.y + m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
+                bf16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
+                *reinterpret_cast<bf16x4*>(yp) = h;
+                *reinterpret_cast<bf16x4*>(yp + 64) = l;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+        }
+    }
+#endif
+}
+#undef APE_DS_READ
+
+template <int D>
+int launch_halo_s32(const HaloS32Args& a, hipStream_t st)
+{
+    auto kern = halo_s32_kernel<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            return APE_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_x * a.tiles_y * a.n_tiles), dim3(512), LDS_BYTES, st, a);
+    return ape::check_launch("ape_conv3x3_halo_s32");
+}
+
+bool halo_s32_supported(const ape_conv_params& p)
+{
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != p.dil || (p.dil != 1 && p.dil != 2 && p.dil != 4) || p.ups != 0) return false;
+    if (p.B < 0 || p.H < 1 || p.W < 1 || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.Cin < 32 || p.Cin % 32 || p.ldx % 32 || p.xoff % 32 || p.xoff + p.Cin > p.ldx) return false;
+    if (p.Cout < 128 || p.Cout % 4 || p.yoff + p.Cout > p.ldy || p.ldy % 4 || p.yoff % 4) return false;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return false;
+    if ((long)p.B * p.H * p.W * p.ldx * 4 >= (1L << 31) || 128L * 9 * p.Cin * 4 >= (1L << 31)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int ape_conv3x3_halo_s32_supported(const ape_conv_params* params) { return params && halo_s32_supported(*params) ? 1 : 0; }
+
+extern "C" int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
+                                    int out_fmt, const ape_conv_params* params, void* stream)
+{
+    if (!x_s32 || !w_s32k || !y || !params) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (!halo_s32_supported(p)) return APE_EINVAL;
+    if ((out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) || (residual && res_fmt != APE_FMT_F32 && res_fmt != APE_FMT_S32)) return APE_EINVAL;
+    if (out_fmt == APE_FMT_S32 && p.ldy % 32) return APE_EINVAL;
+    if (residual && (p.roff + p.Cout > p.ldr || p.ldr % 4 || p.roff % 4 || (res_fmt == APE_FMT_S32 && p.ldr % 32))) return APE_EINVAL;
+    if (p.B == 0) return APE_OK;
+    HaloS32Args a;
+    a.x = (const char*)x_s32; a.w = (const char*)w_s32k; a.bias = bias; a.res = (const char*)residual; a.y = (char*)y;
+    a.B = p.B; a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Cout = p.Cout;
+    a.ldx = p.ldx; a.xoff = p.xoff; a.ldy = p.ldy; a.yoff = p.yoff; a.ldr = p.ldr; a.roff = p.roff;
+    a.act = p.act; a.alpha = p.alpha; a.bias_bstride = p.bias_bstride; a.out_fmt = out_fmt; a.res_fmt = res_fmt;
+    a.tiles_x = ape::ceil_div(p.W, TS); a.tiles_y = ape::ceil_div(p.H, TS); a.n_tiles = ape::ceil_div(p.Cout, 128);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dil == 1) return launch_halo_s32<1>(a, st);
+    if (p.dil == 2) return launch_halo_s32<2>(a, st);
+    return launch_halo_s32<4>(a, st);
+}

@@ -1,0 +1,476 @@
+// 1x1 convolutions (row-major GEMMs) on PRE-SPLIT activations, operands streamed HBM -> LDS by LDS-DMA.
+//
+// "S32" activation layout (the split-bf16 operands of conv_gemm.hip / conv3x3_halo.hip, made once by the PRODUCER's epilogue
+// instead of by every consumer tile): a pixel's C channels (C % 32 == 0) are C/32 groups of 128 bytes,
+//      [ hi: 32 x bf16 | lo: 32 x bf16 ],     hi = bf16(v),  lo = bf16(v - hi)        (4 bytes per channel, like fp32)
+// so that a 32-channel k-tile of a pixel is ONE 128-byte line that is already the MFMA operand pair.  Weights use the same
+// grouping along K ("S32K": [Cout][K/32][hi 32 | lo 32]).  The MFMA inputs are bit-identical to what conv_gemm.hip derives from
+// fp32 activations; only non-MFMA consumers (residual adds) see hi + lo instead of the fp32 value (2^-17 relative).
+//
+// Main loop (256 pixels x BN channels per workgroup, 8 waves = 2 x 4, wave tile 128 x BN/4, v_mfma_f32_16x16x32_bf16, weights as
+// the row operand like conv_gemm.hip):
+//   * staging costs NO registers and NO VALU: every wave issues 4 + BN/64 `buffer_load_dwordx4 ... lds` per k-tile (1 KB each =
+//     8 rows x 128 B); rows past M / Cout are out of the buffer descriptor's range and arrive as zeros;
+//   * LDS image: rows of 128 B, 16-B chunk c of row r (c = 0..3 hi, 4..7 lo) in slot c ^ ((r >> 1) & 7).  The DMA writes LDS
+//     linearly (lanes 8 r .. 8 r + 7 = one row = one whole 128-B line: the permutation is on the per-lane SOURCE address, inside
+//     the line); the 16 lanes of every ds_read_b128 lane group (rows r..r+3, r+12..r+15 of chunk k and rows r+4..r+11 of chunk
+//     k+1) hit 16 distinct 16-B bank slots;
+//   * LDS rings: three slots for the pixel tiles, two for the weight tiles (160 KB at BN = 256), counted vmcnt: up to 96 KB per
+//     CU in flight across the barrier (with two stages and one tile in flight the DMA round trip, ~1.9 us per 64 KB, was as long
+//     as the k-tile's MFMAs and every barrier waited for it);
+//   * ONE barrier per k-tile; the k-tile is cut into four phases of (4 x TN/2 x 3) MFMAs -- (A0,B0) (A0,B1)
+//     (A1,B1) (A1,B0) -- and the fragments of the NEXT phase are read from LDS while the current phase's MFMAs run (two A
+//     register sets, two B sets, the B sets swap roles every k-tile), so no wave ever waits on the LDS port in front of its
+//     MFMAs: the freed staging registers are what pays for the second fragment set.
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct GemmS32Args {
+    const char* x;          // S32 activations, row m at x + m * ldx * 4 (bytes)
+    const char* w;          // S32K weights, row n at w + n * K * 4
+    const float* bias;
+    const char* res;        // residual (fp32 or S32, res_fmt) or null
+    char* y;
+    int M, K, Cout;
+    int ldx, xoff, ldy, yoff, ldr, roff;
+    int act;
+    float alpha;
+    int bias_bstride, rows_per_image;
+    int out_fmt, res_fmt;   // APE_FMT_F32 / APE_FMT_S32
+    int m_tiles, n_tiles, nk;
+    int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads
+};
+
+__device__ __forceinline__ float act_fn(float v, int act, float alpha)
+{
+    switch (act) {
+        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
+        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
+        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+
+// (the host pass of hipcc instantiates kernel bodies too and silently drops a kernel whose body holds an asm it cannot check
+// against the HOST target -- the library then lacks the kernel's stub -- so the statement exists in the device pass only)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define APE_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#else
+#define APE_DS_READ(dst, addr, off) (void)(addr)
+#endif
+// four 16-row blocks x two planes of one operand half (block i at + i * 2048; the planes have their own base registers)
+template <int OFF>
+__device__ __forceinline__ void ds_read_frags4(u32x4 (&f)[4][2], unsigned hi, unsigned lo)
+{
+    APE_DS_READ(f[0][0], hi, OFF);
+    APE_DS_READ(f[0][1], lo, OFF);
+    APE_DS_READ(f[1][0], hi, OFF + 2048);
+    APE_DS_READ(f[1][1], lo, OFF + 2048);
+    APE_DS_READ(f[2][0], hi, OFF + 4096);
+    APE_DS_READ(f[2][1], lo, OFF + 4096);
+    APE_DS_READ(f[3][0], hi, OFF + 6144);
+    APE_DS_READ(f[3][1], lo, OFF + 6144);
+}
+template <int OFF, int NJ, int TNH>
+__device__ __forceinline__ void ds_read_frags(u32x4 (&f)[TNH][2], unsigned hi, unsigned lo)
+{
+    if constexpr (NJ >= 1) {
+        APE_DS_READ(f[0][0], hi, OFF);
+        APE_DS_READ(f[0][1], lo, OFF);
+    }
+    if constexpr (NJ >= 2) {
+        APE_DS_READ(f[1][0], hi, OFF + 2048);
+        APE_DS_READ(f[1][1], lo, OFF + 2048);
+    }
+}
+#undef APE_DS_READ
+
+constexpr int BM = 256;
+constexpr int A_STAGE = BM * 128;        // bytes of the A image of one k-tile
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)      // (see APE_DS_READ: the host pass only needs the kernel's stub)
+    constexpr int TN = BN / 64;                  // 16-channel blocks per wave
+    constexpr int TNH = (TN + 1) / 2;            // ... in the larger B half
+    constexpr int TN0 = TN / 2;                  // B0 = blocks [0, TN0), B1 = [TN0, TN)
+    constexpr int NB = BN / 64;                  // B blocks (8 rows) each wave stages per k-tile
+    constexpr int B_STAGE = BN * 128;
+    constexpr int NA = 3;                        // A ring slots (pixels: 3 x 32 KB); the weights get two -- 160 KB in all for BN = 256
+    constexpr int B_BASE = NA * A_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nwg = a.m_tiles * a.n_tiles;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const int n_tile = logical % a.n_tiles;
+    const int m_tile = logical / a.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- LDS-DMA sources: buffer descriptors whose range ends at the last valid row (rows beyond read as zeros) -----------
+    const long a_bytes = ((long)(a.M - m0) * a.ldx - a.xoff) * 4;
+    const long b_bytes = (long)(a.Cout - n0) * a.K * 4;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + ((long)m0 * a.ldx + a.xoff) * 4), 0, (int)(a_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)a_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.w + (long)n0 * a.K * 4), 0, (int)(b_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)b_bytes), 0x00020000);
+    // one DMA = 8 rows x 128 B: lanes 8 r .. 8 r + 7 fetch ONE row (a whole 128-B line), its 16-B chunks permuted by the row's XOR
+    // swizzle ((row >> 1) & 7: the rows of a block are 8-aligned, so this is ((lane >> 4) & 3) | parity-free bits of the block)
+    unsigned va[4], vb[NB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        va[i] = (unsigned)(row * a.ldx * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (wave * NB + i) * 8 + (lane >> 3);
+        vb[i] = (unsigned)(row * a.K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+    auto dma_a = [&](int kt, int slot_bytes) {        // 4 pieces per wave into A ring slot `slot_bytes` / A_STAGE
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], kt * 128, 0, 0);
+    };
+    auto dma_a_piece = [&](int kt, int slot_bytes, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], kt * 128, 0, 0);
+    };
+    auto dma_b_piece = [&](int kt, int stage, int i) {
+        if (i < NB)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], kt * 128, 0, 0);
+    };
+    auto dma_b = [&](int kt, int stage) {             // NB pieces per wave
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], kt * 128, 0, 0);
+    };
+
+    // ---- fragment addresses: lane (frow, fc) reads chunk fc (hi) / 4 + fc (lo) of row frow of a 16-row block ----------------
+    const int frow = lane & 15, fc = lane >> 4;
+    // LDS image: rows of 128 B, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7).  The hi chunk fc and the lo chunk 4 + fc of a lane
+    // are 64 B apart, but on which side depends on the row: one base register per plane; the 16-row block (i | j) is at + 2048,
+    // an immediate.  B: one pair per stage (compile-time stage); A: the ring slot of the current tile ([0]) and of the next one
+    // ([1]) rotate, two v_add per k-tile.
+    const int swz = (frow >> 1) & 7;
+    const int lane_hi = frow * 128 + ((fc ^ swz) * 16), lane_lo = frow * 128 + (((4 + fc) ^ swz) * 16);
+    const unsigned a_lane[2] = {(unsigned)(wm * 16 * 1024 + lane_hi), (unsigned)(wm * 16 * 1024 + lane_lo)};
+    unsigned a_addr[2][2] = {{a_lane[0], a_lane[1]}, {a_lane[0] + A_STAGE, a_lane[1] + A_STAGE}};
+    const unsigned b_addr[2][2] = {{(unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_hi), (unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_lo)},
+                                   {(unsigned)(B_BASE + B_STAGE + wn * (TN * 2) * 1024 + lane_hi), (unsigned)(B_BASE + B_STAGE + wn * (TN * 2) * 1024 + lane_lo)}};
+    // The fragment reads are inline asm so that they stay where the schedule puts them -- at the HEAD of the phase before the one
+    // that consumes them (left to hipcc they sink to the last use of the registers they reuse, i.e. to the end of the phase, in
+    // front of the wait) -- which also makes their completion invisible to the compiler: every phase ends with lgkmcnt(0) and a
+    // sched_barrier (cdna_hip_programming.md 5.4 rule 18).
+    u32x4 A[2][4][2], B[2][TNH][2];
+    auto read_a = [&](auto which_c, auto half_c, auto set_c) {        // which: 0 = the current k-tile's ring slot, 1 = the next one's
+        constexpr int which = decltype(which_c)::value, half = decltype(half_c)::value, set = decltype(set_c)::value;
+        if (a.dbg & 8) return;
+        ds_read_frags4<half * 4 * 2048>(A[set], a_addr[which][0], a_addr[which][1]);
+    };
+    auto read_b = [&](auto stage_c, auto half_c, auto set_c) {
+        constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, set = decltype(set_c)::value;
+        constexpr int j0 = half ? TN0 : 0, nj = half ? TN - TN0 : TN0;
+        if (a.dbg & 8) return;
+        ds_read_frags<j0 * 2048, nj, TNH>(B[set], b_addr[stage][0], b_addr[stage][1]);
+    };
+    f32x4 acc[8][TN];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    // `hook(i)` runs after the MFMAs of pixel block i of the phase (pinned there): the DMA pieces of the next tiles are spread over
+    // the MFMA stream this way instead of being issued in one burst behind the barrier, where both waves of every SIMD would stall
+    // on their ~8 x 100-cycle issue at the same time
+    auto mfma = [&](auto ahalf_c, auto aset_c, auto bhalf_c, auto bset_c, auto&& hook) {
+        constexpr int ahalf = decltype(ahalf_c)::value, aset = decltype(aset_c)::value, bhalf = decltype(bhalf_c)::value, bset = decltype(bset_c)::value;
+        constexpr int j0 = bhalf ? TN0 : 0, nj = bhalf ? TN - TN0 : TN0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!(a.dbg & 4)) {
+#pragma unroll
+                for (int j = 0; j < nj; ++j) {
+                    f32x4& c = acc[ahalf * 4 + i][j0 + j];
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, B[bset][j][0]), bl = __builtin_bit_cast(bf16x8, B[bset][j][1]);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, A[aset][i][0]), al = __builtin_bit_cast(bf16x8, A[aset][i][1]);
+                    // weights as the row operand: D[channel 4 fc + e][pixel frow]; same products and k order as conv_gemm.hip
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, c, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            hook(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto no_hook = [](int) {};
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto phase_end = [&]() {        // (the sched_barrier in FRONT keeps the phase's MFMAs above the wait: they are not ordered against an asm)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // DMA schedule.  Rings: A (pixels) three slots, B (weights) two.  At the middle of k-tile t (its barrier: every wave has read
+    // all of tile t's fragments) the slots of A(t) and B(t) are free: B(t+2) and A(t+3) are issued there, in that order.  The same
+    // barrier needs tile t+1 landed: B(t+1) was issued one k-tile ago, A(t+1) two k-tiles ago, and the only younger pieces are the
+    // four of A(t+2) => vmcnt(4), never 0 in the steady state: up to 96 KB per CU are in flight across the barrier.
+    const int nk = a.nk;
+    dma_a(0, 0);
+    dma_b(0, 0);
+    if (nk > 1) { dma_a(1, A_STAGE); dma_b(1, 1); }
+    if (nk > 2) dma_a(2, 2 * A_STAGE);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NB) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(I0{}, I0{}, I0{});
+    read_b(I0{}, I0{}, I0{});
+    phase_end();
+    int slot_free = 0;             // byte offset of the A ring slot that holds the current tile (free after its barrier)
+
+    // one k-tile; X = kt & 1 = its B stage = the B register set that holds its B0
+    auto ktile = [&](int kt, auto xc) {
+        constexpr int X = decltype(xc)::value;
+        using S = std::integral_constant<int, X>;
+        using T = std::integral_constant<int, X ^ 1>;
+        // phase 0: (A0, B0) while B1 of this tile is read into the other B set
+        read_b(S{}, I1{}, T{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(I0{}, I0{}, I0{}, S{}, no_hook);
+        phase_end();
+        // phase 1: (A0, B1) while A1 of this tile is read
+        read_a(I0{}, I1{}, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(I0{}, I0{}, I1{}, T{}, no_hook);
+        phase_end();
+        // every read of tile kt is back; tile kt+1 must have landed (only A(kt+2)'s four pieces may still be in flight)
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(a.dbg & 2)) __builtin_amdgcn_s_barrier();
+        const bool more_b = kt + 2 < nk && !(a.dbg & 1), more_a = kt + 3 < nk && !(a.dbg & 1);
+        const int slot = slot_free;
+        slot_free = slot_free + A_STAGE == NA * A_STAGE ? 0 : slot_free + A_STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: (A1, B1) while A0 of the next tile is read; B(kt+2) goes out piece by piece between the MFMA rows
+        read_a(I1{}, I0{}, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(I1{}, I1{}, I1{}, T{}, [&](int i) { if (more_b) dma_b_piece(kt + 2, X, i); });
+        phase_end();
+        // phase 3: (A1, B0) while B0 of the next tile is read into the set B1 just left; A(kt+3) goes out likewise
+        read_b(T{}, I0{}, T{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(I1{}, I1{}, I0{}, S{}, [&](int i) { if (more_a) dma_a_piece(kt + 3, slot, i); });
+        // rotate the A slot addresses: next becomes current, the one after it is slot_free + A_STAGE (mod the ring)
+        {
+            const int nxt = slot_free + A_STAGE == NA * A_STAGE ? 0 : slot_free + A_STAGE;
+            a_addr[0][0] = a_addr[1][0]; a_addr[0][1] = a_addr[1][1];
+            a_addr[1][0] = a_lane[0] + (unsigned)nxt; a_addr[1][1] = a_lane[1] + (unsigned)nxt;
+        }
+        phase_end();
+    };
+    int kt = 0;
+#pragma unroll 1
+    for (; kt + 1 < nk; kt += 2) {
+        ktile(kt, I0{});
+        ktile(kt + 1, I1{});
+    }
+    if (kt < nk) ktile(kt, I0{});
+
+    // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel 16 i + frow ---------
+    const int nq = n0 + wn * (TN * 16) + fc * 4;
+    float4 b4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nq + j * 16;
+        b4[j] = (a.bias && !a.bias_bstride && n < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + frow;
+        if (m >= a.M) continue;
+        const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
+        float4 rr[TN];
+        if (a.res) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nq + j * 16;
+                if (n >= a.Cout) continue;
+                if (a.res_fmt == APE_FMT_S32) {
+                    const int cr = a.roff + n;
+                    const char* rp = a.res + (size_t)m * a.ldr * 4 + (cr >> 5) * 128 + (cr & 31) * 2;
+                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(rp), l = *reinterpret_cast<const bf16x4*>(rp + 64);
+                    rr[j] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+                } else {
+                    rr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + (size_t)m * a.ldr + a.roff + n);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nq + j * 16;
+            if (n >= a.Cout) continue;
+            float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
+            else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
+            if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = act_fn(vv[e], a.act, a.alpha);
+            if (a.out_fmt == APE_FMT_S32) {
+                const int cy = a.yoff + n;
+                char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
+                bf16x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
+                *reinterpret_cast<bf16x4*>(yp) = h;
+                *reinterpret_cast<bf16x4*>(yp + 64) = l;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+        }
+    }
+#endif
+}
+
+template <int BN>
+int launch_s32(GemmS32Args& a, hipStream_t st)
+{
+    constexpr size_t lds = 3 * (size_t)A_STAGE + 2 * (size_t)BN * 128;
+    auto kern = gemm_s32_kernel<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            return APE_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    a.m_tiles = ape::ceil_div(a.M, BM);
+    a.n_tiles = ape::ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(512), lds, st, a);
+    return ape::check_launch("ape_conv_gemm_s32");
+}
+
+bool supported_s32(const ape_conv_params& p)
+{
+    if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.ups != 0) return false;
+    if (p.B < 0 || p.H < 1 || p.W < 1 || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.Cin < 32 || p.Cin % 32 || p.ldx % 32 || p.xoff % 32 || p.xoff + p.Cin > p.ldx) return false;
+    if (p.Cout < 128 || p.Cout % 4 || p.yoff + p.Cout > p.ldy || p.ldy % 4 || p.yoff % 4) return false;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return false;
+    if ((long)p.B * p.H * p.W > (1L << 30) || 256L * p.ldx * 4 >= (1L << 31) || 256L * p.Cin * 4 >= (1L << 31)) return false;
+    return true;
+}
+
+}  // namespace
+
+/* w[cout][K] f32 (K % 32 == 0) -> S32K: [cout][K/32][hi 32 | lo 32] bf16 */
+__global__ void pack_weights_s32k_kernel(const float* __restrict__ w, __bf16* __restrict__ out, long total, int K)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / K;
+        const int k = (int)(i - n * K);
+        const float v = w[i];
+        const __bf16 h = (__bf16)v;
+        __bf16* g = out + (n * (K / 32) + k / 32) * 64;
+        g[k % 32] = h;
+        g[32 + k % 32] = (__bf16)(v - (float)h);
+    }
+}
+
+extern "C" int ape_pack_weights_s32k(const float* w, void* out, int cout, int K, void* stream)
+{
+    if (!w || !out || cout < 1 || K < 32 || K % 32) return APE_EINVAL;
+    const long total = (long)cout * K;
+    long g = (total + 255) / 256;
+    g = g > 4096 ? 4096 : g;
+    hipLaunchKernelGGL(pack_weights_s32k_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, w, (__bf16*)out, total, K);
+    return ape::check_launch("ape_pack_weights_s32k");
+}
+
+/* fp32 [rows][C] <-> S32 [rows][C] (C % 32 == 0); one thread per 4 channels */
+__global__ void f32_to_s32_kernel(const float4* __restrict__ x, char* __restrict__ y, long n4, int C)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / (C / 4);
+        const int c = (int)(i - row * (C / 4)) * 4;
+        const float4 v = x[i];
+        bf16x4 h, l;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]); l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+        char* p = y + row * C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<bf16x4*>(p) = h;
+        *reinterpret_cast<bf16x4*>(p + 64) = l;
+    }
+}
+__global__ void s32_to_f32_kernel(const char* __restrict__ x, float4* __restrict__ y, long n4, int C)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / (C / 4);
+        const int c = (int)(i - row * (C / 4)) * 4;
+        const char* p = x + row * C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(p), l = *reinterpret_cast<const bf16x4*>(p + 64);
+        y[i] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
+    }
+}
+extern "C" int ape_convert_s32(const void* x, void* y, long rows, int C, int to_s32, void* stream)
+{
+    if (!x || !y || rows < 0 || C < 32 || C % 32) return APE_EINVAL;
+    if (rows == 0) return APE_OK;
+    const long n4 = rows * (C / 4);
+    long g = (n4 + 255) / 256;
+    g = g > 65536 ? 65536 : g;
+    if (to_s32) hipLaunchKernelGGL(f32_to_s32_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (char*)y, n4, C);
+    else hipLaunchKernelGGL(s32_to_f32_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const char*)x, (float4*)y, n4, C);
+    return ape::check_launch("ape_convert_s32");
+}
+
+static int g_s32_dbg = 0;
+/* timing ablations of ape_conv_gemm_s32 (development aid; any non-zero value makes the results wrong) */
+extern "C" int ape_conv_gemm_s32_debug(int bits) { g_s32_dbg = bits; return APE_OK; }
+
+extern "C" int ape_conv_gemm_s32_supported(const ape_conv_params* params) { return params && supported_s32(*params) ? 1 : 0; }
+
+extern "C" int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
+                                 int out_fmt, const ape_conv_params* params, void* stream)
+{
+    if (!x_s32 || !w_s32k || !y || !params) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (!supported_s32(p)) return APE_EINVAL;
+    if ((out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) || (residual && res_fmt != APE_FMT_F32 && res_fmt != APE_FMT_S32)) return APE_EINVAL;
+    if (out_fmt == APE_FMT_S32 && (p.ldy % 32 || p.yoff % 4)) return APE_EINVAL;
+    if (residual && (p.roff + p.Cout > p.ldr || p.ldr % 4 || p.roff % 4 || (res_fmt == APE_FMT_S32 && p.ldr % 32))) return APE_EINVAL;
+    const long M = (long)p.B * p.H * p.W;
+    if (M == 0) return APE_OK;
+    GemmS32Args a;
+    a.x = (const char*)x_s32; a.w = (const char*)w_s32k; a.bias = bias; a.res = (const char*)residual; a.y = (char*)y;
+    a.M = (int)M; a.K = p.Cin; a.Cout = p.Cout;
+    a.ldx = p.ldx; a.xoff = p.xoff; a.ldy = p.ldy; a.yoff = p.yoff; a.ldr = p.ldr; a.roff = p.roff;
+    a.act = p.act; a.alpha = p.alpha; a.bias_bstride = p.bias_bstride; a.rows_per_image = p.H * p.W;
+    a.out_fmt = out_fmt; a.res_fmt = res_fmt;
+    a.nk = p.Cin / 32;
+    a.dbg = g_s32_dbg;
+    hipStream_t st = (hipStream_t)stream;
+    const int waste256 = ape::ceil_div(p.Cout, 256) * 256 - p.Cout;
+    const int waste192 = ape::ceil_div(p.Cout, 192) * 192 - p.Cout;
+    if (p.Cout <= 128) return launch_s32<128>(a, st);
+    if (waste192 < waste256) return launch_s32<192>(a, st);
+    return launch_s32<256>(a, st);
+}

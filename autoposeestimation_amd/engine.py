@@ -52,6 +52,46 @@ USE_GEMM_KERNEL = os.environ.get("APE_USE_GEMM_KERNEL", "1") != "0"    # route C
 GEMM_VARIANT = 0          # 0 = chosen from the shape; 1..4 force a block shape (tools/microbench_generic.py)
 
 
+FMT_F32, FMT_S32 = 0, 1
+USE_S32 = os.environ.get("APE_USE_S32", "1") != "0"    # pre-split activations between the segmentor's bf16x3 layers (conv_gemm_s32.hip)
+
+
+class S32:
+    """A pre-split activation tensor (include/ape_hip.h "S32"): per pixel and 32-channel group 128 bytes [hi 32 x bf16 | lo 32 x bf16].
+    Same bytes per channel as fp32, so it lives in a float32 torch tensor `t` of the logical shape [B,H,W,C]; only kernels that
+    declare S32 operands may read it (the element values of `t` are NOT the activations)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        if t.dtype != torch.float32 or t.shape[-1] % 32:
+            raise ValueError("S32 needs a float32 buffer with a multiple of 32 channels")
+        self.t = t
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def __getitem__(self, idx):          # batch slicing only
+        return S32(self.t[idx])
+
+    def to_f32(self):
+        y = torch.empty_like(self.t)
+        c = self.t.shape[-1]
+        _lib.check(_lib.lib().ape_convert_s32(_lib.dptr(self.t, torch.float32), _lib.dptr(y), self.t.numel() // c, c, 0, _st()), "ape_convert_s32")
+        return y
+
+    @staticmethod
+    def from_f32(x):
+        y = torch.empty_like(x)
+        c = x.shape[-1]
+        _lib.check(_lib.lib().ape_convert_s32(_lib.dptr(x, torch.float32), _lib.dptr(y), x.numel() // c, c, 1, _st()), "ape_convert_s32")
+        return S32(y)
+
+
 def pack_conv_weight(w, device):
     """[Cout,Cin,KH,KW] | [Cout,Cin,1] | [Cout,Cin]  ->  contiguous f32 [Cout,KH,KW,Cin4] on `device`."""
     w = w.detach()
@@ -89,6 +129,16 @@ class Conv:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.stride, self.pad, self.dil, self.act, self.alpha = stride, pad, dil, act, float(alpha)
 
+    def s32k(self):
+        """the weights in the S32K grouping ([Cout][K/32][hi 32 | lo 32] bf16) for the S32 consumers; built on first use"""
+        ws = getattr(self, "_ws32", None)
+        if ws is None:
+            k = self.kh * self.kw * self.cin
+            ws = torch.empty(self.cout * k * 2, dtype=torch.bfloat16, device=self.w.device)
+            _lib.check(_lib.lib().ape_pack_weights_s32k(_lib.dptr(self.w), _lib.dptr(ws), self.cout, k, _st()), "ape_pack_weights_s32k")
+            self._ws32 = ws
+        return ws
+
     def _generic_variant(self, m):
         """name of the template instantiation ape_conv2d_nhwc_* dispatches to (mirrors the C++ rule; profiling label only)"""
         if self.nsplit and self.cout >= 256 and ((-(-self.cout // 256)) * 256 - self.cout) * 8 <= self.cout and m >= 65536:
@@ -121,10 +171,15 @@ class Conv:
         wo = (w + 2 * self.pad - self.dil * (self.kw - 1) - 1) // self.stride + 1
         return ho, wo
 
-    def __call__(self, x, out=None, xoff=0, yoff=0, residual=None, roff=0, bias=None, bias_bstride=0, act=None, upsample2x=False):
+    def __call__(self, x, out=None, xoff=0, yoff=0, residual=None, roff=0, bias=None, bias_bstride=0, act=None, upsample2x=False,
+                 out_fmt=FMT_F32):
         """x[B,H,W,ldx] (reads channels xoff..xoff+cin) -> out[B,Ho,Wo,ldy] (writes yoff..yoff+cout).
         upsample2x: the conv runs on the bilinear x2 (align_corners=True) up-sampling of x, fused into the LDS-halo kernel
-        when it applies, otherwise materialised by ape_bilinear_nhwc_f32 first."""
+        when it applies, otherwise materialised by ape_bilinear_nhwc_f32 first.
+        x / residual may be `S32` (pre-split) tensors and out_fmt=FMT_S32 returns one: only on the split-bf16 kernels that
+        declare S32 operands (this never converts silently -- an unsupported combination raises)."""
+        if isinstance(x, S32) or isinstance(residual, S32) or out_fmt == FMT_S32:
+            return self._call_s32(x, out, xoff, yoff, residual, roff, bias, bias_bstride, act, out_fmt)
         if upsample2x:
             can_fuse = (self.nsplit and USE_HALO_KERNEL and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == 1
                         and self.dil == 1 and self.cin % 32 == 0 and x.shape[3] == self.cin and xoff == 0)
@@ -183,6 +238,56 @@ class Conv:
             e1.record()
             prof.records.append((label, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
         return out
+
+
+def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride, act, out_fmt):
+    if self.nsplit != 3:
+        raise ValueError("S32 operands exist only in the split-bf16 ('bf16x3') precision")
+    if not isinstance(x, S32):
+        raise ValueError("S32 output / residual needs an S32 input on this path")
+    xt = x.t
+    b, h, w, ldx = xt.shape
+    ho, wo = self.out_hw(h, w)
+    if out is None:
+        out = torch.empty(b, ho, wo, self.cout, dtype=torch.float32, device=xt.device)
+    out_t = out.t if isinstance(out, S32) else out
+    if tuple(out_t.shape[:3]) != (b, ho, wo):
+        raise ValueError("conv output buffer %s does not match %s" % (tuple(out_t.shape), (b, ho, wo)))
+    res_t, res_fmt = None, FMT_F32
+    if residual is not None:
+        res_t, res_fmt = (residual.t, FMT_S32) if isinstance(residual, S32) else (residual, FMT_F32)
+        if tuple(res_t.shape[:3]) != (b, ho, wo):
+            raise ValueError("residual shape mismatch")
+    bias = self.bias if bias is None else bias
+    p = ConvParams(B=b, H=h, W=w, Cin=self.cin, ldx=ldx, xoff=xoff, Ho=ho, Wo=wo, Cout=self.cout, ldy=out_t.shape[3], yoff=yoff,
+                   KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad, dil=self.dil, act=self.act if act is None else act,
+                   alpha=self.alpha, bias_bstride=bias_bstride, ldr=0 if res_t is None else res_t.shape[3], roff=roff, ups=0)
+    is3 = self.kh == 3
+    if is3:
+        if not _lib.lib().ape_conv3x3_halo_s32_supported(ctypes.byref(p)):
+            raise ValueError("no S32 kernel for this layer geometry (3x3, stride %d, dil %d, Cin %d, Cout %d)" % (self.stride, self.dil, self.cin, self.cout))
+        label = "halo_s32_kernel<%d>" % self.dil
+    else:
+        if not _lib.lib().ape_conv_gemm_s32_supported(ctypes.byref(p)):
+            raise ValueError("no S32 kernel for this layer geometry (%dx%d, stride %d, Cin %d, Cout %d)" % (self.kh, self.kw, self.stride, self.cin, self.cout))
+        label = "gemm_s32_kernel<%d>" % (128 if self.cout <= 128 else 192 if (-(-self.cout // 192) * 192 - self.cout) < (-(-self.cout // 256) * 256 - self.cout) else 256)
+    prof = PROFILE
+    if prof is not None and not prof.wants(label):
+        prof = None
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    fn = _lib.lib().ape_conv3x3_halo_s32 if is3 else _lib.lib().ape_conv_gemm_s32
+    rc = fn(_lib.dptr(xt, torch.float32), _lib.dptr(self.s32k()), _lib.dptr(bias), _lib.dptr(res_t), res_fmt,
+            _lib.dptr(out_t, torch.float32), out_fmt, ctypes.byref(p), _st())
+    _lib.check(rc, "ape_conv3x3_halo_s32" if is3 else "ape_conv_gemm_s32")
+    if prof is not None:
+        e1.record()
+        prof.records.append((label, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+    return S32(out_t) if out_fmt == FMT_S32 else out_t
+
+
+Conv._call_s32 = _conv_call_s32
 
 
 def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False):

@@ -88,6 +88,29 @@ int ape_conv2d_nhwc_bf16(const float* x, const void* w_packed, const float* bias
 int ape_conv_gemm_supported(const ape_conv_params* params_host);
 int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                        const ape_conv_params* params_host, int nsplit, int variant, void* stream);
+/* ---- pre-split ("S32") activations --------------------------------------------------------------------------------------
+ * The split-bf16 operands of the bf16 kernels above, made ONCE by the producing kernel's epilogue instead of by every consumer
+ * tile: a pixel's C channels (C % 32 == 0) are C/32 groups of 128 bytes [hi: 32 x bf16 | lo: 32 x bf16], hi = bf16(v),
+ * lo = bf16(v - hi) -- 4 bytes per channel, so (ld, offset) arithmetic in channels is unchanged.  Weights for S32 consumers use
+ * the same grouping along K ("S32K": [Cout][K/32][hi 32 | lo 32], ape_pack_weights_s32k from w[Cout][K] f32).
+ * ape_conv_gemm_s32: the 1x1 / stride-1 layers (pspnet.py:12-17,22-24 and the low-resolution channel mixing of :27-37) with
+ * x in S32, operands streamed HBM -> LDS by LDS-DMA (no staging registers, no split VALU), y and the residual in either format.
+ * Needs Cin % 32 == 0, ldx % 32 == 0, xoff % 32 == 0, Cout >= 128 and % 4; ape_conv_gemm_s32_supported(params) says so. */
+enum { APE_FMT_F32 = 0, APE_FMT_S32 = 1 };
+int ape_pack_weights_s32k(const float* w, void* out, int cout, int K, void* stream);
+/* x[rows][C] f32 -> y[rows][C] S32 (to_s32 = 1) or back (to_s32 = 0: hi + lo); C % 32 == 0.  Tests and format boundaries only. */
+int ape_convert_s32(const void* x, void* y, long rows, int C, int to_s32, void* stream);
+int ape_conv_gemm_s32_supported(const ape_conv_params* params_host);
+int ape_conv_gemm_s32_debug(int bits);   /* timing ablations (tools/mb_gemm_s32.py); 0 = off, anything else breaks the results */
+int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
+                      int out_fmt, const ape_conv_params* params_host, void* stream);
+/* 3x3 / stride 1 / pad == dilation in {1,2,4} convolutions with Cout >= 128 on S32 activations (extractors.py:29-43 blocks of layers
+ * 2-4): the LDS-halo kernel with the halo rows and the weight tiles streamed by LDS-DMA into rings and every fragment read
+ * prefetched one tap ahead.  Same accumulators as ape_conv3x3_halo_bf16(nsplit = 3) on the fp32 form of x; weights S32K in the
+ * (tap, channel) K order of the packed layout; y / residual in either format. */
+int ape_conv3x3_halo_s32_supported(const ape_conv_params* params_host);
+int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
+                         int out_fmt, const ape_conv_params* params_host, void* stream);
 /* The ResNet stem in one kernel: Conv2d(3 -> 64, 7x7, stride 2, pad 3) + ReLU + MaxPool2d(3, 2, 1)  (extractors.py:82-85, 111-117).
  * x[B][H][W][4] f32 (RGB + a zero channel), w[64][7][7][4] f32 (the UNPACKED ape_conv2d_nhwc_f32 layout: the kernel splits its
  * own weight fragments), bias[64] or NULL -> y[B][Hp][Wp][64] with Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1 (same for W).
