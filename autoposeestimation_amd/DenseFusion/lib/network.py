@@ -108,6 +108,7 @@ class _PSPPlan:
     def __init__(self, sd, prefix, backend, dev, precision="f32"):
         g = lambda k: sd[prefix + k]  # noqa: E731
         _Conv = lambda *a, **k: E.Conv(*a, precision=precision, **k)  # noqa: E731
+        self.precision = precision
         self.stem = _Conv(g("feats.conv1.weight"), None, 2, 3, 1, E.ACT_RELU, device=dev)
         self.blocks = []
         inplanes = 64
@@ -148,6 +149,11 @@ class _PSPPlan:
 
     def features(self, x, taps=None, stop_before_up3=False):
         """x[B,H,W,4] (RGB + zero pad) -> up_3 activation [B,H,W,64]"""
+        # the S32 graph's 3x3 kernel tiles the 1/8-resolution map in 16x16 pixels: worth it only when those tiles are mostly full
+        # (the 480x640 segmentor: 60x80 -> 94 %; a 160x160 crop: 20x20 -> 39 %, which stays on the flattened-M kernels)
+        h8, w8 = -(-x.shape[1] // 8), -(-x.shape[2] // 8)
+        if self.precision == "bf16x3" and E.USE_S32 and h8 * w8 >= 0.8 * (-(-h8 // 16) * -(-w8 // 16) * 256):
+            return self._features_s32(x, taps, stop_before_up3)
         y = E.stem_pool(self.stem, x)
         for c1, c2, down in self.blocks:
             res = y if down is None else down(y)
@@ -168,6 +174,45 @@ class _PSPPlan:
         if stop_before_up3:
             return p
         p = self.up3(p, upsample2x=True)     # bilinear x2 fused into the conv's halo load when the LDS-halo kernel applies
+        if taps is not None:
+            taps["up_3"] = p
+        return p
+
+    def _features_s32(self, x, taps, stop_before_up3):
+        """The same graph with PRE-SPLIT ("S32", include/ape_hip.h) activations between the split-bf16 layers from layer 2 on: every
+        producer writes the bf16 hi | lo pair its consumers' matrix cores take, the 3x3 and 1x1 layers stream it HBM -> LDS by
+        LDS-DMA (conv3x3_halo_s32.hip, conv_gemm_s32.hip).  The MFMA operands are bit-identical to the fp32-activation graph; residual
+        adds and the pools read hi + lo (2^-17 relative) instead of the fp32 value.  fp32 stays where a VALU kernel consumes the
+        tensor: the stem / layer 1 (64 channels: the narrow halo kernel), the 9*Cout tap tensors of up_1 / up_2, up_2's output
+        (bilinearly re-sampled inside up_3's halo load)."""
+        S = E.FMT_S32
+        y = E.stem_pool(self.stem, x)
+        for c1, c2, down in self.blocks:
+            wide = c1.cout >= 128
+            if not wide:                                  # layer 1: fp32 in and out
+                res = y if down is None else down(y)
+                y = c2(c1(y), residual=res)
+                continue
+            res = y if down is None else down(y)          # fp32 (a residual only) from either kernel
+            t = c1(y, out_fmt=S)                          # stride-2 first conv of layer 2: conv_gemm.hip with an S32 epilogue
+            y = c2(t, residual=res, out_fmt=S)
+        f = y
+        b, h, w, _ = f.shape
+        pools = E.adaptive_avgpool_multi(f, (2, 3, 6))
+        pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f.to_f32(), 1)
+        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]
+        p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w), out_fmt=S)
+        if taps is not None:
+            taps["feats"], taps["psp"] = f.to_f32(), p.to_f32()
+        p = self.up[0](p, out_fmt=S)
+        if taps is not None:
+            taps["up_1"] = p.to_f32()
+        p = self.up[1](p)
+        if taps is not None:
+            taps["up_2"] = p
+        if stop_before_up3:
+            return p
+        p = self.up3(p, upsample2x=True)
         if taps is not None:
             taps["up_3"] = p
         return p

@@ -17,6 +17,7 @@
 // Loads are unconditional (coordinates clamped into the tensor); out-of-image taps are zeroed when the registers are
 // written to LDS, rows >= M and columns >= Cout are computed on clamped data and dropped by the epilogue.
 #include "common.h"
+#include "s32.h"
 
 namespace {
 
@@ -32,6 +33,7 @@ struct GemmArgs {
     float* y;
     ape_conv_params p;
     int M, Kp, m_tiles, n_tiles, nk;
+    int out_fmt;       // APE_FMT_F32 | APE_FMT_S32 (pre-split output for the S32 consumers; needs ldy % 32 == 0 and the vector path)
     int dbg;           // ablation bits (timing experiments only, results are wrong): 1 no in-loop global loads, 2 no in-loop LDS restage, 4 no MFMAs
     long plane_stride;
 };
@@ -306,9 +308,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                     if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
                     else if (a.bias) { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
                     if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
-                    *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) =
-                        make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha), activate(vv[2], p.act, p.alpha),
-                                    activate(vv[3], p.act, p.alpha));
+                    const float4 o4 = make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha), activate(vv[2], p.act, p.alpha),
+                                                  activate(vv[3], p.act, p.alpha));
+                    if (a.out_fmt == APE_FMT_S32) ape::s32_store4(a.y, (long)m, p.ldy / 4, (p.yoff + n) / 4, o4);
+                    else *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o4;
                 } else {
                     for (int k = 0; k < nvalid; ++k) {
                         float t = vv[k];
@@ -358,6 +361,17 @@ extern "C" int ape_conv_gemm_supported(const ape_conv_params* params) { return p
 extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
                                   const ape_conv_params* params, int nsplit, int variant, void* stream)
 {
+    return ape_conv_gemm_bf16_fmt(x, w_packed, bias, residual, y, APE_FMT_F32, params, nsplit, variant, stream);
+}
+
+/* the same with the OUTPUT in either activation format (APE_FMT_S32: ldy % 32 == 0, Cout % 4 == 0, yoff % 4 == 0) */
+extern "C" int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, const float* bias, const float* residual, void* y_, int out_fmt,
+                                      const ape_conv_params* params, int nsplit, int variant, void* stream)
+{
+    float* y = (float*)y_;
+    if (out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) return APE_EINVAL;
+    if (out_fmt == APE_FMT_S32 && params && (params->ldy % 32 || params->Cout % 4 || params->yoff % 4 || (residual && (params->ldr % 4 || params->roff % 4))))
+        return APE_EINVAL;
     if (!x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3) || variant < 0 || (variant & 15) > 6) return APE_EINVAL;
     const ape_conv_params& p = *params;
     if (!supported(p)) return APE_EINVAL;
@@ -372,6 +386,7 @@ extern "C" int ape_conv_gemm_bf16(const float* x, const void* w_packed, const fl
     a.nk = K / BK;
     a.plane_stride = (long)p.Cout * a.Kp;
     a.dbg = variant >> 4;
+    a.out_fmt = out_fmt;
     variant &= 15;
     const bool pure = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
     hipStream_t st = (hipStream_t)stream;

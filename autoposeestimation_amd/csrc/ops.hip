@@ -10,6 +10,7 @@
 // Each is one pass over its input (algorithmic bytes = bytes read + bytes written once); grids are sized to
 // >= 2048 workgroups-worth of work and grid-stride the rest.
 #include "common.h"
+#include "s32.h"
 
 namespace {
 
@@ -88,6 +89,7 @@ struct PoolPlan {
 
 // grid (B * ny, C4 / 64): one atom ROW per workgroup; the 4 waves split its pixel rows, a lane owns one float4 of channels and
 // keeps one accumulator per atom column
+template <bool S32IN>
 __global__ __launch_bounds__(256) void avgpool_atoms_kernel(const float4* __restrict__ x, float4* __restrict__ atoms, const PoolPlan pl,
                                                             int H, int W, int C4)
 {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void avgpool_atoms_kernel(const float4* __rest
             for (int a = 0; a < kPoolMaxAtoms; ++a) {
                 if (a >= pl.nx) break;
                 for (int xx = pl.xe[a]; xx < pl.xe[a + 1]; ++xx) {
-                    const float4 v = row[(long)xx * C4];
+                    const float4 v = S32IN ? ape::s32_load4(x, (long)(b * H + y) * W + xx, C4, c) : row[(long)xx * C4];
                     acc[a].x += v.x; acc[a].y += v.y; acc[a].z += v.z; acc[a].w += v.w;
                 }
             }
@@ -354,6 +356,7 @@ __global__ void head_select_kernel(const float* __restrict__ h, int ldh, int off
 // and the upsampled 2h x 2w x Cin tensor is never written.
 constexpr int kUpCols = 12;     // low-resolution columns under 16 + 2 output columns at scale ~1/2 (at most 11)
 
+template <bool S32OUT>
 __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __restrict__ z, const float* __restrict__ bias,
                                                             float4* __restrict__ out, int B, int h, int w, int C4, float sh, float sw,
                                                             int act, float alpha)
@@ -462,7 +465,8 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
             acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;
             acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
         }
-        out[((long)(b * Ho + Y) * Wo + X) * C4 + c] = acc;
+        if (S32OUT) ape::s32_store4(out, (long)(b * Ho + Y) * Wo + X, C4, c, acc);
+        else out[((long)(b * Ho + Y) * Wo + X) * C4 + c] = acc;
     }
 }
 
@@ -590,6 +594,14 @@ extern "C" size_t ape_adaptive_avgpool_multi_workspace_bytes(int B, int C)
 extern "C" int ape_adaptive_avgpool_multi_nhwc_f32(const float* x, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H,
                                                    int W, int C, void* workspace, size_t workspace_bytes, void* stream)
 {
+    return ape_adaptive_avgpool_multi_nhwc_fmt(x, APE_FMT_F32, ys_host, sizes_host, nsizes, B, H, W, C, workspace, workspace_bytes, stream);
+}
+
+/* the same with x in either activation format (APE_FMT_S32: C % 32 == 0); the pooled outputs are fp32 */
+extern "C" int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H,
+                                                   int W, int C, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if ((in_fmt != APE_FMT_F32 && in_fmt != APE_FMT_S32) || (in_fmt == APE_FMT_S32 && C % 32)) return APE_EINVAL;
     if (!x || !ys_host || !sizes_host || !workspace || nsizes < 1 || nsizes > kPoolMaxSizes || B < 0 || H < 1 || W < 1 || C < 4 || C % 4)
         return APE_EINVAL;
     if (B == 0) return APE_OK;
@@ -608,8 +620,12 @@ extern "C" int ape_adaptive_avgpool_multi_nhwc_f32(const float* x, float* const*
     if (pl.ny < 0 || pl.nx < 0) return APE_EINVAL;
     if (workspace_bytes < (size_t)B * pl.ny * pl.nx * C * sizeof(float)) return APE_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(avgpool_atoms_kernel, dim3(B * pl.ny, ape::ceil_div(C / 4, 64)), dim3(256), 0, st, (const float4*)x,
-                       (float4*)workspace, pl, H, W, C / 4);
+    if (in_fmt == APE_FMT_S32)
+        hipLaunchKernelGGL(avgpool_atoms_kernel<true>, dim3(B * pl.ny, ape::ceil_div(C / 4, 64)), dim3(256), 0, st, (const float4*)x,
+                           (float4*)workspace, pl, H, W, C / 4);
+    else
+        hipLaunchKernelGGL(avgpool_atoms_kernel<false>, dim3(B * pl.ny, ape::ceil_div(C / 4, 64)), dim3(256), 0, st, (const float4*)x,
+                           (float4*)workspace, pl, H, W, C / 4);
     const long total = (long)B * bins_total * (C / 4);
     hipLaunchKernelGGL(avgpool_bins_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, (const float4*)workspace, pl, B, H, W, C / 4,
                        bins_total);
@@ -702,6 +718,14 @@ extern "C" int ape_head_select_f32(const float* h, int ldh, int off_r, int off_t
 extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float* out, int B, int h, int w, int C, int act, float alpha,
                                         void* stream)
 {
+    return ape_upconv3x3_gather_fmt(z, bias, out, APE_FMT_F32, B, h, w, C, act, alpha, stream);
+}
+
+/* the same with the OUTPUT in either activation format (APE_FMT_S32: C % 32 == 0) */
+extern "C" int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act,
+                                        float alpha, void* stream)
+{
+    if ((out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) || (out_fmt == APE_FMT_S32 && C % 32)) return APE_EINVAL;
     if (!z || !out || B < 0 || h < 1 || w < 1 || C < 4 || C % 4 || act < APE_ACT_NONE || act > APE_ACT_PRELU) return APE_EINVAL;
     const long total = (long)B * 4 * h * w * (C / 4);
     if (total == 0) return APE_OK;
@@ -711,8 +735,12 @@ extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float
     if (g >= (1L << 31)) return APE_EINVAL;
     const size_t lds = (size_t)3 * kUpCols * (C / 4) * sizeof(float4);
     if (lds > 64 * 1024) return APE_EINVAL;             // C <= 1364
-    hipLaunchKernelGGL(upconv_gather_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
-                       h, w, C / 4, sh, sw, act, alpha);
+    if (out_fmt == APE_FMT_S32)
+        hipLaunchKernelGGL(upconv_gather_kernel<true>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
+                           h, w, C / 4, sh, sw, act, alpha);
+    else
+        hipLaunchKernelGGL(upconv_gather_kernel<false>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
+                           h, w, C / 4, sh, sw, act, alpha);
     return ape::check_launch("ape_upconv3x3_gather_f32");
 }
 

@@ -178,8 +178,10 @@ class Conv:
         when it applies, otherwise materialised by ape_bilinear_nhwc_f32 first.
         x / residual may be `S32` (pre-split) tensors and out_fmt=FMT_S32 returns one: only on the split-bf16 kernels that
         declare S32 operands (this never converts silently -- an unsupported combination raises)."""
-        if isinstance(x, S32) or isinstance(residual, S32) or out_fmt == FMT_S32:
+        if isinstance(x, S32) or isinstance(residual, S32):
             return self._call_s32(x, out, xoff, yoff, residual, roff, bias, bias_bstride, act, out_fmt)
+        if out_fmt == FMT_S32 and isinstance(out, S32):
+            out = out.t
         if upsample2x:
             can_fuse = (self.nsplit and USE_HALO_KERNEL and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == 1
                         and self.dil == 1 and self.cin % 32 == 0 and x.shape[3] == self.cin and xoff == 0)
@@ -206,6 +208,8 @@ class Conv:
         halo = (self.nsplit and USE_HALO_KERNEL and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256))
                 and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
         gemm = bool(not halo and self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)))
+        if out_fmt == FMT_S32 and not gemm:
+            raise ValueError("an S32 output from an fp32 input exists only on the conv_gemm kernel (Cin % 32 == 0, not a halo layer)")
         prof = PROFILE
         if prof is not None:
             label = ("conv3x3_halo_kernel<%d,%d,%d,%s,false>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
@@ -221,10 +225,10 @@ class Conv:
                                                   self.nsplit, _st())
             _lib.check(rc, "ape_conv3x3_halo_bf16")
         elif gemm:
-            rc = _lib.lib().ape_conv_gemm_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
-                                               _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
-                                               self.nsplit, GEMM_VARIANT, _st())
-            _lib.check(rc, "ape_conv_gemm_bf16")
+            rc = _lib.lib().ape_conv_gemm_bf16_fmt(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
+                                                   _lib.dptr(residual), _lib.dptr(out, torch.float32), out_fmt, ctypes.byref(p),
+                                                   self.nsplit, GEMM_VARIANT, _st())
+            _lib.check(rc, "ape_conv_gemm_bf16_fmt")
         elif self.nsplit:
             rc = _lib.lib().ape_conv2d_nhwc_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                  _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
@@ -237,7 +241,7 @@ class Conv:
         if prof is not None:
             e1.record()
             prof.records.append((label, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
-        return out
+        return S32(out) if out_fmt == FMT_S32 else out
 
 
 def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride, act, out_fmt):
@@ -361,17 +365,20 @@ def adaptive_avgpool(x, s):
 def adaptive_avgpool_multi(x, sizes):
     """{s: AdaptiveAvgPool2d((s, s))(x)} for several sizes in one pass over x[B,H,W,C]; per-size launches when the bin edges of
     the sizes cut an axis into more than 12 atoms."""
-    b, h, w, c = x.shape
+    fmt = FMT_S32 if isinstance(x, S32) else FMT_F32
+    xt = x.t if fmt == FMT_S32 else x
+    b, h, w, c = xt.shape
     sizes = list(sizes)
-    ys = [torch.empty(b, s, s, c, dtype=torch.float32, device=x.device) for s in sizes]
-    ws = _workspace(_lib.lib().ape_adaptive_avgpool_multi_workspace_bytes(b, c), x.device)
+    ys = [torch.empty(b, s, s, c, dtype=torch.float32, device=xt.device) for s in sizes]
+    ws = _workspace(_lib.lib().ape_adaptive_avgpool_multi_workspace_bytes(b, c), xt.device)
     ptrs = (ctypes.c_void_p * len(sizes))(*[y.data_ptr() for y in ys])
     szs = (ctypes.c_int * len(sizes))(*sizes)
-    rc = _lib.lib().ape_adaptive_avgpool_multi_nhwc_f32(_lib.dptr(x, torch.float32), ptrs, szs, len(sizes), b, h, w, c, _lib.dptr(ws),
+    rc = _lib.lib().ape_adaptive_avgpool_multi_nhwc_fmt(_lib.dptr(xt, torch.float32), fmt, ptrs, szs, len(sizes), b, h, w, c, _lib.dptr(ws),
                                                         ws.numel() * ws.element_size(), _st())
     if rc == -1:      # APE_EINVAL: too many atoms for this geometry
-        return {s: adaptive_avgpool(x, s) for s in sizes}
-    _lib.check(rc, "ape_adaptive_avgpool_multi_nhwc_f32")
+        xf = x.to_f32() if fmt == FMT_S32 else x
+        return {s: adaptive_avgpool(xf, s) for s in sizes}
+    _lib.check(rc, "ape_adaptive_avgpool_multi_nhwc_fmt")
     return dict(zip(sizes, ys))
 
 
@@ -407,14 +414,15 @@ class UpConv:
         self.bias = bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.alpha, self.cout = float(alpha), cout
 
-    def __call__(self, x):
+    def __call__(self, x, out_fmt=FMT_F32):
+        """x fp32 or S32 -> [B,2h,2w,Cout] in `out_fmt` (the 9*Cout-channel intermediate z stays fp32: the gather is VALU work)"""
         b, h, w, _ = x.shape
         z = self.mix(x)
-        out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=x.device)
-        rc = _lib.lib().ape_upconv3x3_gather_f32(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), b, h, w,
+        out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=z.device)
+        rc = _lib.lib().ape_upconv3x3_gather_fmt(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), out_fmt, b, h, w,
                                                  self.cout, ACT_PRELU, self.alpha, _st())
-        _lib.check(rc, "ape_upconv3x3_gather_f32")
-        return out
+        _lib.check(rc, "ape_upconv3x3_gather_fmt")
+        return S32(out) if out_fmt == FMT_S32 else out
 
 
 def gather_rows(x, index):

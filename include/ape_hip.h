@@ -104,6 +104,16 @@ int ape_conv_gemm_s32_supported(const ape_conv_params* params_host);
 int ape_conv_gemm_s32_debug(int bits);   /* timing ablations (tools/mb_gemm_s32.py); 0 = off, anything else breaks the results */
 int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
                       int out_fmt, const ape_conv_params* params_host, void* stream);
+/* Format-aware forms of three fp32 entry points, for the tensors that cross between fp32 and S32 kernels: ape_conv_gemm_bf16 with the
+ * OUTPUT in either format (the stride-2 convs that feed the first S32 3x3 layer), ape_adaptive_avgpool_multi_nhwc_f32 with the INPUT
+ * in either format (the PSP pools of the S32 layer-4 map), ape_upconv3x3_gather_f32 with the OUTPUT in either format (up_1's result
+ * feeds up_2's S32 channel mixing).  Declared further down next to their fp32 forms' documentation. */
+int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, const float* bias, const float* residual, void* y, int out_fmt,
+                           const ape_conv_params* params_host, int nsplit, int variant, void* stream);
+int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H, int W,
+                                        int C, void* workspace, size_t workspace_bytes, void* stream);
+int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act, float alpha,
+                             void* stream);
 /* 3x3 / stride 1 / pad == dilation in {1,2,4} convolutions with Cout >= 128 on S32 activations (extractors.py:29-43 blocks of layers
  * 2-4): the LDS-halo kernel with the halo rows and the weight tiles streamed by LDS-DMA into rings and every fragment read
  * prefetched one tap ahead.  Same accumulators as ape_conv3x3_halo_bf16(nsplit = 3) on the fp32 form of x; weights S32K in the
