@@ -10,7 +10,7 @@
 //       wavefronts to fill 256 CUs even for 1000 queries); lane s scans refs s, s+S, ... in ascending
 //       order with a strict '<', then the S partial minima are merged by wave shuffles with the
 //       (distance, index) lexicographic rule -> exactly "lowest index wins ties" (knn_cpu.cpp:30).
-//   knn_general  (any dim, k <= 64): one query per lane, stable insertion into a k-entry list.
+//   knn_general  (any dim, any k <= ref_nb): one query per lane, stable insertion into a 64-entry list, ceil(k / 64) passes.
 //
 // Bit-exactness: d = ((dx*dx) + (dy*dy)) + (dz*dz) with __fmul_rn/__fadd_rn (no FMA contraction), the
 // same roundings as the reference's scalar x86 build (`dist = 0; dist += diff*diff` per dimension).
@@ -79,27 +79,39 @@ __global__ __launch_bounds__(kBlock) void knn_general(const float* __restrict__ 
     const int q = blockIdx.x * kBlock + threadIdx.x;
     if (q >= query_nb) return;
 
+    // k <= 64 neighbours are kept in one sorted register list.  Larger k (the reference takes any k <= ref_nb, knn_cpu.cpp:18-44) runs
+    // ceil(k / 64) passes over the refs: pass p keeps the 64 smallest (distance, index) pairs that come AFTER the last pair the
+    // previous pass emitted -- the same ascending (distance, then ref index) order as the reference's stable bubble sort.
     float bd[kMaxK];
     int bi[kMaxK];
-    int filled = 0;
-    for (int r = 0; r < ref_nb; ++r) {
-        float d = 0.f;
-        for (int h = 0; h < dim; ++h) {
-            const float diff = ref[(size_t)h * ref_nb + r] - query[(size_t)h * query_nb + q];
-            d = __fadd_rn(d, __fmul_rn(diff, diff));
+    float thr_d = -1.f;           // squared distances are >= 0: nothing is excluded in the first pass
+    int thr_r = -1;
+    for (int done = 0; done < k;) {
+        const int want = k - done < kMaxK ? k - done : kMaxK;
+        int filled = 0;
+        for (int r = 0; r < ref_nb; ++r) {
+            float d = 0.f;
+            for (int h = 0; h < dim; ++h) {
+                const float diff = ref[(size_t)h * ref_nb + r] - query[(size_t)h * query_nb + q];
+                d = __fadd_rn(d, __fmul_rn(diff, diff));
+            }
+            if (!(d > thr_d || (d == thr_d && r > thr_r))) continue;       // emitted by an earlier pass
+            // stable insertion: new entry goes after every entry with distance <= d
+            if (filled < want) {
+                int j = filled++;
+                while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+                bd[j] = d; bi[j] = r;
+            } else if (bd[want - 1] > d) {
+                int j = want - 1;
+                while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+                bd[j] = d; bi[j] = r;
+            }
         }
-        // stable insertion: new entry goes after every entry with distance <= d
-        if (filled < k) {
-            int j = filled++;
-            while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
-            bd[j] = d; bi[j] = r;
-        } else if (bd[k - 1] > d) {
-            int j = k - 1;
-            while (j > 0 && bd[j - 1] > d) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
-            bd[j] = d; bi[j] = r;
-        }
+        for (int i = 0; i < want; ++i) idx[(size_t)(done + i) * query_nb + q] = (int64_t)bi[i] + 1;
+        thr_d = bd[want - 1];
+        thr_r = bi[want - 1];
+        done += want;
     }
-    for (int i = 0; i < k; ++i) idx[(size_t)i * query_nb + q] = (int64_t)bi[i] + 1;
 }
 
 template <int S>
@@ -131,7 +143,6 @@ extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
             default: launch_knn1<64>(ref, query, idx, batch, ref_nb, query_nb, st); break;
         }
     } else {
-        if (k > kMaxK) return APE_EINVAL;
         dim3 grid(ape::ceil_div(query_nb, kBlock), batch);
         hipLaunchKernelGGL(knn_general, grid, dim3(kBlock), 0, st, ref, query, idx, dim, ref_nb, query_nb, k);
     }

@@ -81,6 +81,19 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
 #pragma unroll
     for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? __expf(acc[r] - m) : 0.f; s += e[r]; }
     s = quad_sum(s, lane);
+    // The reference's arg-max runs over the PROBABILITIES (pipeline/utils.py:430-435): a class whose logit lies so close below the
+    // maximum that exp(l - m) rounds to 1 has the same float32 probability and torch.argmax returns the LOWER index -- take the
+    // lowest class with e == 1 (the maximum itself always qualifies)
+    {
+        int tmin = am;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (e[r] == 1.f && kq * 4 + r < tmin) tmin = kq * 4 + r;
+        const int o16 = (int)lane_xor16_u((unsigned)tmin, lane);
+        tmin = o16 < tmin ? o16 : tmin;
+        const int o32 = (int)lane_xor32_u((unsigned)tmin, lane);
+        am = o32 < tmin ? o32 : tmin;
+    }
     float pm = 1.f / s;
     if (double_softmax) {
         const float inv = pm;

@@ -39,8 +39,14 @@ __global__ void seg_argmax_kernel(const float* __restrict__ logits, int ld, int 
         int am = 0;
         for (int c = 1; c < C; ++c)
             if (l[c] > m) { m = l[c]; am = c; }  // first maximum, like torch.argmax on the CPU
+        // The reference takes the arg-max of the PROBABILITIES (pipeline/utils.py:430-435): a class whose logit is so close below the
+        // maximum that exp(l - m) rounds to 1 has the same float32 probability, and torch.argmax then returns the LOWER index.
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+        for (int c = 0; c < C; ++c) {
+            const float e = expf(l[c] - m);
+            if (e == 1.f && c < am) am = c;
+            s += e;
+        }
         float pm = 1.f / s;  // softmax(logits)[am]  (activation='softmax' inside predict, create_labels.py:23)
         if (double_softmax) {
             // F.softmax applied again on the probabilities (pipeline/utils.py:430): the maximum is p1[am]

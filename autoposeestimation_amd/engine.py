@@ -19,25 +19,60 @@ def _st():
 
 
 class LaunchProfile:
-    """Optional per-launch HIP-event timing of the conv kernels on torch's current stream (bench.py's roofline leg).
-    Events are recorded on the very stream the kernel is enqueued on; durations are read after the final sync."""
+    """Optional per-launch HIP-event timing of the heavy kernels on torch's current stream (bench.py's roofline leg).
+    Events are recorded on the very stream the kernel is enqueued on; durations are read after the final sync.
+    A record = (kernel label as rocprofv3 spells it, shape string, algorithmic flop, algorithmic bytes, start, end): the flop are
+    2 * M * Cout * KH * KW * Cin of the convolution the launch evaluates, the bytes its activations in + weights + residual +
+    output, each counted once (what a perfect kernel would move)."""
 
     def __init__(self, only=None):
-        self.records = []       # (kernel variant, algorithmic flop, start event, end event)
-        self.only = only        # None: time every conv launch; else a set of variant labels (the others run un-timed, without
+        self.records = []
+        self.only = only        # None: time every profiled launch; else a set of labels (the others run un-timed, without
                                 # the two event packets per launch that cost ~4 us of dispatch gap each)
 
     def wants(self, label):
         return self.only is None or label in self.only
 
-    def summary(self):
+    def begin(self, label):
+        """-> a start event, or None when this label is not being timed"""
+        if not self.wants(label):
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def end(self, e0, label, shape, flop, nbytes):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((label, shape, float(flop), float(nbytes), e0, e1))
+
+    def summary(self, by_shape=False):
         out = {}
-        for name, flop, e0, e1 in self.records:
-            d = out.setdefault(name, {"launches": 0, "flop": 0.0, "ms": 0.0})
+        for name, shape, flop, nbytes, e0, e1 in self.records:
+            key = (name, shape) if by_shape else name
+            d = out.setdefault(key, {"launches": 0, "flop": 0.0, "bytes": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flop"] += flop
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
         return out
+
+
+def _prof_begin(label):
+    prof = PROFILE
+    return None if prof is None else prof.begin(label)
+
+
+def _prof_end(e0, label, shape, flop, nbytes):
+    if e0 is not None and PROFILE is not None:
+        PROFILE.end(e0, label, shape, flop, nbytes)
+
+
+def _conv_cost(conv, b, h_in, w_in, ho, wo, residual):
+    """(algorithmic flop, algorithmic bytes) of one conv launch: see LaunchProfile"""
+    flop = 2.0 * b * ho * wo * conv.cout * conv.kh * conv.kw * conv.cin_real
+    nbytes = 4.0 * (b * h_in * w_in * conv.cin_real + conv.cout * conv.kh * conv.kw * conv.cin_real + b * ho * wo * conv.cout * (2 if residual else 1))
+    return flop, nbytes
 
 
 PROFILE = None   # set to a LaunchProfile() to time conv launches
@@ -210,15 +245,11 @@ class Conv:
         gemm = bool(not halo and self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)))
         if out_fmt == FMT_S32 and not gemm:
             raise ValueError("an S32 output from an fp32 input exists only on the conv_gemm kernel (Cin % 32 == 0, not a halo layer)")
-        prof = PROFILE
-        if prof is not None:
+        e0 = None
+        if PROFILE is not None:
             label = ("conv3x3_halo_kernel<%d,%d,%d,%s,false>" % (self.nsplit, self.dil, 64 if self.cout <= 64 else 128, "true" if upsample2x else "false")
                      if halo else self._gemm_variant(b * ho * wo) if gemm else self._generic_variant(b * ho * wo))
-            if not prof.wants(label):
-                prof = None
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0 = _prof_begin(label)
         if halo:
             rc = _lib.lib().ape_conv3x3_halo_bf16(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                   _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
@@ -238,9 +269,10 @@ class Conv:
             rc = _lib.lib().ape_conv2d_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(self.w), _lib.dptr(bias),
                                                 _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p), _st())
             _lib.check(rc, "ape_conv2d_nhwc_f32")
-        if prof is not None:
-            e1.record()
-            prof.records.append((label, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+        if e0 is not None:
+            hin, win = (h // 2, w // 2) if upsample2x else (h, w)
+            _prof_end(e0, label, "%dx%dx%d %d->%d k%d s%d d%d%s" % (b, ho, wo, self.cin_real, self.cout, self.kh, self.stride, self.dil, " ups" if upsample2x else ""),
+                      *_conv_cost(self, b, hin, win, ho, wo, residual is not None))
         return S32(out) if out_fmt == FMT_S32 else out
 
 
@@ -275,19 +307,14 @@ def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride,
         if not _lib.lib().ape_conv_gemm_s32_supported(ctypes.byref(p)):
             raise ValueError("no S32 kernel for this layer geometry (%dx%d, stride %d, Cin %d, Cout %d)" % (self.kh, self.kw, self.stride, self.cin, self.cout))
         label = "gemm_s32_kernel<%d>" % (128 if self.cout <= 128 else 192 if (-(-self.cout // 192) * 192 - self.cout) < (-(-self.cout // 256) * 256 - self.cout) else 256)
-    prof = PROFILE
-    if prof is not None and not prof.wants(label):
-        prof = None
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _prof_begin(label)
     fn = _lib.lib().ape_conv3x3_halo_s32 if is3 else _lib.lib().ape_conv_gemm_s32
     rc = fn(_lib.dptr(xt, torch.float32), _lib.dptr(self.s32k()), _lib.dptr(bias), _lib.dptr(res_t), res_fmt,
             _lib.dptr(out_t, torch.float32), out_fmt, ctypes.byref(p), _st())
     _lib.check(rc, "ape_conv3x3_halo_s32" if is3 else "ape_conv_gemm_s32")
-    if prof is not None:
-        e1.record()
-        prof.records.append((label, 2.0 * b * ho * wo * self.cout * self.kh * self.kw * self.cin_real, e0, e1))
+    if e0 is not None:
+        _prof_end(e0, label, "%dx%dx%d %d->%d k%d s%d d%d" % (b, ho, wo, self.cin_real, self.cout, self.kh, self.stride, self.dil),
+                  *_conv_cost(self, b, h, w, ho, wo, residual is not None))
     return S32(out_t) if out_fmt == FMT_S32 else out_t
 
 
@@ -310,20 +337,18 @@ def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False
                    stride=1, pad=1, dil=1, act=conv.act, alpha=conv.alpha, bias_bstride=0, ldr=0, roff=0, ups=int(bool(upsample2x)))
     label = torch.empty(b, h, w, dtype=torch.uint8, device=x.device)
     score = torch.empty(b, h, w, dtype=torch.float32, device=x.device)
-    prof = PROFILE
     hlabel = "conv3x3_halo_kernel<%d,1,64,%s,true>" % (conv.nsplit, "true" if upsample2x else "false")
-    if prof is not None and not prof.wants(hlabel):
-        prof = None
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    e0 = _prof_begin(hlabel)
     rc = _lib.lib().ape_conv3x3_halo_seghead_bf16(_lib.dptr(x, torch.float32), _lib.dptr(conv.wp), _lib.dptr(conv.bias), ctypes.byref(p),
                                                   conv.nsplit, _lib.dptr(head_w, torch.float32), _lib.dptr(head_b), c, _lib.dptr(label),
                                                   _lib.dptr(score), int(bool(double_softmax)), _st())
     _lib.check(rc, "ape_conv3x3_halo_seghead_bf16")
-    if prof is not None:
-        e1.record()
-        prof.records.append((hlabel, 2.0 * b * h * w * conv.cout * 9 * conv.cin_real, e0, e1))
+    if e0 is not None:
+        hin, win = (h // 2, w // 2) if upsample2x else (h, w)
+        # the 64-channel activation is never written: out = label (1 B) + score (4 B) per pixel
+        _prof_end(e0, hlabel, "%dx%dx%d %d->%d k3 s1 d1%s +head" % (b, h, w, conv.cin_real, conv.cout, " ups" if upsample2x else ""),
+                  2.0 * b * h * w * conv.cout * 9 * conv.cin_real,
+                  4.0 * (b * hin * win * conv.cin_real + conv.cout * 9 * conv.cin_real) + 5.0 * b * h * w)
     return label, score
 
 
@@ -419,9 +444,13 @@ class UpConv:
         b, h, w, _ = x.shape
         z = self.mix(x)
         out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=z.device)
+        glabel = "upconv_gather_kernel<%s>" % ("true" if out_fmt == FMT_S32 else "false")
+        e0 = _prof_begin(glabel)
         rc = _lib.lib().ape_upconv3x3_gather_fmt(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), out_fmt, b, h, w,
                                                  self.cout, ACT_PRELU, self.alpha, _st())
         _lib.check(rc, "ape_upconv3x3_gather_fmt")
+        if e0 is not None:      # HBM-bound: z read once (9 * Cout channels at low resolution) + the output written once
+            _prof_end(e0, glabel, "%dx%dx%d C%d" % (b, 2 * h, 2 * w, self.cout), 0.0, 4.0 * (b * h * w * 9 * self.cout + b * 4 * h * w * self.cout))
         return S32(out) if out_fmt == FMT_S32 else out
 
 

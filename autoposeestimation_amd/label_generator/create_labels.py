@@ -18,9 +18,17 @@ def get_default_model(root, ds_name, n_classes, name="PsPNet", encoder_name="res
                            "classes": n_classes}
     model = get_model(name, segmentation_config)
     if load:
-        cp = torch.load(os.path.join(root, "segmentation", "trained_models", ds_name,
-                                     "{}_{}.ckpt".format(name, segmentation_config["encoder_name"])),
-                        map_location=torch.device("cpu"))
+        ckpt_dir = os.path.join(root, "segmentation", "trained_models", ds_name)
+        path = os.path.join(ckpt_dir, "{}_{}.ckpt".format(name, segmentation_config["encoder_name"]))
+        if not os.path.exists(path):
+            smp_ckpt = os.path.join(ckpt_dir, "Unet_{}.ckpt".format(segmentation_config["encoder_name"]))
+            hint = ""
+            if os.path.exists(smp_ckpt):
+                hint = (" -- {} is the reference's segmentation_models_pytorch Unet checkpoint (create_labels.py:20-35): its state-dict "
+                        "layout belongs to a third-party model that is not part of the reference tree and cannot be loaded here; train the "
+                        "in-repo 'PsPNet' segmentor and save it as {}".format(smp_ckpt, os.path.basename(path)))
+            raise FileNotFoundError("segmentor checkpoint {} not found{}".format(path, hint))
+        cp = torch.load(path, map_location=torch.device("cpu"))
         model.load_state_dict(cp["state_dict"])
     return model
 

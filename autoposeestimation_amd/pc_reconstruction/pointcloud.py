@@ -371,39 +371,114 @@ def surface_points(label, depth, intr, robot2cam, device="cuda"):
     return out
 
 
-# ---- o3d.io stand-ins: ASCII .ply / .pcd with xyz only (what the label path writes and reads back) ------------------
-def write_point_cloud(path, pcd):
-    pts = np.array(pcd.points, dtype=np.float64).reshape(-1, 3)
+# ---- o3d.io stand-ins: .ply / .pcd point clouds, xyz only -----------------------------------------------------------------------
+# The reference writes its clouds with o3d.io.write_point_cloud's defaults (create_pointcloud.py:324-344: write_ascii=False,
+# compressed=False), i.e. `format binary_little_endian 1.0` PLY with double x/y/z (+ optional normals / colours) and `DATA binary`
+# PCD; both, their ASCII forms and extra per-vertex properties are read here, and the writer produces open3d's default layout.
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+_PCD_TYPES = {("F", 4): "f4", ("F", 8): "f8", ("I", 1): "i1", ("I", 2): "i2", ("I", 4): "i4", ("I", 8): "i8",
+              ("U", 1): "u1", ("U", 2): "u2", ("U", 4): "u4", ("U", 8): "u8"}
+
+
+def write_point_cloud(path, pcd, write_ascii=False, compressed=False):
+    if compressed:
+        raise NotImplementedError("compressed point-cloud files are not written")
+    pts = np.ascontiguousarray(np.array(pcd.points, dtype=np.float64).reshape(-1, 3))
     ext = os.path.splitext(path)[1].lower()
-    with open(path, "w") as f:
-        if ext == ".ply":
-            f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\nend_header\n" % len(pts))
-        elif ext == ".pcd":
-            f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\n"
-                    "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA ascii\n" % (len(pts), len(pts)))
+    if ext == ".ply":
+        head = ("ply\nformat %s 1.0\ncomment Created by autoposeestimation_amd\nelement vertex %d\nproperty double x\nproperty double y\n"
+                "property double z\nend_header\n" % ("ascii" if write_ascii else "binary_little_endian", len(pts)))
+    elif ext == ".pcd":
+        head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z\nSIZE 8 8 8\nTYPE F F F\nCOUNT 1 1 1\n"
+                "WIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA %s\n" % (len(pts), len(pts), "ascii" if write_ascii else "binary"))
+    else:
+        raise ValueError("unsupported point-cloud format %r" % ext)
+    with open(path, "wb") as f:
+        f.write(head.encode("ascii"))
+        if write_ascii:
+            f.write("".join("%.17g %.17g %.17g\n" % (p[0], p[1], p[2]) for p in pts).encode("ascii"))
         else:
-            raise ValueError("unsupported point-cloud format %r" % ext)
-        for p in pts:
-            f.write("%.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+            f.write(pts.astype("<f8").tobytes())
     return True
+
+
+def _read_ply(raw):
+    end = raw.index(b"end_header")
+    end = raw.index(b"\n", end) + 1
+    head = raw[:end].decode("ascii", "replace").split("\n")
+    fmt = [ln.split()[1] for ln in head if ln.startswith("format")][0]
+    props, n, in_vertex, before = [], 0, False, 0
+    for ln in head:
+        t = ln.split()
+        if not t:
+            continue
+        if t[0] == "element":
+            if in_vertex:
+                in_vertex = False
+            elif t[1] == "vertex":
+                in_vertex, n = True, int(t[2])
+            elif not props:
+                before += 1
+        elif t[0] == "property" and in_vertex:
+            if t[1] == "list":
+                raise ValueError("list properties on PLY vertices are not supported")
+            props.append((t[-1], _PLY_TYPES[t[1]]))
+    if before:
+        raise ValueError("PLY files with elements in front of `vertex` are not supported")
+    names = [p[0] for p in props]
+    if not all(k in names for k in "xyz"):
+        raise ValueError("PLY vertex element lacks x / y / z")
+    if fmt == "ascii":
+        rows = raw[end:].decode("ascii", "replace").split("\n")[:n]
+        tab = np.array([[float(v) for v in r.split()[:len(props)]] for r in rows], dtype=np.float64).reshape(n, len(props))
+        return np.stack([tab[:, names.index(k)] for k in "xyz"], 1)
+    order = "<" if fmt == "binary_little_endian" else ">"
+    dt = np.dtype([(nm, order + ty) for nm, ty in props])
+    rec = np.frombuffer(raw, dtype=dt, count=n, offset=end)
+    return np.stack([rec[k].astype(np.float64) for k in "xyz"], 1)
+
+
+def _read_pcd(raw):
+    pos, hdr = 0, {}
+    while True:
+        nl = raw.index(b"\n", pos)
+        line = raw[pos:nl].decode("ascii", "replace").strip()
+        pos = nl + 1
+        if line.startswith("#") or not line:
+            continue
+        key, _, val = line.partition(" ")
+        hdr[key] = val.split()
+        if key == "DATA":
+            break
+    fields = hdr["FIELDS"]
+    sizes = [int(v) for v in hdr["SIZE"]]
+    types = hdr["TYPE"]
+    counts = [int(v) for v in hdr.get("COUNT", ["1"] * len(fields))]
+    n = int(hdr["POINTS"][0]) if "POINTS" in hdr else int(hdr["WIDTH"][0]) * int(hdr["HEIGHT"][0])
+    if not all(k in fields for k in "xyz"):
+        raise ValueError("PCD file lacks x / y / z fields")
+    mode = hdr["DATA"][0]
+    if mode == "ascii":
+        cols = np.cumsum([0] + counts)
+        rows = raw[pos:].decode("ascii", "replace").split("\n")[:n]
+        tab = np.array([[float(v) for v in r.split()] for r in rows], dtype=np.float64).reshape(n, -1)
+        return np.stack([tab[:, cols[fields.index(k)]] for k in "xyz"], 1)
+    if mode != "binary":
+        raise NotImplementedError("PCD DATA %s is not supported (open3d writes `binary` unless compressed=True)" % mode)
+    dt = np.dtype([(f, "<" + _PCD_TYPES[(t, s)], (c,)) if c > 1 else (f, "<" + _PCD_TYPES[(t, s)]) for f, t, s, c in zip(fields, types, sizes, counts)])
+    rec = np.frombuffer(raw, dtype=dt, count=n, offset=pos)
+    return np.stack([rec[k].astype(np.float64).reshape(n) for k in "xyz"], 1)
 
 
 def read_point_cloud(path, device="cuda"):
     ext = os.path.splitext(path)[1].lower()
-    with open(path) as f:
-        lines = f.read().split("\n")
+    with open(path, "rb") as f:
+        raw = f.read()
     if ext == ".ply":
-        if "format ascii" not in "\n".join(lines[:10]):
-            raise ValueError("only ASCII .ply files are supported")
-        start = lines.index("end_header") + 1
-        n = int([ln for ln in lines[:start] if ln.startswith("element vertex")][0].split()[-1])
+        pts = _read_ply(raw)
     elif ext == ".pcd":
-        start = [i for i, ln in enumerate(lines) if ln.startswith("DATA")][0]
-        if "ascii" not in lines[start]:
-            raise ValueError("only ASCII .pcd files are supported")
-        n = int([ln for ln in lines[:start] if ln.startswith("POINTS")][0].split()[-1])
-        start += 1
+        pts = _read_pcd(raw)
     else:
         raise ValueError("unsupported point-cloud format %r" % ext)
-    pts = np.array([[float(v) for v in ln.split()[:3]] for ln in lines[start:start + n]], dtype=np.float64).reshape(-1, 3)
-    return PointCloud(pts, device=device)
+    return PointCloud(np.ascontiguousarray(pts, dtype=np.float64), device=device)

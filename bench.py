@@ -7,8 +7,9 @@ A "step" is one pass of the whole live path (FramePipeline.run: u8 RGB + u16 dep
 segmentation at 480x640 -> masks / CCL / bbox -> 160x160 crop -> PoseNet(N=1000) -> 2x PoseRefineNet -> float64 pose)
 over one batch of synthetic frames (BASELINE config 3: batch=64 640x480 frames per GPU).  Frames shard across ranks
 (weak scaling, no data-path collective); each step ends with the single RCCL all_gather of the poses (config 4).
-`--overlap` software-pipelines the loop (pose stage of step i on a second HIP stream beside the segmentation of step i+1):
-about +2 % frames/s, off by default so that the roofline leg's event timings are the kernels' own.
+By default the loop is software-pipelined (pose stage of step i on a second HIP stream beside the segmentation of step i+1; every
+step still does all of its work between the fences): about +4 % frames/s over `--no-overlap`, whose per-kernel event timings are
+the kernels' own (with the overlap they include what the co-running small pose launches cost them).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,6 +33,7 @@ H, W, N_POINTS = 480, 640, 1000
 GFLOP_PER_FRAME = 309.0
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA, dense"
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.29 TB/s measured by a float4 copy)
 
 
 def pmc_traffic(kernel):
@@ -94,23 +96,110 @@ def build_models(device, frames_for_fit):
     return seg, est.to(device).eval(), ref.to(device).eval(), seg_sd, est_sd, ref_sd
 
 
-def cpu_baseline(frames, seg_sd, est_sd, ref_sd, n_frames=3):
-    """The oracle (CPU restatement of pipeline/utils.py:410-641, validated against reference goldens) timed on the host
-    cores on a bounded sample of the SAME frames.  Reported baseline only -- never part of `value`."""
+def _cpu_info():
+    model, phys = "unknown", None
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys_id = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core_id = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys_id is not None and core_id is not None:
+                    cores.add((phys_id, core_id))
+                phys_id = core_id = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))       # the CPUs this process may run on (the GPU box gives a share of the host)
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return model, phys, usable
+
+
+def cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=16):
+    """The oracle (CPU restatement of pipeline/utils.py:410-641, pinned by the reference goldens) timed on the host cores on a bounded
+    sample of the SAME frames.  The reference path is batch-1 Python + torch CPU and does not scale with intra-op threads (one frame
+    on 128 threads is SLOWER than on one), so the fair multi-core figure runs independent frames side by side: W single-threaded
+    workers (W = the CPUs of a one-GPU box share, at most 16), `n_frames` frames.  Also reported: one frame on one thread.
+    Reported baseline only -- never part of `value`.  `gpu_choose(frame, class, nz, n)` injects the GPU run's point selection (the
+    reference draws it from an unseeded shuffle), so the oracle results double as the checker of the `parity` block."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import densefusion_oracle as O
+    model, phys, usable = _cpu_info()
+    workers = max(1, min(16, usable or 1, phys or 16))
+    n_frames = min(n_frames, len(frames))
 
-    def choose_fn(name, nz, n):
-        return nz[(np.arange(n) * len(nz)) // n] if len(nz) > n else np.pad(nz, (0, n - len(nz)), "wrap")
+    def run(i):
+        rgb, depth, _ = frames[i]
+        return O.full_prediction(rgb, depth, S.REALSENSE_META, seg_sd, est_sd, ref_sd, CLASSES,
+                                 choose_fn=lambda name, nz, n: gpu_choose(i, name, nz, n))
 
-    O.full_prediction(*frames[0][:2], S.REALSENSE_META, seg_sd, est_sd, ref_sd, CLASSES, choose_fn=choose_fn)  # warm
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(1)                                 # intra-op: one thread per frame; the frames run in parallel
+    run(0)                                                   # warm (oneDNN primitives)
+    t1 = time.time()
+    run(0)
+    dt1 = time.time() - t1
     t = time.time()
-    found = 0
-    for rgb, depth, _ in frames[:n_frames]:
-        found += len(O.full_prediction(rgb, depth, S.REALSENSE_META, seg_sd, est_sd, ref_sd, CLASSES, choose_fn=choose_fn))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        results = dict(zip(range(n_frames), ex.map(run, range(n_frames))))
     dt = time.time() - t
-    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d of the benchmark's 640x480 frames (%d objects found), oracle/densefusion_oracle.full_prediction, "
-                      "torch CPU fp32, %d threads" % (n_frames, found, torch.get_num_threads())}
+    torch.set_num_threads(old_threads)
+    found = sum(len(r) for r in results.values())
+    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": workers, "kind": "port",
+            "single_thread_value": round(1.0 / dt1, 4), "cpu_model": model, "physical_cores": phys, "usable_cpus": usable,
+            "sample": "%d of the benchmark's 640x480 frames (%d objects found) through oracle/densefusion_oracle.full_prediction "
+                      "(torch CPU fp32), %d single-threaded workers side by side; single_thread_value = 1 frame on 1 thread"
+                      % (n_frames, found, workers)}, results
+
+
+def parity_block(out, oracle_results, frames, seg_sd):
+    """GPU (the timed path's last step) vs the oracle on the frames cpu_baseline ran: max |dq| (sign-aligned quaternion), max |dt| (m),
+    differing mask pixels, and how many of those are NOT arg-max near-ties in the oracle's own probabilities (must be 0)."""
+    from oracle import densefusion_oracle as O
+    import torch.nn.functional as F
+    objmap = out["objmap"].cpu().numpy()
+    pose = out["pose"].cpu().numpy()
+    max_dq = max_dt = 0.0
+    diff_px = diff_outside = missing = 0
+    for fi, want in oracle_results.items():
+        mine = {CLASSES[o[1] - 1]: k for k, o in enumerate(out["objects"]) if o[0] == fi}
+        missing += len(set(want) ^ set(mine))
+        for name, w in want.items():
+            if name not in mine:
+                continue
+            k = mine[name]
+            cls = out["objects"][k][1]
+            differs = (objmap[fi] == cls) != (w["mask"] == 255)
+            if differs.any():
+                with torch.no_grad():
+                    pr = F.softmax(O.segmentor_predict(seg_sd, O.seg_input(frames[fi][0]), len(CLASSES) + 1), dim=1)[0]
+                ys, xs = np.nonzero(differs)
+                top = torch.topk(pr[:, ys, xs], 2, dim=0).values
+                diff_px += len(ys)
+                diff_outside += int(((top[0] - top[1]) >= 1e-4).sum())
+            q = pose[k, :4] if np.dot(pose[k, :4], w["rotation"]) >= 0 else -pose[k, :4]
+            max_dq = max(max_dq, float(np.abs(q - w["rotation"]).max()))
+            max_dt = max(max_dt, float(np.abs(pose[k, 4:] - w["position"]).max()))
+    return {"frames": len(oracle_results), "max_dq": max_dq, "max_dt": max_dt, "tolerance": 1e-4, "mask_diff_px": diff_px,
+            "mask_diff_px_outside_tie_band": diff_outside, "objects_not_matched": missing,
+            "note": "mask pixels may differ only where the oracle's own top-2 class probabilities are closer than 1e-4 (arg-max near-ties)"}
+
+
+def kernel_peak(label):
+    """(bound, peak, unit) for a profiled kernel label"""
+    if "upconv_gather" in label:
+        return "hbm", PEAK_HBM_GBS, "GB/s"
+    if "conv_f32" in label:
+        return "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+    split = "_s32_kernel" in label or "<3," in label        # split-bf16: three bf16 MFMAs per algorithmic product
+    return "mfma", PEAK_BF16_MFMA_TFLOPS / (3.0 if split else 1.0), "TFLOP/s"
 
 
 def main():
@@ -120,9 +209,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="pose stage of step i on a second HIP stream beside the segmentation of step i+1 (software-pipelined loop): "
-                         "+2 %% frames/s, but the per-kernel event timings of the roofline leg then include the co-running pose kernels")
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
+                    help="(default) pose stage of step i on a second HIP stream beside the segmentation of step i+1 (software-pipelined "
+                         "loop, every step still does all of its work inside the fences): +4 %% frames/s; the per-kernel event timings "
+                         "of the roofline leg then include whatever the co-running pose kernels cost them")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="one stream, segmentation and pose stage back to back")
     ap.add_argument("--seg-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--pose-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
@@ -199,10 +290,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The roofline leg times ONE kernel live, with HIP events on the stream it is launched on, over the timed region.  Which
-    # kernel is dominant is found in the last warm-up step (every conv launch timed); in the timed steps only that kernel's
-    # launches carry the two event packets (each costs ~4 us of dispatch gap, ~0.5 ms per step when all ~120 convs have them).
-    dom_only = None
+    # The roofline leg times the FIVE heaviest kernels live, with HIP events on the stream they are launched on, over the timed
+    # region.  Which five is found in the last warm-up step (every profiled launch timed); in the timed steps only their launches
+    # carry the two event packets (each costs ~4 us of dispatch gap, ~0.5 ms per step when all ~120 launches have them).
+    top_only = None
     out = None
     if args.warmup > 1:
         out = run_steps(0, args.warmup - 1)
@@ -215,8 +306,8 @@ def main():
     if args.warmup:
         wsum = E.PROFILE.summary()
         if wsum:
-            dom_only = {max(wsum, key=lambda k: wsum[k]["ms"])}
-    prof = E.PROFILE = E.LaunchProfile(only=dom_only)
+            top_only = set(sorted(wsum, key=lambda k: -wsum[k]["ms"])[:5])
+    prof = E.PROFILE = E.LaunchProfile(only=top_only)
     t0 = time.perf_counter()
     out = run_steps(args.warmup, args.steps)
     fence()
@@ -234,19 +325,45 @@ def main():
 
     if rank == 0:
         summ = prof.summary()
-        dom = max(summ, key=lambda k: summ[k]["ms"]) if summ else None
+        by_shape = prof.summary(by_shape=True)
+
+        def entry(label, d, shapes=None):
+            bound, peak, unit = kernel_peak(label)
+            sec = d["ms"] * 1e-3
+            ach = (d["bytes"] / sec / 1e9) if bound == "hbm" else (d["flop"] / sec / 1e12)
+            traffic = pmc_traffic(label)
+            alg_b = d["bytes"] / d["launches"]
+            e = {"kernel": label, "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
+                 "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
+                 "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3), "avg_launch_algorithmic_mb": round(alg_b / 1e6, 1),
+                 "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_b, 2),
+                 "share_of_step_time": round(sec / dt, 3)}
+            if shapes:
+                e["shapes"] = shapes
+            return e
+
+        kernels = []
+        for label in sorted(summ, key=lambda k: -summ[k]["ms"]):
+            shapes = []
+            for (lab, shape), d in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"]):
+                if lab != label:
+                    continue
+                bound, peak, unit = kernel_peak(label)
+                sec = d["ms"] * 1e-3
+                ach = (d["bytes"] / sec / 1e9) if bound == "hbm" else (d["flop"] / sec / 1e12)
+                shapes.append({"shape": shape, "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
+                               "gflop": round(d["flop"] / d["launches"] / 1e9, 3), "algorithmic_mb": round(d["bytes"] / d["launches"] / 1e6, 1),
+                               "achieved": round(ach, 2), "frac": round(ach / peak, 4)})
+            kernels.append(entry(label, summ[label], shapes))
+        # the dominant kernel: largest summed time over the timed region (deterministic given the timings)
         roofline = None
-        if dom:
-            d = summ[dom]
-            ach = d["flop"] / (d["ms"] * 1e-3) / 1e12
-            # algorithmic flop (2*M*N*K of the convolution) against the peak of the instruction the kernel issues; a
-            # split-bf16 kernel issues 3 bf16 MFMAs per algorithmic product, so its ceiling is the bf16 peak / 3
-            peak = PEAK_F32_MFMA_TFLOPS if "conv_f32" in dom else PEAK_BF16_MFMA_TFLOPS / (3.0 if "<3," in dom else 1.0)
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": round(peak, 1),
-                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom),
-                        "launches": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                        "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3),
-                        "share_of_step_time": round(d["ms"] * 1e-3 / dt, 3)}
+        if kernels:
+            roofline = {k: v for k, v in kernels[0].items() if k != "shapes"}
+            roofline["kernels"] = kernels
+            roofline["note"] = ("achieved = algorithmic flop (2*M*Cout*KH*KW*Cin; a split-bf16 kernel issues 3 MFMAs per product, so its peak is the bf16 "
+                                "dense peak / 3) or algorithmic bytes per launch / HIP-event time on the launch stream, timed region only; traffic = "
+                                "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), averaged over the kernel's shapes"
+                                + ("; --overlap: the pose stage of the previous step runs beside these kernels on a second stream" if args.overlap else ""))
         total_frames = args.batch * world * args.steps
         line = {
             "metric": "RGB-D frames/sec (seg+DenseFusion+2-refine), 640x480 N=1000",
@@ -265,10 +382,23 @@ def main():
                        "crop_buckets_last_step": crop_hist,
                        "gflop_per_frame_algorithmic": GFLOP_PER_FRAME, "parallelism": "frames sharded x%d, 1 all_gather of poses/step" % world},
             "achieved_tflops_algorithmic": round(total_frames * GFLOP_PER_FRAME / dt / 1e3, 2),
+            "overlap": bool(args.overlap),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
-            line["cpu_baseline"] = cpu_baseline(frames, seg_sd, est_sd, ref_sd)
+            if out.get("stream") is not None:
+                out["stream"].synchronize()
+            choose_h = out["choose"].cpu().numpy()
+            by_frame = {(o[0], CLASSES[o[1] - 1]): k for k, o in enumerate(out["objects"])}
+
+            def gpu_choose(fi, name, nz, n):
+                k = by_frame.get((fi, name))
+                if k is None:       # the GPU did not detect this object: any deterministic selection (counted in objects_not_matched)
+                    return nz[(np.arange(n) * len(nz)) // n] if len(nz) > n else np.pad(nz, (0, n - len(nz)), "wrap")
+                return choose_h[k]
+
+            line["cpu_baseline"], oracle_results = cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=min(16, args.batch))
+            line["parity"] = parity_block(out, oracle_results, frames, seg_sd)
         print(json.dumps(line))
     if dist:
         dist.barrier()

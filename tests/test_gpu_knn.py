@@ -39,7 +39,10 @@ def test_knn_vs_oracle_bit_exact(oracle_knn_lib, b, nr, nq, qz):
 def test_knn_general_k_and_dim(oracle_knn_lib):
     rng = np.random.default_rng(5)
     for (b, d, nr, nq, k, qz) in [(2, 3, 100, 300, 4, 0.5), (1, 8, 64, 129, 2, 0), (1, 128, 100, 1000, 2, 0),
-                                  (1, 2, 70, 65, 64, 1.0)]:
+                                  (1, 2, 70, 65, 64, 1.0),
+                                  # k > 64 (the reference takes any k <= ref_nb): several selection passes, ties across the pass boundary,
+                                  # k == ref_nb (a full sort)
+                                  (1, 3, 200, 77, 65, 0.5), (2, 2, 150, 40, 150, 1.0), (1, 3, 300, 33, 200, 0)]:
         ref = rng.standard_normal((b, d, nr)).astype(np.float32)
         qry = rng.standard_normal((b, d, nq)).astype(np.float32)
         if qz:

@@ -138,3 +138,56 @@ def test_pipeline_is_bitwise_deterministic():
     assert torch.equal(c["choose"], a["choose"]) and torch.equal(c["pose"], a["pose"])
     q = a["pose"][:, :4]
     assert torch.allclose(q.norm(dim=1), torch.ones(len(q), dtype=torch.float64, device=q.device), atol=1e-9) and (q[:, 0] >= 0).all()
+
+
+def test_get_prediction_models_from_a_dataset_tree(tmp_path):
+    """pipeline/utils.py:643-718 on a synthetic dataset tree in the reference's layout (classes.txt, <cls>.xyz model clouds in mm,
+    pose_model.pth / pose_refine_model.pth state dicts, the segmentor checkpoint with a 'state_dict' entry): the 9-tuple contract, the
+    weights really loaded, and the tuple drives full_prediction to the same result as directly built models."""
+    import os
+    from autoposeestimation_amd.pipeline.utils import full_prediction, get_prediction_models, read_xyz_cloud
+    root, ds = str(tmp_path), "synth"
+    seg, est, ref, seg_sd, est_sd, ref_sd = _models("resnet34")
+    frames = [S.synthetic_frame(700 + i, cls=c, box=bx, size=sz) for i, (c, bx, sz) in enumerate([(2, (150, 250), (150, 150)), (7, (60, 80), (100, 120))])]
+    seg, seg_sd = _fit_segmentor(seg, seg_sd, frames)
+    os.makedirs(os.path.join(root, "label_generator", "data_sets", "segmentation", ds))
+    with open(os.path.join(root, "label_generator", "data_sets", "segmentation", ds, "classes.txt"), "w") as f:
+        f.write("\n".join(CLASSES) + "\n")
+    rng = np.random.default_rng(0)
+    clouds = {}
+    for name in CLASSES:
+        d = os.path.join(root, "pc_reconstruction", "data", name)
+        os.makedirs(d)
+        clouds[name] = (rng.random((1200, 3)) - 0.5) * 100.0          # mm
+        with open(os.path.join(d, name + ".xyz"), "w") as f:
+            for p in clouds[name]:
+                f.write("[{} {} {}]\n".format(*p))                    # create_pointcloud.py:373-376 writes str(ndarray row)
+    pose_dir = os.path.join(root, "DenseFusion", "trained_models", ds)
+    os.makedirs(pose_dir)
+    torch.save(est_sd, os.path.join(pose_dir, "pose_model.pth"))
+    torch.save(ref_sd, os.path.join(pose_dir, "pose_refine_model.pth"))
+    seg_dir = os.path.join(root, "segmentation", "trained_models", ds)
+    os.makedirs(seg_dir)
+    torch.save({"state_dict": seg_sd, "epoch": 3, "iou": 0.9}, os.path.join(seg_dir, "PsPNet_resnet34.ckpt"))
+
+    out = get_prediction_models(root, ds)
+    assert len(out) == 9
+    segmentor, estimator, refiner, classes, to_tensor, normalize, cld, device, cuda = out
+    assert classes == CLASSES and cuda is True and device.type == "cuda" and sorted(cld) == list(range(12))
+    np.testing.assert_allclose(cld[3], clouds[CLASSES[3]] / 1000.0, rtol=0, atol=1e-12)             # mm -> m (pipeline/utils.py:667-686)
+    np.testing.assert_allclose(read_xyz_cloud(os.path.join(root, "pc_reconstruction", "data", CLASSES[0], CLASSES[0] + ".xyz"), False), clouds[CLASSES[0]])
+    assert torch.equal(estimator.state_dict()["conv4_r.weight"].cpu(), est_sd["conv4_r.weight"])
+    assert torch.equal(refiner.state_dict()["conv3_t.bias"].cpu(), ref_sd["conv3_t.bias"])
+    assert torch.equal(segmentor.state_dict()["final.0.weight"].cpu(), seg_sd["final.0.weight"])
+    t = normalize(to_tensor(frames[0][0]))
+    assert t.shape == (3, 480, 640) and abs(float(t.mean())) < 3
+    rgb, depth, _ = frames[0]
+    got = full_prediction(rgb, depth, S.REALSENSE_META, segmentor, estimator, refiner, to_tensor, normalize, device, cuda, {}, class_names=classes)
+    want = full_prediction(rgb, depth, S.REALSENSE_META, seg, est, ref, None, None, torch.device("cuda:0"), True, {}, class_names=CLASSES)
+    assert set(got["predictions"]) == set(want["predictions"]) and len(got["predictions"]) >= 1
+    for name, w in want["predictions"].items():
+        assert np.array_equal(got["predictions"][name]["mask"], w["mask"])
+    # the reference's smp checkpoint name is recognised and refused with an explanation
+    os.rename(os.path.join(seg_dir, "PsPNet_resnet34.ckpt"), os.path.join(seg_dir, "Unet_resnet34.ckpt"))
+    with pytest.raises(FileNotFoundError, match="segmentation_models_pytorch"):
+        get_prediction_models(root, ds)

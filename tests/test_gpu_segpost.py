@@ -219,3 +219,30 @@ def test_fused_seg_head_matches_conv_plus_argmax():
     label2, score2 = E.seg_argmax(conv(feat), 13, double_softmax=True)
     assert (label != label2).sum().item() <= 2
     assert (score - score2).abs().max().item() < 1e-5
+
+
+def test_argmax_breaks_probability_ties_like_torch():
+    """pipeline/utils.py:430-435 takes the arg-max of the float32 PROBABILITIES: two logits closer than the rounding of exp() give equal
+    probabilities and torch.argmax returns the lower class -- also when the higher class has the (marginally) larger logit."""
+    from autoposeestimation_amd import engine as E
+    n, C = 64, 5
+    logits = torch.full((1, 1, n, 8), -4.0)
+    logits[0, 0, :, 1] = 2.0
+    logits[0, 0, :, 3] = torch.nextafter(torch.tensor(2.0), torch.tensor(3.0))      # one ulp above class 1
+    logits[0, 0, n // 2:, 3] = 2.5                                                  # a real margin on the second half
+    p = F.softmax(F.softmax(logits[..., :C], -1), -1)
+    want = p.argmax(-1)[0, 0]
+    assert int(want[0]) == 1 and int(want[-1]) == 3                                 # the premise: torch sees a tie on the first half
+    label, score = E.seg_argmax(logits.cuda(), C, double_softmax=True)
+    assert torch.equal(label[0, 0].cpu().long(), want)
+    # the fused head: 64 -> C contraction with weights that reproduce these logits from a one-hot-ish feature
+    feat = torch.zeros(1, 1, n, 64)
+    feat[..., 0] = 1.0
+    w = torch.zeros(C, 64)
+    w[:, 0] = torch.tensor([-4.0, 2.0, -4.0, 0.0, -4.0])
+    b = torch.zeros(C)
+    w[3, 0] = float(torch.nextafter(torch.tensor(2.0), torch.tensor(3.0)))
+    feat[0, 0, n // 2:, 1] = 1.0
+    w[3, 1] = 0.5
+    l2, _ = E.seg_head(feat.cuda(), w.cuda().contiguous(), b.cuda(), True)
+    assert torch.equal(l2[0, 0].cpu().long(), want)

@@ -18,7 +18,8 @@ POSENET_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(
 def test_posenet_and_refiner(case):
     g = golden(case)
     n, num_obj, obj = int(g["n"]), int(g["num_obj"]), int(g["obj"])
-    est_sd, ref_sd = S.posenet_state_dict(num_obj, 0), S.refiner_state_dict(num_obj, 0)
+    wseed = int(g["wseed"]) if "wseed" in g.files else 0       # synthetic-weight seed the reference ran with (tools/gen_golden.py)
+    est_sd, ref_sd = S.posenet_state_dict(num_obj, wseed), S.refiner_state_dict(num_obj, wseed)
     img = torch.from_numpy(g["img"]).unsqueeze(0)
     pts = torch.from_numpy(g["points"]).unsqueeze(0)
     ch = torch.from_numpy(g["choose"]).view(1, 1, -1)

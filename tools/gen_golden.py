@@ -97,11 +97,19 @@ def gen_posenet():
         ("n1000_o12_160x160", 1000, 12, 0, 4, (150, 250), (150, 150), 3, S.REALSENSE_META),
         ("n1000_o12_120x200", 1000, 12, 13, 7, (300, 400), (101, 170), 6, S.REALSENSE_META),
     ]
+    # synthetic-weight seed per case: with seed 0 the tiny 40x40 crop saturates the confidence head (c in 0.9978..0.9999 and a top-2
+    # margin of 1e-6, below fp32 noise: the arg-max winner -- hence R, t -- was not comparable); seed 4 gives c in 0.08..0.15 and a
+    # margin of 1e-2
+    wseeds = {"n1000_o12_40x40": 4}
+    only = os.environ.get("APE_GOLDEN_ONLY")
     for name, n, num_obj, frame, cls, box, size, obj, meta in cases:
+        if only and only != "posenet_" + name:
+            continue
         est = PoseNet(num_points=n, num_obj=num_obj).eval()
-        est.load_state_dict(S.posenet_state_dict(num_obj, seed=0), strict=True)
+        wseed = wseeds.get(name, 0)
+        est.load_state_dict(S.posenet_state_dict(num_obj, seed=wseed), strict=True)
         refiner = PoseRefineNet(num_points=n, num_obj=num_obj).eval()
-        refiner.load_state_dict(S.refiner_state_dict(num_obj, seed=0), strict=True)
+        refiner.load_state_dict(S.refiner_state_dict(num_obj, seed=wseed), strict=True)
         lab = np.zeros((480, 640), bool)
         lab[box[0]:box[0] + size[0], box[1]:box[1] + size[1]] = True
         bbox = tuple(int(v) for v in get_bbox(lab))
@@ -138,7 +146,7 @@ def gen_posenet():
         c = pred_c.view(-1)
         top2 = torch.topk(c, 2).values
         save("posenet_" + name,
-             n=n, num_obj=num_obj, obj=obj, bbox=np.array(bbox), frame=frame, cls=cls,
+             n=n, num_obj=num_obj, obj=obj, bbox=np.array(bbox), frame=frame, cls=cls, wseed=wseed,
              box=np.array(box), size=np.array(size),
              fx=meta['intr']['fx'], fy=meta['intr']['fy'], ppx=meta['intr']['ppx'], ppy=meta['intr']['ppy'],
              depth_scale=meta['depth_scale'],
@@ -291,6 +299,9 @@ def gen_pc_utils():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if os.environ.get("APE_GOLDEN_ONLY", "").startswith("posenet_"):       # regenerate one PoseNet fixture, leave the rest untouched
+        gen_posenet()
+        sys.exit(0)
     gen_knn()
     gen_bbox()
     gen_pose_utils()
