@@ -227,9 +227,10 @@ def test_argmax_breaks_probability_ties_like_torch():
     from autoposeestimation_amd import engine as E
     n, C = 64, 5
     logits = torch.full((1, 1, n, 8), -4.0)
-    logits[0, 0, :, 1] = 2.0
-    logits[0, 0, :, 3] = torch.nextafter(torch.tensor(2.0), torch.tensor(3.0))      # one ulp above class 1
-    logits[0, 0, n // 2:, 3] = 2.5                                                  # a real margin on the second half
+    hi = float(torch.nextafter(torch.tensor(0.1), torch.tensor(1.0)))               # one ulp (7.5e-9) above 0.1: exp(-7.5e-9) rounds to 1.0f
+    logits[0, 0, :, 1] = 0.1
+    logits[0, 0, :, 3] = hi
+    logits[0, 0, n // 2:, 3] = 0.6                                                  # a real margin on the second half
     p = F.softmax(F.softmax(logits[..., :C], -1), -1)
     want = p.argmax(-1)[0, 0]
     assert int(want[0]) == 1 and int(want[-1]) == 3                                 # the premise: torch sees a tie on the first half
@@ -239,9 +240,9 @@ def test_argmax_breaks_probability_ties_like_torch():
     feat = torch.zeros(1, 1, n, 64)
     feat[..., 0] = 1.0
     w = torch.zeros(C, 64)
-    w[:, 0] = torch.tensor([-4.0, 2.0, -4.0, 0.0, -4.0])
+    w[:, 0] = torch.tensor([-4.0, 0.1, -4.0, 0.0, -4.0])
     b = torch.zeros(C)
-    w[3, 0] = float(torch.nextafter(torch.tensor(2.0), torch.tensor(3.0)))
+    w[3, 0] = hi
     feat[0, 0, n // 2:, 1] = 1.0
     w[3, 1] = 0.5
     l2, _ = E.seg_head(feat.cuda(), w.cuda().contiguous(), b.cuda(), True)
