@@ -192,12 +192,23 @@ def create_pose_label(root, object_name, global_regression, icp_point2point, icp
 
 
 def create_pose_data(root, classes, ds_name, reference_point=np.array([]), new_pred=True, get_extra_labels=False, plot=False,
-                     use_cuda=True, model=None, n_viewpoints=30, batch=16):
+                     use_cuda=True, model=None, n_viewpoints=30, batch=16, dist=None, rng_seed=None):
     """reference :40-289 ("Create Pose labels"): per class (1) re-label every frame with the segmentor + trust checks
     (`<id>.new_pred.label.png`), (2) fuse the selected views into the object's point cloud, (3) write the pose labels.
     `model` (an already loaded segmentor) and `n_viewpoints` / `batch` are additions; everything else keeps the reference
-    names, defaults and hyper-parameters (:219-231)."""
+    names, defaults and hyper-parameters (:219-231).
+
+    `dist` (an initialised torch.distributed module, one process per GPU on a shared file system): the frames of the
+    relabel loop are independent -- every rank relabels its contiguous share of each directory's samples and writes their PNGs --
+    then load_point_cloud shards as described there and rank 0 writes the pose labels.  `rng_seed` seeds the view selection (needed
+    with `dist`: all ranks must draw the same views).  The returned stats are summed over the ranks."""
+    from autoposeestimation_amd import sharding
     from autoposeestimation_amd.data_generation import sample_io as io
+    dist_on = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if dist_on else 0
+    world = dist.get_world_size() if dist_on else 1
+    if dist_on and rng_seed is None:
+        rng_seed = 0
     from autoposeestimation_amd.pc_reconstruction.create_pointcloud import load_point_cloud
     if not (torch.cuda.is_available() and use_cuda):
         raise RuntimeError("create_pose_data needs the GPU: the MI355X path has no CPU fallback")
@@ -219,6 +230,8 @@ def create_pose_data(root, classes, ds_name, reference_point=np.array([]), new_p
             label_path = os.path.join(root, "label_generator/data", cls, d)
             os.makedirs(label_path, exist_ok=True)
             samples = io.list_samples(data_dir)
+            lo, hi = sharding.shard_range(len(samples), rank, world)
+            samples = samples[lo:hi]
             for s0 in range(0, len(samples), batch):
                 ids = samples[s0:s0 + batch]
                 rgb = torch.from_numpy(np.stack([io.read_color(data_dir, i) for i in ids])).to(device)
@@ -240,15 +253,27 @@ def create_pose_data(root, classes, ds_name, reference_point=np.array([]), new_p
                         for stale in (new_png, os.path.join(label_path, "{}.meta.json".format(sid))):
                             if os.path.exists(stale):
                                 os.remove(stale)
+        if dist_on:
+            torch.cuda.synchronize()
+            dist.barrier()                      # every rank's label PNGs are on the shared file system
         times["seg"].append(time.time() - t0)
         t0 = time.time()
         load_point_cloud(cls, os.path.join(root, "pc_reconstruction/data"), root, reference_point=reference_point, mode=mode,
                          n_viewpoints=n_viewpoints, min_friends=20, min_dist=5, nb_neighbors=20, threshold=10, voxel_size=2,
-                         voxel_size_out=5, l_arrow=75, global_regression=False, icp_point2point=True, icp_point2plane=False)
+                         voxel_size_out=5, l_arrow=75, global_regression=False, icp_point2point=True, icp_point2plane=False,
+                         rng=None if rng_seed is None else np.random.default_rng(rng_seed + class_id), dist=dist if dist_on else None)
         times["pc"].append(time.time() - t0)
         t0 = time.time()
-        create_pose_label(root, cls, False, True, False, plot=False, view_label=False, with_extra=get_extra_labels)
+        if rank == 0:
+            create_pose_label(root, cls, False, True, False, plot=False, view_label=False, with_extra=get_extra_labels)
+        if dist_on:
+            dist.barrier()
         times["pose"].append(time.time() - t0)
         print("class {}: seg {:.2f} s, pc {:.2f} s, pose {:.2f} s; stats {}".format(cls, times["seg"][-1], times["pc"][-1],
                                                                                    times["pose"][-1], stats))
+    if dist_on:
+        keys = sorted(stats)
+        t = torch.tensor([stats[k] for k in keys], dtype=torch.int64, device=sharding._dist_device(dist))
+        dist.all_reduce(t)
+        stats = {k: int(v) for k, v in zip(keys, t.cpu().tolist())}
     return stats, times

@@ -121,15 +121,12 @@ def get_surface(label, depth_frame, intr, robot2Cam_ft, min_friends, min_dist, n
     return _post_filter(surface, min_friends, min_dist, nb_neighbors)
 
 
-def fuse_views(views, intr, voxel_size=2, threshold=10, min_friends=20, min_dist=5, nb_neighbors=20, voxel_size_out=None,
-               icp_point2point=True, icp_point2plane=False):
-    """The sequential accumulation at the heart of load_point_cloud (pc_reconstruction/create_pointcloud.py:276-312):
-    `views` = iterable of (label u8[H,W], depth [H,W], robot2cam 4x4); each new surface is registered to the accumulating
-    cloud, merged, and the union is voxel down-sampled.  The chain is order-dependent (replicas only inside
-    one chain; different (object, direction) chains shard across GPUs).  Returns (cloud, [T per view])."""
+def fuse_surfaces(surfaces, voxel_size=2, threshold=10, voxel_size_out=None, icp_point2point=True, icp_point2plane=False):
+    """The sequential accumulation at the heart of load_point_cloud (pc_reconstruction/create_pointcloud.py:288-312) over already
+    pre-processed surfaces (PointClouds in view order, empty ones skipped): each is registered to the accumulating cloud, merged, and
+    the union is voxel down-sampled.  Order-dependent: one rank runs a chain.  Returns (cloud, [T per surface])."""
     acc, tfs = None, []
-    for label, depth, robot2cam in views:
-        source = get_surface(label, depth, intr, robot2cam, min_friends, min_dist, nb_neighbors, voxel_size)
+    for source in surfaces:
         if len(source) == 0:
             tfs.append(None)
             continue
@@ -146,6 +143,33 @@ def fuse_views(views, intr, voxel_size=2, threshold=10, min_friends=20, min_dist
     if acc is not None and voxel_size_out:
         acc = acc.voxel_down_sample(voxel_size_out)
     return acc, tfs
+
+
+def fuse_views(views, intr, voxel_size=2, threshold=10, min_friends=20, min_dist=5, nb_neighbors=20, voxel_size_out=None,
+               icp_point2point=True, icp_point2plane=False, dist=None, owner=0):
+    """`views` = sequence of (label u8[H,W], depth [H,W], robot2cam 4x4) of ONE (object, direction) chain (create_pointcloud.py:276-312):
+    get_surface per view, then fuse_surfaces.  With a torch.distributed group (`dist`) the per-view get_surface work is sharded over the
+    ranks and one padded all-gather hands the surfaces to the chain's `owner`, which fuses them (SURVEY.md 8e; sharding.sharded_chain);
+    the other ranks return (None, None).  The result on the owner is bit-identical to the single-rank call."""
+    from autoposeestimation_amd import sharding
+    views = list(views)
+
+    def make_set(view):
+        label, depth, robot2cam = view() if callable(view) else view       # a callable decodes its files only on the rank that owns the view
+        return get_surface(label, depth, intr, robot2cam, min_friends, min_dist, nb_neighbors, voxel_size)._p
+
+    def fuse(sets):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        clouds = []
+        for p in sets:
+            c = _pc.PointCloud(device=dev)
+            c.points = p.to(dev)
+            clouds.append(c)
+        return fuse_surfaces(clouds, voxel_size=voxel_size, threshold=threshold, voxel_size_out=voxel_size_out,
+                             icp_point2point=icp_point2point, icp_point2plane=icp_point2plane)
+
+    res = sharding.sharded_chain(views, make_set, fuse, owner, dist)
+    return res if res is not None else (None, None)
 
 
 import torch  # noqa: E402

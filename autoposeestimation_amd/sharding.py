@@ -1,7 +1,14 @@
 """Frame sharding across the GPUs of one node: frames are independent, so each rank (one process per GPU)
 owns a contiguous block and the only collective of the live path is ONE all_gather of the per-frame results
 `[frames_per_rank, max_obj, 8] f32 = (cls, qw,qx,qy,qz, tx,ty,tz)` -- a few KB, latency-bound on any xGMI link.
-Works with any torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests)."""
+Works with any torch.distributed backend (RCCL on the GPU box, gloo in the CPU tests).
+
+Label generation (BASELINE configs[4]): inside one (object, rotation-directory) CHAIN the fusion is sequential and
+order-dependent (create_pointcloud.py:288-312), so a chain is owned by ONE rank (`chain_owner`); what shards inside a chain is the
+per-view work (decode, `get_surface` incl. its filters): every rank pre-processes its `shard_range` of the chain's views and ONE
+padded all-gather (`gather_point_sets`) hands the variable-length surfaces to the owner, which registers them in view order --
+bit-identical to the single-rank chain because the surfaces are the same arrays in the same order."""
+import numpy as np
 import torch
 
 
@@ -35,3 +42,61 @@ def gather_results(local, dist=None):
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local.contiguous())
     return torch.cat(parts, 0)
+
+
+def chain_owner(chain_index, world):
+    """rank that owns chain number `chain_index` of an (object x direction) enumeration: round robin"""
+    return chain_index % max(1, world)
+
+
+def _dist_device(dist):
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def gather_point_sets(local_sets, n_total, dist=None):
+    """local_sets: [(global_index, points[n_i, 3] float64 tensor or ndarray)] this rank produced; n_total: number of sets over all
+    ranks (each rank holds at most ceil(n_total / world) of them, cf. shard_range).  Returns the list of all n_total point arrays
+    (float64 tensors on the collective's device) in global-index order, on EVERY rank: one small all_gather of the (index, count)
+    table and ONE all_gather of the surfaces padded to [sets_per_rank, Pmax, 3]."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = [None] * n_total
+        for gi, pts in local_sets:
+            out[gi] = torch.as_tensor(pts, dtype=torch.float64)
+        return out
+    world = dist.get_world_size()
+    dev = _dist_device(dist)
+    per_rank = -(-n_total // world)
+    if len(local_sets) > per_rank:
+        raise ValueError("a rank holds %d point sets, more than ceil(%d / %d)" % (len(local_sets), n_total, world))
+    table = torch.full((per_rank, 2), -1, dtype=torch.int64, device=dev)
+    for k, (gi, pts) in enumerate(local_sets):
+        table[k, 0], table[k, 1] = gi, len(pts)
+    tables = [torch.empty_like(table) for _ in range(world)]
+    dist.all_gather(tables, table)
+    tables = torch.stack(tables).cpu().numpy()                       # [world, per_rank, 2]
+    pmax = max(1, int(tables[..., 1].max()))
+    buf = torch.zeros(per_rank, pmax, 3, dtype=torch.float64, device=dev)
+    for k, (gi, pts) in enumerate(local_sets):
+        buf[k, :len(pts)] = torch.as_tensor(pts, dtype=torch.float64).to(dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    out = [None] * n_total
+    for r in range(world):
+        for k in range(per_rank):
+            gi, cnt = int(tables[r, k, 0]), int(tables[r, k, 1])
+            if gi >= 0:
+                out[gi] = bufs[r][k, :cnt].clone()
+    if any(o is None for o in out):
+        raise RuntimeError("gather_point_sets: some of the %d sets were produced by no rank" % n_total)
+    return out
+
+
+def sharded_chain(items, make_set, fuse, owner, dist=None):
+    """One chain: `items` (its views, in fusion order) -> make_set(item) for this rank's shard_range of them -> one padded all-gather
+    -> `fuse(list of point arrays in item order)` on the owner rank only (None elsewhere)."""
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    lo, hi = shard_range(len(items), rank, world)
+    local = [(i, make_set(items[i])) for i in range(lo, hi)]
+    sets = gather_point_sets(local, len(items), dist)
+    return fuse(sets) if rank == owner else None

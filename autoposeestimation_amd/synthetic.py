@@ -187,3 +187,56 @@ def fit_final_layer(feats, labels, n_out, margin=8.0, ridge=1e-2):
     ata = a.t() @ a + ridge * p * torch.eye(a.shape[1], dtype=torch.float64, device=f.device)
     sol = torch.linalg.solve(ata, a.t() @ t)          # [65, n_out]
     return sol[:64].t().float().cpu().contiguous(), sol[64].float().cpu().contiguous()
+
+
+# ---- label path (BASELINE configs[4]): synthetic multi-view depth renders of a known object --------------------------------------
+LABEL_INTR = {"fx": 615.0, "fy": 615.0, "ppx": 320.0, "ppy": 240.0}
+LABEL_CENTRE = np.array([400.0, -20.0, 150.0])
+
+
+def rigid(rx, ry, rz, t):
+    """4x4 from Euler ZYX angles (R = Rz Ry Rx) and a translation"""
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]]) @ np.array([[cy, 0, sy], [0, 1.0, 0], [-sy, 0, cy]]) @ np.array([[1.0, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return T
+
+
+def bumpy_sphere(n, seed, radius=60.0, centre=LABEL_CENTRE):
+    """a sphere with bumps (SURVEY.md 8d, config 5's known object), n surface samples in the robot frame (mm)"""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    r = radius * (1 + 0.15 * np.sin(3 * v[:, 0]) * np.cos(4 * v[:, 1]) + 0.1 * np.sin(5 * v[:, 2]))
+    return v * r[:, None] + np.asarray(centre)
+
+
+def render_depth(points, cam2robot, intr=LABEL_INTR, h=480, w=640):
+    """z-buffer render of a robot-frame cloud into a uint16 depth image (mm) for a pin-hole camera at `cam2robot`"""
+    Tinv = np.linalg.inv(cam2robot)
+    pc = points @ Tinv[:3, :3].T + Tinv[:3, 3]
+    pc = pc[pc[:, 2] > 50]
+    u = np.round(pc[:, 0] * intr["fx"] / pc[:, 2] + intr["ppx"]).astype(int)
+    v = np.round(pc[:, 1] * intr["fy"] / pc[:, 2] + intr["ppy"]).astype(int)
+    ok = (u >= 0) & (u < w) & (v >= 0) & (v < h)
+    depth = np.zeros((h, w), np.float64)
+    order = np.argsort(-pc[ok, 2])
+    depth[v[ok][order], u[ok][order]] = np.round(pc[ok, 2][order])
+    return depth.astype(np.uint16)
+
+
+def label_views(n_views, seed=0, cloud=None, distance=500.0):
+    """`n_views` (label u8, depth u16, robot2cam 4x4) of the bumpy sphere from camera poses on a cap around it (the arc pattern of
+    robot_controller/robot_path/viewpointsPath2.json reduced to its geometry: the camera looks at the object from 500 mm, tilted by
+    up to +-1 rad about y and +-0.5 rad about x)"""
+    cloud = bumpy_sphere(300000, 21) if cloud is None else cloud
+    rng = np.random.default_rng(seed)
+    views = []
+    for _ in range(n_views):
+        ang_y, ang_x = rng.uniform(-1.0, 1.0), rng.uniform(-0.5, 0.5)
+        cam = rigid(np.pi, 0.0, 0.0, tuple(LABEL_CENTRE + [0, 0, distance]))
+        cam = rigid(0, 0, 0, tuple(LABEL_CENTRE)) @ rigid(ang_x, ang_y, 0.0, (0, 0, 0)) @ rigid(0, 0, 0, tuple(-LABEL_CENTRE)) @ cam
+        depth = render_depth(cloud, cam)
+        views.append(((depth != 0).astype(np.uint8) * 255, depth, cam))
+    return views

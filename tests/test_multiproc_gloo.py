@@ -55,3 +55,70 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+# ---- label generation (BASELINE configs[4]): chains owned by one rank, per-view work sharded, one padded all-gather ------------------
+def _views(n):
+    """stand-ins for the pre-processed surfaces of n views: ragged float64 point sets, one of them empty"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    return [rng.standard_normal((0 if i == 3 else 40 + 17 * i, 3)) * 50 for i in range(n)]
+
+
+def _order_dependent_fuse(sets):
+    """a fusion whose result depends on the ORDER of the sets like the sequential ICP accumulation does (create_pointcloud.py:288-312)"""
+    import numpy as np
+    acc = np.zeros(3)
+    for k, s in enumerate(sets):
+        s = s.numpy() if hasattr(s, "numpy") else np.asarray(s)
+        if len(s):
+            acc = acc * 0.5 + s.sum(0) * (k + 1)
+    return acc
+
+
+def _label_worker(rank, world, port, q):
+    import numpy as np
+    from autoposeestimation_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    views = _views(7)
+    made = []
+
+    def make_set(v):
+        made.append(len(v))
+        return torch.from_numpy(v * 2.0)             # the "get_surface" of a view (any deterministic per-view function)
+
+    res = {}
+    for chain, owner in ((0, sharding.chain_owner(0, world)), (1, sharding.chain_owner(1, world))):
+        res[chain] = sharding.sharded_chain(views, make_set, _order_dependent_fuse, owner, dist)
+    sets = sharding.gather_point_sets([(i, views[i]) for i in range(7) if i % world == rank][:4], 7, dist) if world == 2 else None
+    q.put((rank, {k: (None if v is None else v.tolist()) for k, v in res.items()}, len(made), [len(s) for s in sets]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_label_chain_sharding_two_ranks_equals_single_rank():
+    import numpy as np
+    from autoposeestimation_amd import sharding
+    views = _views(7)
+    want = _order_dependent_fuse([v * 2.0 for v in views])
+    single = sharding.sharded_chain(views, lambda v: torch.from_numpy(v * 2.0), _order_dependent_fuse, 0, None)
+    assert np.array_equal(single, want)
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_label_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (res, made, lens)) for r, res, made, lens in (q.get(), q.get()))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # chain 0 belongs to rank 0, chain 1 to rank 1; the owner's result is bit-identical to the single-rank chain, the other rank has none
+    assert got[0][0][0] == want.tolist() and got[0][0][1] is None
+    assert got[1][0][1] == want.tolist() and got[1][0][0] is None
+    # each rank pre-processed only its share of the views, per chain: 4 + 3 of 7
+    assert got[0][1] == 2 * 4 and got[1][1] == 2 * 3
+    # the gather returns every set, in global order, with its true (ragged) length on both ranks
+    assert got[0][2] == got[1][2] == [len(v) for v in views]
