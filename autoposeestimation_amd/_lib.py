@@ -90,7 +90,9 @@ SIGNATURES = {
     "ape_grid_nn1_f64": [_P, _P, _P, _P, _I, _D, _P, _I, _D, _P, _P, _P],
     "ape_grid_normals_f64": [_P, _P, _P, _P, _I, _D, _P, _I, _D, _I, _P, _P],
     "ape_knn_mean_dist_f64": [_P, _I, _I, _P, _P],
+    "ape_grid_knn_mean_dist_f64": [_P, _P, _P, _P, _I, _D, _I, _P, _P],
     "ape_icp_sums_f64": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _c.c_size_t, _P],
+    "ape_icp_run_f64": [_I, _P, _P, _P, _P, _I, _D, _P, _I, _P, _P, _D, _D, _D, _I, _I, _I, _P, _P, _P, _P, _P, _c.c_size_t, _P],
     "ape_mahalanobis_f64": [_P, _I, _P, _P, _P],
     "ape_select_points_f64": [_P, _P, _I, _P, _P, _P, _P, _c.c_size_t, _P],
 }

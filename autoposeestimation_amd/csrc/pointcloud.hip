@@ -193,8 +193,12 @@ __global__ void radius_count_kernel(Grid g, const double* __restrict__ q, int nq
     }
 }
 
-__global__ void nn1_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx, double* __restrict__ dist2)
+// `skip` (optional, everywhere below): a device word that, once non-zero, turns the launch into a no-op -- the ICP loop runs a fixed
+// number of enqueued iterations and the device decides when it has converged (icp_step_kernel)
+__global__ void nn1_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx, double* __restrict__ dist2,
+                           const double* __restrict__ skip = nullptr)
 {
+    if (skip && skip[0] != 0.0) return;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
         double best = r2;
         unsigned bi = 0xffffffffu;
@@ -308,6 +312,69 @@ __global__ __launch_bounds__(kT) void knn_mean_kernel(const double* __restrict__
     }
 }
 
+// The same through the uniform grid: cells are visited in growing Chebyshev shells around the query's cell; after shell R every
+// unvisited point is at least R*h away, so the search stops once the k-th best distance is inside that bound.  The k smallest squared
+// distances are the same multiset as the brute-force kernel finds and are summed in the same (ascending) order => bitwise equal means.
+// Queries are the grid's own points taken in key order (neighbouring lanes walk neighbouring cells).  Isolated points whose search
+// would pass kKnnMaxShell shells fall back to the scan of all points.
+constexpr int kKnnMaxShell = 6;
+
+__device__ __forceinline__ void knn_insert(double* bd, int& cnt, int k, double d2)
+{
+    if (cnt < k) {
+        int p = cnt++;
+        while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; --p; }
+        bd[p] = d2;
+    } else if (bd[k - 1] > d2) {
+        int p = k - 1;
+        while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; --p; }
+        bd[p] = d2;
+    }
+}
+
+__global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double* __restrict__ mean)
+{
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= g.n) return;
+    const double q[3] = {g.sorted[(size_t)i * 3], g.sorted[(size_t)i * 3 + 1], g.sorted[(size_t)i * 3 + 2]};
+    long c[3];
+    cell_of(q, g.origin, g.h, c);
+    double bd[kMaxNN];
+    int cnt = 0;
+    auto run = [&](long cx, long cy, long z0, long z1) {
+        if (cx < 0 || cx > 2097151 || cy < 0 || cy > 2097151) return;
+        z0 = z0 < 0 ? 0 : z0;
+        z1 = z1 > 2097151 ? 2097151 : z1;
+        if (z0 > z1) return;
+        const u64 k0 = pack_key(cx, cy, z0), k1 = pack_key(cx, cy, z1);
+        for (int j = lower_bound(g.keys, g.n, k0); j < g.n && g.keys[j] <= k1; ++j) {
+            const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
+            knn_insert(bd, cnt, k, (ex * ex + ey * ey) + ez * ez);
+        }
+    };
+    bool done = false;
+    for (long R = 0; R <= kKnnMaxShell && !done; ++R) {
+        for (long dx = -R; dx <= R; ++dx)
+            for (long dy = -R; dy <= R; ++dy) {
+                const bool edge = dx == -R || dx == R || dy == -R || dy == R;
+                if (edge) run(c[0] + dx, c[1] + dy, c[2] - R, c[2] + R);       // a whole new column of the shell
+                else { run(c[0] + dx, c[1] + dy, c[2] - R, c[2] - R); run(c[0] + dx, c[1] + dy, c[2] + R, c[2] + R); }   // its two caps (R >= 1 here)
+            }
+        const double bound = (double)R * g.h;
+        done = cnt == k && bd[k - 1] < bound * bound * (1.0 - 1e-12);
+    }
+    if (!done) {
+        cnt = 0;
+        for (int j = 0; j < g.n; ++j) {
+            const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
+            knn_insert(bd, cnt, k, (ex * ex + ey * ey) + ez * ez);
+        }
+    }
+    double sum = 0;
+    for (int p = 0; p < cnt; ++p) sum += sqrt(bd[p]);
+    mean[g.order[i]] = cnt ? sum / (double)cnt : -1.0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // generic fixed-order reduction of NV doubles per element: stage 1 -> part[blocks][NV], stage 2 -> out[NV]
 template <int NV, class F>
@@ -329,16 +396,19 @@ __device__ void reduce_stage1(int n, F value, double* part)
     }
 }
 
-__global__ void reduce_stage2(const double* __restrict__ part, int g, int nv, double* __restrict__ out)
+__global__ void reduce_stage2(const double* __restrict__ part, int g, int nv, double* __restrict__ out, const double* __restrict__ skip = nullptr)
 {
+    if (skip && skip[0] != 0.0) return;
     const int v = threadIdx.x;
     if (v < nv) { double s = 0; for (int b = 0; b < g; ++b) s += part[b * nv + v]; out[v] = s; }
 }
 
 // out: [0] count, [1] sum d^2, [2..4] sum s, [5..7] sum t, [8..16] sum s_a t_b (row a, col b)
 __global__ __launch_bounds__(kT) void p2p_sums_kernel(const double* __restrict__ src, const double* __restrict__ tgt, const int* __restrict__ corr,
-                                                      const double* __restrict__ d2, int n, double* __restrict__ part)
+                                                      const double* __restrict__ d2, int n, double* __restrict__ part,
+                                                      const double* __restrict__ skip = nullptr)
 {
+    if (skip && skip[0] != 0.0) return;
     reduce_stage1<17>(n, [&](int i, double* e) {
         const int j = corr[i];
         if (j < 0) return false;
@@ -353,8 +423,10 @@ __global__ __launch_bounds__(kT) void p2p_sums_kernel(const double* __restrict__
 // out: [0] count, [1] sum d^2, [2..22] upper triangle of J^T J (row major), [23..28] J^T r
 __global__ __launch_bounds__(kT) void p2plane_sums_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
                                                           const double* __restrict__ tn, const int* __restrict__ corr,
-                                                          const double* __restrict__ d2, int n, double* __restrict__ part)
+                                                          const double* __restrict__ d2, int n, double* __restrict__ part,
+                                                          const double* __restrict__ skip = nullptr)
 {
+    if (skip && skip[0] != 0.0) return;
     reduce_stage1<29>(n, [&](int i, double* e) {
         const int j = corr[i];
         if (j < 0) return false;
@@ -548,6 +620,14 @@ extern "C" int ape_knn_mean_dist_f64(const double* pts, int n, int k, double* me
     return ape::check_launch("ape_knn_mean_dist_f64");
 }
 
+extern "C" int ape_grid_knn_mean_dist_f64(GRID_ARGS, int k, double* mean, void* stream)
+{
+    if (!sorted || !keys || !order || !origin3 || !mean || n < 1 || k < 1 || k > kMaxNN || k > n || !(cell > 0)) return APE_EINVAL;
+    MAKE_GRID;
+    hipLaunchKernelGGL(knn_mean_grid_kernel, dim3(ape::ceil_div(n, kT)), dim3(kT), 0, (hipStream_t)stream, g, k, mean);
+    return ape::check_launch("ape_grid_knn_mean_dist_f64");
+}
+
 /* kind 0: point-to-point sums out[17]; kind 1: point-to-plane out[29] (needs tgt_normals); kind 2: moments of src, out[9] */
 extern "C" int ape_icp_sums_f64(int kind, const double* src, const double* tgt, const double* tgt_normals, const int* corr,
                                 const double* dist2, int n, double* out, void* ws, size_t ws_bytes, void* stream)
@@ -588,4 +668,186 @@ extern "C" int ape_select_points_f64(const double* pts, const uint8_t* keep, int
     if (hipcub::DeviceSelect::Flagged(ws, tb, hipcub::CountingInputIterator<int>(0), keep, sel_idx, n_out, n, st) != hipSuccess) return APE_ELAUNCH;
     hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pts, sel_idx, n_out, out);
     return ape::check_launch("ape_select_points_f64");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ICP iteration entirely on the device (open3d 0.9 RegistrationICP as called at pc_reconstruction/open3d_utils.py:96-117): the
+// correspondence search and the 17 / 29 reduced sums were device work already; here the 3x3 SVD (Umeyama, point-to-point) / the 6x6
+// solve (point-to-plane), the composition T <- update . T, the fitness / rmse bookkeeping and the convergence test run in a
+// one-thread kernel between them, so a registration needs ONE device-to-host copy (its result) instead of one per iteration.
+// state[40]: [0] done, [1] updates applied, [2] fitness, [3] inlier rmse, [4] correspondences, [5..20] T (row major), [21..36] the
+// last update, [37] 1 = converged by the relative criteria, 2 = too few correspondences, 3 = iteration limit.
+namespace {
+
+__device__ void svd3_rotation(const double C[3][3], double R[3][3])
+{
+    // R = U diag(1, 1, det(U) det(V)) V^T for C = U S V^T (Eigen::umeyama without scaling).  One-sided (Hestenes) Jacobi: rotate
+    // column pairs of A = C until orthogonal: A V' = U S.
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = C[i][j];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 3; ++k) { alpha += A[k][p] * A[k][p]; beta += A[k][q] * A[k][q]; gamma += A[k][p] * A[k][q]; }
+                if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+                off += fabs(gamma);
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < 3; ++k) {
+                    const double ap = A[k][p], aq = A[k][q];
+                    A[k][p] = c * ap - sn * aq; A[k][q] = sn * ap + c * aq;
+                    const double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - sn * vq; V[k][q] = sn * vp + c * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    double sig[3];
+    for (int j = 0; j < 3; ++j) sig[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    int ord[3] = {0, 1, 2};                               // descending singular values
+    for (int a = 0; a < 2; ++a) for (int b2 = a + 1; b2 < 3; ++b2) if (sig[ord[b2]] > sig[ord[a]]) { const int t = ord[a]; ord[a] = ord[b2]; ord[b2] = t; }
+    double U[3][3], W[3][3];
+    for (int j = 0; j < 3; ++j) {
+        const int o = ord[j];
+        for (int k = 0; k < 3; ++k) { W[k][j] = V[k][o]; U[k][j] = sig[o] > 0 ? A[k][o] / sig[o] : 0.0; }
+    }
+    const double tiny = 1e-13 * (sig[ord[0]] > 0 ? sig[ord[0]] : 1.0);
+    if (sig[ord[1]] <= tiny) {                            // rank <= 1: complete U with any orthonormal pair
+        double e[3] = {fabs(U[0][0]) < 0.9 ? 1.0 : 0.0, fabs(U[0][0]) < 0.9 ? 0.0 : 1.0, 0.0};
+        double d = e[0] * U[0][0] + e[1] * U[1][0] + e[2] * U[2][0];
+        double n2 = 0;
+        for (int k = 0; k < 3; ++k) { e[k] -= d * U[k][0]; n2 += e[k] * e[k]; }
+        for (int k = 0; k < 3; ++k) U[k][1] = e[k] / sqrt(n2);
+    }
+    if (sig[ord[2]] <= tiny) {                            // rank 2: third left vector = u0 x u1
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+    auto det3 = [](const double M[3][3]) {
+        return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+    };
+    const double s33 = det3(U) * det3(W) < 0 ? -1.0 : 1.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[i][j] = (U[i][0] * W[j][0] + U[i][1] * W[j][1]) + s33 * U[i][2] * W[j][2];
+}
+
+__device__ bool solve6(double M[6][7])
+{
+    // Gaussian elimination with partial pivoting on the augmented system (numpy.linalg.solve = LAPACK gesv); false when exactly singular
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r) if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (M[piv][c] == 0.0) return false;
+        if (piv != c) for (int k = 0; k < 7; ++k) { const double t = M[c][k]; M[c][k] = M[piv][k]; M[piv][k] = t; }
+        for (int r = c + 1; r < 6; ++r) {
+            const double f = M[r][c] / M[c][c];
+            for (int k = c; k < 7; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    for (int r = 5; r >= 0; --r) {
+        double v = M[r][6];
+        for (int k = r + 1; k < 6; ++k) v -= M[r][k] * M[k][6];
+        M[r][6] = v / M[r][r];
+    }
+    return true;
+}
+
+__global__ void icp_step_kernel(int kind, const double* __restrict__ s, double* __restrict__ st, int ns, double rel_fitness, double rel_rmse,
+                                int max_iteration)
+{
+    if (st[0] != 0.0) return;
+    const double n_corr = floor(s[0] + 0.5);
+    const double fitness = n_corr / (double)ns;
+    const double rmse = n_corr > 0 ? sqrt(s[1] / n_corr) : 0.0;
+    const bool first = st[1] == 0.0 && st[38] == 0.0;      // st[38]: set once the first evaluation has been recorded
+    const double pf = st[2], pr = st[3];
+    st[2] = fitness; st[3] = rmse; st[4] = n_corr; st[38] = 1.0;
+    if (!first && fabs(pf - fitness) < rel_fitness && fabs(pr - rmse) < rel_rmse) { st[0] = 1.0; st[37] = 1.0; return; }
+    if (st[1] >= (double)max_iteration) { st[0] = 1.0; st[37] = 3.0; return; }
+    if (n_corr < (kind == 0 ? 3.0 : 6.0)) { st[0] = 1.0; st[37] = 2.0; return; }
+    double U[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    if (kind == 0) {
+        const double n = s[0];
+        double mu_s[3], mu_t[3], C[3][3], R[3][3];
+        for (int a = 0; a < 3; ++a) { mu_s[a] = s[2 + a] / n; mu_t[a] = s[5 + a] / n; }
+        for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) C[a][b2] = s[8 + b2 * 3 + a] / n - mu_t[a] * mu_s[b2];     // (1/n) sum (t - mu_t)(s - mu_s)^T
+        svd3_rotation(C, R);
+        for (int a = 0; a < 3; ++a) {
+            for (int b2 = 0; b2 < 3; ++b2) U[a][b2] = R[a][b2];
+            U[a][3] = mu_t[a] - ((R[a][0] * mu_s[0] + R[a][1] * mu_s[1]) + R[a][2] * mu_s[2]);
+        }
+    } else {
+        double M[6][7];
+        int k = 2;
+        for (int a = 0; a < 6; ++a) for (int b2 = a; b2 < 6; ++b2) { M[a][b2] = M[b2][a] = s[k]; ++k; }
+        for (int a = 0; a < 6; ++a) M[a][6] = -s[23 + a];
+        if (solve6(M)) {
+            const double x[6] = {M[0][6], M[1][6], M[2][6], M[3][6], M[4][6], M[5][6]};
+            const double cx = cos(x[0]), sx = sin(x[0]), cy = cos(x[1]), sy = sin(x[1]), cz = cos(x[2]), sz = sin(x[2]);
+            // TransformVector6dToMatrix4d: R = Rz(x2) Ry(x1) Rx(x0)
+            const double Rx[3][3] = {{1, 0, 0}, {0, cx, -sx}, {0, sx, cx}}, Ry[3][3] = {{cy, 0, sy}, {0, 1, 0}, {-sy, 0, cy}}, Rz[3][3] = {{cz, -sz, 0}, {sz, cz, 0}, {0, 0, 1}};
+            double T1[3][3];
+            for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) T1[a][b2] = (Rz[a][0] * Ry[0][b2] + Rz[a][1] * Ry[1][b2]) + Rz[a][2] * Ry[2][b2];
+            for (int a = 0; a < 3; ++a) {
+                for (int b2 = 0; b2 < 3; ++b2) U[a][b2] = (T1[a][0] * Rx[0][b2] + T1[a][1] * Rx[1][b2]) + T1[a][2] * Rx[2][b2];
+                U[a][3] = x[3 + a];
+            }
+        }
+    }
+    double T[4][4], Tn[4][4];
+    for (int a = 0; a < 4; ++a) for (int b2 = 0; b2 < 4; ++b2) T[a][b2] = st[5 + a * 4 + b2];
+    for (int a = 0; a < 4; ++a)
+        for (int b2 = 0; b2 < 4; ++b2) Tn[a][b2] = ((U[a][0] * T[0][b2] + U[a][1] * T[1][b2]) + U[a][2] * T[2][b2]) + U[a][3] * T[3][b2];
+    for (int a = 0; a < 4; ++a) for (int b2 = 0; b2 < 4; ++b2) { st[5 + a * 4 + b2] = Tn[a][b2]; st[21 + a * 4 + b2] = U[a][b2]; }
+    st[1] += 1.0;
+}
+
+__global__ void icp_transform_kernel(double* __restrict__ pts, int n, const double* __restrict__ st)
+{
+    if (st[0] != 0.0) return;
+    const double* T = st + 21;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        for (int r = 0; r < 3; ++r) pts[i * 3 + r] = ((T[r * 4] * x + T[r * 4 + 1] * y) + T[r * 4 + 2] * z) + T[r * 4 + 3];
+    }
+}
+
+}  // namespace
+
+/* Enqueue `n_iter` ICP iterations (kind 0 point-to-point, 1 point-to-plane) with everything on the device; see the block comment above.
+ * `src` [ns][3] is the source ALREADY transformed by the initial guess and is updated in place; `state` [40] doubles on the device: the
+ * caller zeroes it and writes the initial T into state[5..20] before the FIRST call of a registration (first_call = 1 also runs the
+ * evaluation that precedes open3d's loop), and reads it back (one copy) after each call: state[0] != 0 means finished.  Grid arguments:
+ * the target's search grid from ape_grid_build_f64 (cell >= max_dist).  ws: n-blocks x 29 doubles as for ape_icp_sums_f64. */
+extern "C" int ape_icp_run_f64(int kind, GRID_ARGS, double* src, int ns, const double* tgt, const double* tgt_normals, double max_dist,
+                               double rel_fitness, double rel_rmse, int max_iteration, int n_iter, int first_call, int* corr, double* dist2,
+                               double* sums, double* state, void* ws, size_t ws_bytes, void* stream)
+{
+    if (kind < 0 || kind > 1 || !sorted || !keys || !order || !origin3 || !src || !tgt || !corr || !dist2 || !sums || !state || !ws) return APE_EINVAL;
+    if (kind == 1 && !tgt_normals) return APE_EINVAL;
+    if (n < 1 || ns < 1 || max_dist > cell || n_iter < 0 || max_iteration < 0) return APE_EINVAL;
+    const int nv = kind == 0 ? 17 : 29;
+    const int nb = grid_for(ns, 512);
+    if (ws_bytes < (size_t)nb * nv * 8) return APE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    MAKE_GRID;
+    double* part = (double*)ws;
+    auto evaluate = [&]() {
+        hipLaunchKernelGGL(nn1_kernel, dim3(grid_for(ns)), dim3(kT), 0, st, g, (const double*)src, ns, max_dist * max_dist, corr, dist2, (const double*)state);
+        if (kind == 0) hipLaunchKernelGGL(p2p_sums_kernel, dim3(nb), dim3(kT), 0, st, (const double*)src, tgt, (const int*)corr, (const double*)dist2, ns, part, (const double*)state);
+        else hipLaunchKernelGGL(p2plane_sums_kernel, dim3(nb), dim3(kT), 0, st, (const double*)src, tgt, tgt_normals, (const int*)corr, (const double*)dist2, ns, part, (const double*)state);
+        hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(64), 0, st, (const double*)part, nb, nv, sums, (const double*)state);
+    };
+    if (first_call) evaluate();
+    for (int it = 0; it < n_iter; ++it) {
+        hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(1), 0, st, kind, (const double*)sums, state, ns, rel_fitness, rel_rmse, max_iteration);
+        hipLaunchKernelGGL(icp_transform_kernel, dim3(grid_for(ns)), dim3(kT), 0, st, src, ns, (const double*)state);
+        evaluate();
+    }
+    return ape::check_launch("ape_icp_run_f64");
 }

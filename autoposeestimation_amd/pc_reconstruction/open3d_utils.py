@@ -91,7 +91,7 @@ def icp_regression(target, source, voxel_size=5, threshold=100, global_regressio
 def _post_filter(cloud, min_friends, min_dist, nb_neighbors):
     cloud, _ = cloud.remove_radius_outlier(nb_points=min_friends, radius=min_dist)
     std_ratio = np.abs(np.std(np.abs(np.array(cloud.compute_mahalanobis_distance()))))
-    cloud, _ = cloud.remove_statistical_outlier(nb_neighbors=nb_neighbors, std_ratio=std_ratio)
+    cloud, _ = cloud.remove_statistical_outlier(nb_neighbors=nb_neighbors, std_ratio=std_ratio, cell_hint=min_dist)
     return cloud
 
 

@@ -166,6 +166,14 @@ class PointCloud:
         _lib.check(rc, "ape_grid_build_f64")
         return g
 
+    def _safe_cell(self, cell):
+        """a k-NN cell size that keeps every cell coordinate inside the 21-bit key range (the shell bound needs unclamped cells)"""
+        cell = float(cell)
+        if len(self) * cell > 0 and cell < 1e-3:           # only tiny cells can overflow 2^21 cells per axis: check the extent then
+            ext = float((self._p.max(0).values - self._p.min(0).values).max().item())
+            cell = max(cell, ext / 1048576.0)
+        return cell
+
     @staticmethod
     def _gargs(g):
         return (_lib.dptr(g["sorted"]), _lib.dptr(g["keys"]), _lib.dptr(g["order"]), _lib.dptr(g["origin"]), g["n"], g["cell"])
@@ -195,15 +203,25 @@ class PointCloud:
         _lib.check(rc, "ape_grid_radius_count_f64")
         return self._select((count > int(nb_points)).to(torch.uint8))
 
-    def remove_statistical_outlier(self, nb_neighbors, std_ratio):
+    def remove_statistical_outlier(self, nb_neighbors, std_ratio, cell_hint=None):
         """open3d 0.9 RemoveStatisticalOutliers: mean distance to the nb_neighbors nearest (self included) must be
-        < cloud mean + std_ratio * sample std; -> (cloud, kept indices)"""
+        < cloud mean + std_ratio * sample std; -> (cloud, kept indices).  The k-NN search walks a uniform grid (exact for any cell
+        size, ape_grid_knn_mean_dist_f64); `cell_hint` = a radius expected to hold the k neighbours (get_surface passes the radius of
+        the radius-outlier filter that ran just before), otherwise it is derived from the cloud's extent and point count."""
         n = len(self)
         if n == 0:
             return PointCloud(device=self.device), []
+        k = int(min(nb_neighbors, n))
         mean = torch.empty(n, dtype=_D, device=self.device)
-        rc = _lib.lib().ape_knn_mean_dist_f64(_lib.dptr(self._p, _D), n, int(min(nb_neighbors, n)), _lib.dptr(mean), _st())
-        _lib.check(rc, "ape_knn_mean_dist_f64")
+        if cell_hint is None:
+            ext = (self._p.max(0).values - self._p.min(0).values).cpu().numpy()
+            area = ext[0] * ext[1] + ext[1] * ext[2] + ext[0] * ext[2]       # a surface scan: ~n / area points per unit area
+            cell_hint = math.sqrt(max(k * area / (3.0 * n), 1e-300))
+            if not (cell_hint > 0 and math.isfinite(cell_hint)):
+                cell_hint = 1.0
+        g = self._grid(self._safe_cell(cell_hint))
+        rc = _lib.lib().ape_grid_knn_mean_dist_f64(*self._gargs(g), k, _lib.dptr(mean), _st())
+        _lib.check(rc, "ape_grid_knn_mean_dist_f64")
         m = mean.cpu().numpy()
         valid = m >= 0
         cloud_mean = m[valid].sum() / max(int(valid.sum()), 1)
@@ -300,10 +318,15 @@ def _point_to_plane(s):
     return _vec6_to_mat4(x)
 
 
-def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None):
+_ICP_CHUNK = 6            # iterations enqueued per device round trip; the reference's criteria (1e-2 relative) stop after 2-4
+
+
+def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None, host_solve=False):
     """open3d 0.9 registration::RegistrationICP (call sites open3d_utils.py:56-58,98-117).  The source cloud is NOT
-    modified (open3d works on a transformed copy).  One small D2H per iteration (the 17/29 reduced doubles) drives the
-    host-side 3x3 SVD / 6x6 solve and the convergence test."""
+    modified (open3d works on a transformed copy).  The whole iteration -- correspondence search, the 17/29 reduced sums, the
+    3x3 SVD / 6x6 solve, T <- update . T and the convergence test -- runs on the device (ape_icp_run_f64): a chunk of iterations
+    is enqueued at once, launches after convergence are no-ops, and the 40-double state comes back once per chunk (normally once
+    per registration).  `host_solve=True` keeps the round-1 loop (numpy SVD / solve, one D2H per iteration) for the parity tests."""
     estimation_method = estimation_method or TransformationEstimationPointToPoint()
     criteria = criteria or ICPConvergenceCriteria()
     T = np.eye(4) if init is None else np.array(init, dtype=np.float64)
@@ -320,6 +343,24 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
     sums = torch.empty(29, dtype=_D, device=dev)
     ws = torch.empty(512 * 29 * 8, dtype=torch.uint8, device=dev)
     L = _lib.lib()
+    if not host_solve:
+        st0 = np.zeros(40)
+        st0[5:21] = T.reshape(-1)
+        state = torch.from_numpy(st0).to(dev)
+        left, first, chunk = int(criteria.max_iteration) + 1, 1, _ICP_CHUNK     # +1: the step that notices the iteration limit
+        while True:
+            n_it = min(chunk, left)
+            _lib.check(L.ape_icp_run_f64(estimation_method.kind, *PointCloud._gargs(grid), _lib.dptr(pcd._p, _D), ns, _lib.dptr(target._p, _D),
+                                         _lib.dptr(target._n), float(max_correspondence_distance), float(criteria.relative_fitness),
+                                         float(criteria.relative_rmse), int(criteria.max_iteration), n_it, first, _lib.dptr(corr), _lib.dptr(d2),
+                                         _lib.dptr(sums), _lib.dptr(state, _D), _lib.dptr(ws), ws.numel(), _st()), "ape_icp_run_f64")
+            out = state.cpu().numpy()
+            left -= n_it
+            first = 0
+            if out[0] != 0.0 or left <= 0:
+                break
+            chunk *= 2
+        return RegistrationResult(out[5:21].reshape(4, 4).copy(), float(out[2]), float(out[3]), int(out[4]))
 
     def evaluate():
         _lib.check(L.ape_grid_nn1_f64(*PointCloud._gargs(grid), _lib.dptr(pcd._p, _D), ns, float(max_correspondence_distance),

@@ -294,11 +294,28 @@ int ape_grid_normals_f64(const double* sorted, const unsigned long long* keys, c
                          int n, double cell, const double* q, int nq, double radius, int max_nn, double* normals, void* stream);
 /* remove_statistical_outlier's per-point mean distance to its k nearest neighbours (self included)   :208-211 */
 int ape_knn_mean_dist_f64(const double* pts, int n, int k, double* mean, void* stream);
+/* The same means for the points of a grid-indexed cloud (the grid's own points are the queries), searched shell by shell through the
+ * uniform grid instead of over all pairs: bitwise equal to ape_knn_mean_dist_f64 for any cell size; fastest when a cell holds a few
+ * points (cell ~ the radius that contains k neighbours).  k <= 64, k <= n. */
+int ape_grid_knn_mean_dist_f64(const double* sorted, const unsigned long long* keys, const unsigned* order, const double* origin3,
+                               int n, double cell, int k, double* mean, void* stream);
 /* One-pass ICP reductions (bitwise reproducible).  kind 0: point-to-point (Umeyama) out[17] = count, sum d^2, sum s[3],
  * sum t[3], sum s_a t_b[9];  kind 1: point-to-plane out[29] = count, sum d^2, upper triangle of J^T J[21], J^T r[6];
  * kind 2: moments of src, out[9] = sum p[3], sum p_a p_b upper triangle[6] (get_center / compute_mahalanobis_distance). */
 int ape_icp_sums_f64(int kind, const double* src, const double* tgt, const double* tgt_normals, const int* corr,
                      const double* dist2, int n, double* out, void* ws, size_t ws_bytes, void* stream);
+/* registration_icp's LOOP on the device (open3d_utils.py:96-117; open3d 0.9 RegistrationICP): `n_iter` iterations of
+ * [step: fitness / rmse / convergence test, Umeyama 3x3 SVD (kind 0) or 6x6 solve (kind 1), T <- update . T] -> transform src by the
+ * update -> correspondence search -> reduced sums, enqueued at once; every launch is a no-op once state[0] != 0.  `src` is the
+ * source already moved by the initial guess, updated in place.  state[40] doubles on the device: [0] done, [1] updates applied,
+ * [2] fitness, [3] inlier rmse, [4] correspondences, [5..20] T row major, [21..36] last update, [37] stop reason (1 converged,
+ * 2 too few correspondences, 3 iteration limit), [38] internal.  Before the first call of a registration (first_call = 1) the caller
+ * zeroes it and writes the initial T; one copy of it back per call tells whether to enqueue more.  Grid arguments as above
+ * (cell >= max_dist); ws: 512 x 29 doubles.  sums[29], corr[ns], dist2[ns]: caller-owned scratch. */
+int ape_icp_run_f64(int kind, const double* sorted, const unsigned long long* keys, const unsigned* order, const double* origin3, int n,
+                    double cell, double* src, int ns, const double* tgt, const double* tgt_normals, double max_dist, double rel_fitness,
+                    double rel_rmse, int max_iteration, int n_iter, int first_call, int* corr, double* dist2, double* sums, double* state,
+                    void* ws, size_t ws_bytes, void* stream);
 /* compute_mahalanobis_distance    mean_cinv12_host = (mean[3], inverse covariance[9]) */
 int ape_mahalanobis_f64(const double* pts, int n, const double* mean_cinv12_host, double* out, void* stream);
 /* ordered row selection (outlier filters): out = pts[keep != 0], sel_idx = kept indices, *n_out on the device */

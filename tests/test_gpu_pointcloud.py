@@ -85,6 +85,27 @@ def test_normals_match_oracle_up_to_sign_rule():
     assert (got[:, 2] >= 0).all()
 
 
+@pytest.mark.parametrize("cell", [0.7, 5.0, 60.0, 1e4])
+def test_grid_knn_mean_is_bitwise_the_all_pairs_result(cell):
+    """remove_statistical_outlier's k-NN means through the uniform grid (shell search, any cell size, isolated points included)
+    against the all-pairs kernel it replaced: identical bits."""
+    import torch
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    rng = np.random.default_rng(12)
+    pts = np.concatenate([PO.voxel_down_sample(_bumpy_sphere(30000, 9), 2.0), rng.uniform(-500, 900, (40, 3)),
+                          np.repeat(rng.uniform(0, 1, (3, 3)), 5, 0)])          # surface + far strays + exact duplicates
+    pc = PC.PointCloud(pts)
+    n = len(pc)
+    for k in (1, 20, 64):
+        a = torch.empty(n, dtype=torch.float64, device="cuda")
+        b = torch.empty(n, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().ape_knn_mean_dist_f64(_lib.dptr(pc._p, torch.float64), n, k, _lib.dptr(a), None), "knn")
+        g = pc._grid(cell)
+        _lib.check(_lib.lib().ape_grid_knn_mean_dist_f64(*PC.PointCloud._gargs(g), k, _lib.dptr(b), None), "grid knn")
+        assert torch.equal(a, b), (cell, k, int((a != b).sum()))
+
+
 @pytest.mark.parametrize("point_to_plane", [False, True])
 def test_icp_matches_oracle_and_recovers_known_transform(point_to_plane):
     from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
@@ -121,6 +142,55 @@ def test_icp_exact_recovery_on_identical_sampling():
         res = PC.registration_icp(PC.PointCloud(src), target, 10.0, np.eye(4), est, crit)
         np.testing.assert_allclose(res.transformation, T_true, atol=1e-6)
         assert res.fitness == 1.0 and res.inlier_rmse < 1e-6
+
+
+@pytest.mark.parametrize("point_to_plane", [False, True])
+@pytest.mark.parametrize("crit", [(1e-2, 1e-2, 100), (1e-9, 1e-9, 60), (1e-12, 1e-12, 3), (0.0, 0.0, 0)])
+def test_icp_device_loop_equals_host_solve(point_to_plane, crit):
+    """The on-device iteration (Jacobi 3x3 SVD / 6x6 elimination, convergence test, T composition in icp_step_kernel) against the
+    round-1 loop that brings the sums to the host every iteration and solves with LAPACK: same stopping iteration (fitness and the
+    correspondence count equal), transforms to 1e-11 (the kernels before the solve are shared and bitwise reproducible)."""
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    tgt = PO.voxel_down_sample(_bumpy_sphere(20000, 15), 3.0)
+    T_true = _rot(0.05, -0.02, 0.03, (1.5, -2.5, 2.0))
+    src = PO.voxel_down_sample(_bumpy_sphere(15000, 16), 3.0)
+    src = (src - T_true[:3, 3]) @ T_true[:3, :3]
+    target = PC.PointCloud(tgt).estimate_normals(PC.KDTreeSearchParamHybrid(radius=9.0, max_nn=30))
+    est = PC.TransformationEstimationPointToPlane() if point_to_plane else PC.TransformationEstimationPointToPoint()
+    c = PC.ICPConvergenceCriteria(*crit)
+    init = _rot(0.01, 0.0, -0.01, (0.5, 0.0, 0.0))
+    a = PC.registration_icp(PC.PointCloud(src), target, 10.0, init, est, c)
+    b = PC.registration_icp(PC.PointCloud(src), target, 10.0, init, est, c, host_solve=True)
+    assert a.fitness == b.fitness and a.correspondence_count == b.correspondence_count
+    np.testing.assert_allclose(a.transformation, b.transformation, rtol=0, atol=1e-11)
+    assert abs(a.inlier_rmse - b.inlier_rmse) < 1e-11
+    R = a.transformation[:3, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-13)
+    assert abs(np.linalg.det(R) - 1) < 1e-13
+
+
+def test_icp_device_loop_degenerate_inputs():
+    """too few correspondences (stops before any update, T = init), a planar pair (rank-2 covariance in Umeyama: the reflection
+    guard must still return a proper rotation) and a long chain of chunks (more iterations than one enqueue)."""
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    rng = np.random.default_rng(3)
+    far = PC.PointCloud(rng.random((200, 3)) + 1000.0)
+    near = PC.PointCloud(rng.random((300, 3)))
+    init = _rot(0.1, 0.2, 0.3, (1, 2, 3))
+    r = PC.registration_icp(far, near, 0.5, init)
+    assert r.fitness == 0.0 and r.inlier_rmse == 0.0 and np.array_equal(r.transformation, init)
+    # planar clouds: z = 0 grid, source = rotated about z and shifted in the plane
+    g = np.stack(np.meshgrid(np.arange(40.0), np.arange(30.0), indexing="ij"), -1).reshape(-1, 2)
+    g = g + 0.2 * np.sin(g[:, ::-1])
+    plane = np.concatenate([g, np.zeros((len(g), 1))], 1)
+    T_true = _rot(0.0, 0.0, 0.03, (0.2, -0.1, 0.0))
+    src = (plane - T_true[:3, 3]) @ T_true[:3, :3]
+    c = PC.ICPConvergenceCriteria(1e-14, 1e-14, 50)
+    a = PC.registration_icp(PC.PointCloud(src), PC.PointCloud(plane), 2.0, np.eye(4), None, c)
+    b = PC.registration_icp(PC.PointCloud(src), PC.PointCloud(plane), 2.0, np.eye(4), None, c, host_solve=True)
+    np.testing.assert_allclose(a.transformation, b.transformation, atol=1e-10)
+    np.testing.assert_allclose(a.transformation, T_true, atol=1e-8)
+    assert abs(np.linalg.det(a.transformation[:3, :3]) - 1) < 1e-12
 
 
 def test_get_surface_and_sequential_fusion():
