@@ -101,9 +101,9 @@ def load_point_cloud(object_name, save_dir, root, reference_point=np.array([0, 0
     `<obj>_out.{pcd,ply}`, the centred `<obj>.{pcd,ply}` and the >= 1000-point `<obj>.xyz`.  Returns the `_out` cloud.
 
     `dist` (an initialised torch.distributed module; one process per GPU, shared file system): the rotation directories are the
-    CHAINS -- directory i is fused by rank i % world -- the decode + get_surface work of every chain's views is spread over all ranks
-    (each rank reads only the PNGs of its share; one padded all-gather per chain), the per-directory clouds go to rank 0 with one more
-    gather, and rank 0 aligns and exports (it alone returns the cloud; the others return None).  `rng` must then be seeded identically
+    CHAINS -- directory i is fused by rank i % world -- the decode + get_surface work of all chains' views is spread over all ranks
+    (each rank reads only the PNGs of its share; ONE padded all-gather), the owners then fuse their directories side by side
+    (open3d_utils.fuse_chains), the per-directory clouds go to rank 0 with one more gather, and rank 0 aligns and exports (it alone returns the cloud; the others return None).  `rng` must then be seeded identically
     on all ranks (the view selection draws from it)."""
     from autoposeestimation_amd import sharding
     from autoposeestimation_amd.data_generation import sample_io as io
@@ -118,9 +118,8 @@ def load_point_cloud(object_name, save_dir, root, reference_point=np.array([0, 0
     pcd_path = os.path.join(save_dir, object_name)
     os.makedirs(pcd_path, exist_ok=True)
     n = len([f for f in os.listdir(os.path.join(object_label_path, dirs[0])) if ".{}.label.png".format(mode) in f])
-    mine = []
+    chains, tfs = [], []
     for di, d in enumerate(dirs):
-        owner = sharding.chain_owner(di, world)
         metas = [io.read_meta(os.path.join(data_path, d), "{:06d}".format(i)) for i in range(n)]
         cams = np.array([io.robot2cam(m)[:3, 3] for m in metas])
         views, tf = [], None
@@ -133,15 +132,21 @@ def load_point_cloud(object_name, save_dir, root, reference_point=np.array([0, 0
                         io.robot2cam(meta))
             views.append(decode)
         intr = metas[0].get("intr")
-        cloud, _ = fuse_direction(views, intr, point_cloud_tf=tf, voxel_size=voxel_size, threshold=threshold, min_friends=min_friends,
-                                  min_dist=min_dist, nb_neighbors=nb_neighbors, icp_point2point=icp_point2point,
-                                  icp_point2plane=icp_point2plane, dist=dist if dist_on else None, owner=owner)
-        if rank != owner:
-            continue
+        chains.append(views)
+        tfs.append(tf)
+    # all directories at once: per-view work of every chain over all ranks, one all-gather, then the owners fuse side by side
+    fused = utils.fuse_chains(chains, intr, voxel_size=voxel_size, threshold=threshold, min_friends=min_friends, min_dist=min_dist,
+                              nb_neighbors=nb_neighbors, icp_point2point=icp_point2point, icp_point2plane=icp_point2plane,
+                              dist=dist if dist_on else None)
+    mine = []
+    for di in sorted(fused):
+        cloud, _ = fused[di]
         if cloud is None:
-            raise ValueError("no valid surface in %s/%s" % (object_name, d))
-        pc.write_point_cloud(os.path.join(pcd_path, "{}.pcd".format(d)), cloud)
-        pc.write_point_cloud(os.path.join(pcd_path, "{}.ply".format(d)), cloud)
+            raise ValueError("no valid surface in %s/%s" % (object_name, dirs[di]))
+        if tfs[di] is not None:
+            cloud.rotate(R=np.asarray(tfs[di], dtype=np.float64)[:3, :3], center=True)        # as fuse_direction (reference :320)
+        pc.write_point_cloud(os.path.join(pcd_path, "{}.pcd".format(dirs[di])), cloud)
+        pc.write_point_cloud(os.path.join(pcd_path, "{}.ply".format(dirs[di])), cloud)
         mine.append((di, cloud._p))
     sets = sharding.gather_point_sets(mine, len(dirs), dist if dist_on else None)
     if rank != 0:

@@ -152,8 +152,13 @@ def fuse_views(views, intr, voxel_size=2, threshold=10, min_friends=20, min_dist
     ranks and one padded all-gather hands the surfaces to the chain's `owner`, which fuses them (SURVEY.md 8e; sharding.sharded_chain);
     the other ranks return (None, None).  The result on the owner is bit-identical to the single-rank call."""
     from autoposeestimation_amd import sharding
-    views = list(views)
+    make_set, fuse = _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point,
+                                    icp_point2plane)
+    res = sharding.sharded_chain(list(views), make_set, fuse, owner, dist)
+    return res if res is not None else (None, None)
 
+
+def _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point, icp_point2plane):
     def make_set(view):
         label, depth, robot2cam = view() if callable(view) else view       # a callable decodes its files only on the rank that owns the view
         return get_surface(label, depth, intr, robot2cam, min_friends, min_dist, nb_neighbors, voxel_size)._p
@@ -167,9 +172,19 @@ def fuse_views(views, intr, voxel_size=2, threshold=10, min_friends=20, min_dist
             clouds.append(c)
         return fuse_surfaces(clouds, voxel_size=voxel_size, threshold=threshold, voxel_size_out=voxel_size_out,
                              icp_point2point=icp_point2point, icp_point2plane=icp_point2plane)
+    return make_set, fuse
 
-    res = sharding.sharded_chain(views, make_set, fuse, owner, dist)
-    return res if res is not None else (None, None)
+
+def fuse_chains(chains, intr, voxel_size=2, threshold=10, min_friends=20, min_dist=5, nb_neighbors=20, voxel_size_out=None,
+                icp_point2point=True, icp_point2plane=False, dist=None):
+    """`fuse_views` for several (object, direction) chains at once (`chains` = list of view lists): the get_surface work of all views
+    of all chains is spread over the ranks, one padded all-gather, then every rank runs the sequential fusion of the chains it owns
+    (chain i -> rank i % world) -- the chains' ICP sequences proceed in parallel on different GPUs.
+    Returns {chain index: (cloud, [T per view])} for this rank's chains; each is bit-identical to the single-rank fuse_views of it."""
+    from autoposeestimation_amd import sharding
+    make_set, fuse = _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point,
+                                    icp_point2plane)
+    return sharding.sharded_chains([list(v) for v in chains], make_set, fuse, dist)
 
 
 import torch  # noqa: E402

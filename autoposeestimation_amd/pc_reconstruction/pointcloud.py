@@ -318,6 +318,7 @@ def _point_to_plane(s):
     return _vec6_to_mat4(x)
 
 
+ICP_STATS = None          # bench.py --workload label sets a dict here: registrations, evaluations, point pairs, (start, end) events
 _ICP_CHUNK = 6            # iterations enqueued per device round trip; the reference's criteria (1e-2 relative) stop after 2-4
 
 
@@ -348,6 +349,9 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
         st0[5:21] = T.reshape(-1)
         state = torch.from_numpy(st0).to(dev)
         left, first, chunk = int(criteria.max_iteration) + 1, 1, _ICP_CHUNK     # +1: the step that notices the iteration limit
+        if ICP_STATS is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         while True:
             n_it = min(chunk, left)
             _lib.check(L.ape_icp_run_f64(estimation_method.kind, *PointCloud._gargs(grid), _lib.dptr(pcd._p, _D), ns, _lib.dptr(target._p, _D),
@@ -360,6 +364,14 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
             if out[0] != 0.0 or left <= 0:
                 break
             chunk *= 2
+        if ICP_STATS is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            ICP_STATS["registrations"] += 1
+            ICP_STATS["evaluations"] += int(out[1]) + 1
+            ICP_STATS["pairs"] += (int(out[1]) + 1) * ns
+            ICP_STATS["kind%d" % estimation_method.kind] = ICP_STATS.get("kind%d" % estimation_method.kind, 0) + (int(out[1]) + 1) * ns
+            ICP_STATS["events"].append((ev0, ev1))
         return RegistrationResult(out[5:21].reshape(4, 4).copy(), float(out[2]), float(out[3]), int(out[4]))
 
     def evaluate():
@@ -391,13 +403,19 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
 def surface_points(label, depth, intr, robot2cam, device="cuda"):
     """label u8[H,W], depth (integer sensor units) [H,W] -> PointCloud of the valid pixels in the robot frame (mm)."""
     dev = torch.device(device)
-    lab = torch.as_tensor(np.ascontiguousarray(np.asarray(label, dtype=np.uint8))).to(dev)
-    d = np.asarray(depth)
-    if d.dtype != np.uint16:
-        if (d < 0).any() or (d > 65535).any() or (d != np.floor(d)).any():
-            raise ValueError("depth must hold integer sensor units in 0..65535")
-        d = d.astype(np.uint16)
-    dep = torch.from_numpy(np.ascontiguousarray(d)).to(dev)
+    if torch.is_tensor(label) and torch.is_tensor(depth) and label.is_cuda and depth.is_cuda:
+        # views already resident in HBM
+        if label.dtype != torch.uint8 or depth.dtype != torch.uint16:
+            raise ValueError("resident views must be uint8 labels and uint16 depth")
+        lab, dep, dev = label.contiguous(), depth.contiguous(), label.device
+    else:
+        lab = torch.as_tensor(np.ascontiguousarray(np.asarray(label, dtype=np.uint8))).to(dev)
+        d = np.asarray(depth)
+        if d.dtype != np.uint16:
+            if (d < 0).any() or (d > 65535).any() or (d != np.floor(d)).any():
+                raise ValueError("depth must hold integer sensor units in 0..65535")
+            d = d.astype(np.uint16)
+        dep = torch.from_numpy(np.ascontiguousarray(d)).to(dev)
     h, w = lab.shape
     buf = torch.empty(h * w, 3, dtype=_D, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)

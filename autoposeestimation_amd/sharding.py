@@ -100,3 +100,23 @@ def sharded_chain(items, make_set, fuse, owner, dist=None):
     local = [(i, make_set(items[i])) for i in range(lo, hi)]
     sets = gather_point_sets(local, len(items), dist)
     return fuse(sets) if rank == owner else None
+
+
+def sharded_chains(chains, make_set, fuse, dist=None):
+    """Several chains at once: `chains` = list of item lists.  The per-item work of ALL chains is spread over the ranks as one flat
+    list (balanced even when chains differ in length), ONE padded all-gather distributes the sets, and then every rank fuses the
+    chains it owns (`chain_owner`) -- the sequential, order-dependent parts of different chains run side by side on different GPUs,
+    which a loop of `sharded_chain` calls cannot do (each of its all-gathers would wait for the previous chain's owner).
+    Returns {chain index: fuse(sets of that chain)} for the chains this rank owns."""
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    flat = [(ci, item) for ci, items in enumerate(chains) for item in items]
+    lo, hi = shard_range(len(flat), rank, world)
+    local = [(i, make_set(flat[i][1])) for i in range(lo, hi)]
+    sets = gather_point_sets(local, len(flat), dist)
+    out, pos = {}, 0
+    for ci, items in enumerate(chains):
+        if chain_owner(ci, world) == rank:
+            out[ci] = fuse(sets[pos:pos + len(items)])
+        pos += len(items)
+    return out

@@ -202,12 +202,132 @@ def kernel_peak(label):
     return "mfma", PEAK_BF16_MFMA_TFLOPS / (3.0 if split else 1.0), "TFLOP/s"
 
 
+# ---- --workload label: BASELINE configs[4] -------------------------------------------------------------------------------------
+LABEL_KW = dict(voxel_size=2, threshold=10, min_friends=20, min_dist=5, nb_neighbors=20, icp_point2point=True, icp_point2plane=True)
+# algorithmic HBM bytes per (source point, ICP evaluation), float64 xyz: transform 24 r + 24 w; correspondence search 24 r (query) +
+# 24 r (the nearest target, the grid walk's other candidates are not counted) + 12 w (index, distance); sums 24 r (source) + 12 r
+# (index, distance) + 24 r (target point) [+ 24 r target normal for point-to-plane]
+ICP_BYTES_PER_PAIR = {0: 168, 1: 192}
+
+
+def label_cpu_baseline(views_np, n_views=6):
+    """oracle/pointcloud_oracle (numpy + scipy cKDTree restatement of get_surface + the sequential p2p / p2plane fusion,
+    pc_reconstruction/open3d_utils.py:63-213, create_pointcloud.py:288-312) on the first `n_views` views of chain 0, one thread."""
+    from oracle import pointcloud_oracle as PO
+    model, phys, usable = _cpu_info()
+    t0 = time.time()
+    acc = None
+    for label, depth, cam in views_np[:n_views]:
+        p = PO.voxel_down_sample(PO.surface_points(label, depth, S.LABEL_INTR, cam), 2.0)
+        p = p[PO.radius_outlier_mask(p, 20, 5.0)]
+        mask, _ = PO.statistical_outlier_mask(p, 20, float(np.std(PO.mahalanobis(p))))
+        p = p[mask]
+        if acc is None:
+            acc = p
+            continue
+        tg, sr = PO.voxel_down_sample(acc, 2.0), PO.voxel_down_sample(p, 2.0)
+        nrm = PO.estimate_normals(tg, 4.0, 30)
+        T, _, _ = PO.registration_icp(sr, tg, 10.0, np.eye(4), False, None, 1e-2, 1e-2, 100)
+        T, _, _ = PO.registration_icp(sr, tg, 10.0, T, True, nrm, 1e-2, 1e-2, 100)
+        acc = PO.voxel_down_sample(np.concatenate([p @ T[:3, :3].T + T[:3, 3], acc]), 2.0)
+    dt = time.time() - t0
+    return {"value": round(n_views / dt, 3), "unit": "views/s", "cores": 1, "kind": "port", "cpu_model": model, "physical_cores": phys,
+            "usable_cpus": usable, "sample": "the first %d views of chain 0 through oracle/pointcloud_oracle (numpy + scipy cKDTree), one thread; "
+                                             "the chain is sequential, so it has no multi-core form short of running chains side by side" % n_views}, acc
+
+
+def label_main(args, rank, world, device, dist):
+    """configs[4]: pose-label generation.  A step = `--views` synthetic 640x480 views in chains of 25 (one chain = one (object,
+    direction) sequence of create_pointcloud.py:276-312): get_surface (back-projection, voxel / radius / statistical filters) for every
+    view, spread over the ranks; one padded all-gather; then the sequential p2p + point-to-plane ICP fusion of each chain on its
+    owner rank (chain i -> rank i % world).  Total work is fixed as ranks are added (strong scaling).  Views are resident in HBM."""
+    from autoposeestimation_amd.pc_reconstruction import open3d_utils as U
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    per_chain = 25
+    n_chains = max(1, args.views // per_chain)
+    cloud = S.bumpy_sphere(300000, 21)
+    chains_np = [S.label_views(per_chain, seed=c, cloud=cloud) for c in range(n_chains)]
+    chains = [[(torch.from_numpy(l).to(device), torch.from_numpy(d).to(device), cam) for (l, d, cam) in ch] for ch in chains_np]
+    n_views = n_chains * per_chain
+
+    def step():
+        return U.fuse_chains(chains, S.LABEL_INTR, dist=dist, **LABEL_KW)
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    PC.ICP_STATS = {"registrations": 0, "evaluations": 0, "pairs": 0, "events": []}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    stats, PC.ICP_STATS = PC.ICP_STATS, None
+    icp_ms = sum(a.elapsed_time(b) for a, b in stats["events"])
+    counts = torch.tensor([stats["registrations"], stats["evaluations"], stats["pairs"], stats.get("kind0", 0), stats.get("kind1", 0),
+                           sum(len(c) for c, _ in res.values())], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt, icp_ms], dtype=torch.float64, device=device)
+    if dist:
+        dist.all_reduce(counts)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt, icp_ms_max = float(tmax[0]), float(tmax[1])
+    if rank == 0:
+        regs, evals, pairs, p0, p1, fused_pts = [float(x) for x in counts]
+        icp_bytes = p0 * ICP_BYTES_PER_PAIR[0] + p1 * ICP_BYTES_PER_PAIR[1]
+        ach = icp_bytes / world / (icp_ms_max * 1e-3) / 1e9 if icp_ms_max else 0.0
+        line = {"metric": "pose-label views/sec (get_surface + sequential p2p + point-to-plane ICP fusion), 640x480 views",
+                "value": round(n_views * args.steps / dt, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "configs[4]: pose-label generation, %d synthetic 640x480 views of a 300k-point surface in %d chains of %d "
+                                       "(voxel 2 mm, radius + statistical outlier filters, p2p then point-to-plane ICP at 10 mm per view), views "
+                                       "resident in HBM" % (n_views, n_chains, per_chain),
+                           "parallelism": "per-view get_surface over %d ranks, 1 padded all_gather/step, chain i fused on rank i %% %d" % (world, world),
+                           "fused_points_last_step": int(fused_pts)},
+                "icp": {"registrations_per_s": round(regs / dt, 1), "evaluations_per_registration": round(evals / max(regs, 1), 2),
+                        "point_pairs_per_s": round(pairs / dt, 0)},
+                "roofline": {"kernel": "ICP registration (icp_step + icp_transform + nn1 + p2p/p2plane sums per evaluation)", "bound": "hbm",
+                             "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 5),
+                             "traffic": None, "share_of_step_time": round(icp_ms_max * 1e-3 / dt, 3),
+                             "note": "algorithmic bytes = point pairs x %d B (p2p) / %d B (p2plane), see ICP_BYTES_PER_PAIR; time = HIP events around "
+                                     "every registration on its stream (max over ranks).  The clouds hold ~10^4 points (240 KB): every kernel "
+                                     "of the chain is a few microseconds of work behind a dependent launch, so this stage is latency-bound by "
+                                     "construction and sits far below the HBM roofline; chains run side by side to use the GPU(s)"
+                                     % (ICP_BYTES_PER_PAIR[0], ICP_BYTES_PER_PAIR[1])}}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"], acc = label_cpu_baseline(chains_np[0])
+            # parity on the sample: the GPU fusion of the same first views against the oracle's
+            g, _ = U.fuse_views(chains[0][:6], S.LABEL_INTR, **LABEL_KW)
+            gp = np.asarray(g.points)
+            from scipy.spatial import cKDTree
+            d = cKDTree(acc).query(gp)[0]
+            line["parity"] = {"checker": "oracle/pointcloud_oracle on the cpu_baseline sample (6 views of chain 0)", "gpu_points": len(gp),
+                              "oracle_points": len(acc), "max_nn_distance_mm": round(float(d.max()), 6)}
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="BASELINE configs[3]: a step = this many frames in TOTAL, sharded over the ranks (strong scaling; each rank "
+                         "walks its share in sub-batches of --batch) with one all_gather of all poses per step.  0 = configs[2], "
+                         "--batch frames per GPU per step (weak scaling)")
+    ap.add_argument("--workload", default="frames", choices=["frames", "label"],
+                    help="frames: the live path (BASELINE metric).  label: configs[4], pose-label generation -- multi-view depth -> "
+                         "point-cloud fusion + point-to-plane ICP over --views synthetic views, sharded across the ranks")
+    ap.add_argument("--views", type=int, default=200, help="--workload label: views per step (one (object, direction) chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
                     help="(default) pose stage of step i on a second HIP stream beside the segmentation of step i+1 (software-pipelined "
@@ -232,17 +352,29 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.workload == "label":
+        return label_main(args, rank, world, device, dist)
 
     from autoposeestimation_amd.pipeline.utils import FramePipeline
-    frames = make_frames(args.batch, rank)
+    if args.frames:
+        if args.frames % world:
+            raise SystemExit("--frames %d does not divide over %d ranks" % (args.frames, world))
+        per_rank = args.frames // world
+        args.batch = min(args.batch, per_rank)
+        if per_rank % args.batch:
+            raise SystemExit("the rank's share of %d frames is not a multiple of --batch %d" % (per_rank, args.batch))
+    else:
+        per_rank = args.batch
+    n_chunks = per_rank // args.batch
+    frames = make_frames(per_rank, rank)
     # three primary colours (classes 1..3) that a LINEAR read-out of the frozen random features separates cleanly from the
     # grey-noise background AND from each other's blurred borders (six colours left ~10 spurious >100-px detections per 64
     # frames); channels 4..12 of the 13-way segmentor stay silent
     fit_frames = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 + 60 * c + 90 * k), size=(126, 126))
                   for c in range(1, 4) for k in range(2)]
     seg, est, ref, seg_sd, est_sd, ref_sd = build_models(device, fit_frames)
-    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device)        # inputs resident in HBM
-    depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device)
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device).split(args.batch)        # inputs resident in HBM
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device).split(args.batch)
     seg.set_precision(args.seg_precision)
     est.set_precision(args.pose_precision)
     ref.set_precision(args.pose_precision)
@@ -252,10 +384,16 @@ def main():
     pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap)
     from autoposeestimation_amd.sharding import gather_results
 
-    def tail(out):
-        # one result slot per frame: the largest detection (the painted object) wins the slot
+    step_poses = {}
+
+    def tail(out, item):
+        # one result slot per frame: the largest detection (the painted object) wins the slot.  The rank's poses of one step collect in
+        # one [per_rank, 1, 8] buffer; the step's single RCCL all_gather goes out after its last sub-batch.
+        step, chunk = item
         with torch.cuda.stream(out.get("stream") or torch.cuda.current_stream()):     # the pose results live on the pose stream
-            poses = torch.zeros(args.batch, 1, 8, dtype=torch.float32, device=device)
+            if chunk == 0:
+                step_poses[step] = torch.zeros(per_rank, 1, 8, dtype=torch.float32, device=device)
+            poses = step_poses[step][chunk * args.batch:(chunk + 1) * args.batch]
             if out["objects"]:
                 o = np.asarray(out["objects"], dtype=np.int64)
                 order = np.argsort(-(o[:, 3] - o[:, 2]) * (o[:, 5] - o[:, 4]), kind="stable")
@@ -265,23 +403,26 @@ def main():
                 t = torch.from_numpy(np.stack([frames_u, pick, o[pick, 1]])).pin_memory().to(device, non_blocking=True)
                 poses[t[0], 0, 0] = t[2].float()
                 poses[t[0], 0, 1:] = out["pose"][t[1]].float()
-            out["gathered"] = gather_results(poses, dist)   # the single RCCL collective of the path: (cls, q, t) per frame
+            if chunk == n_chunks - 1:
+                out["gathered"] = gather_results(step_poses.pop(step), dist)   # the single RCCL collective of the path: (cls, q, t) per frame
         return out
 
     def run_steps(first, count):
         """`count` steps (batches `first` .. `first + count - 1`), every one a full pass seg -> CCL -> crops -> PoseNet -> 2x refine ->
-        gather.  With the pose stream the loop is software-pipelined: the segmentation of step i+1 is enqueued BEFORE the host
-        waits for step i's detections, so the main stream never idles while the host enqueues step i's ~100 pose launches.
-        Exactly `count` segmentation stages and `count` pose stages are enqueued, all inside the caller's fences."""
+        gather over the rank's frames (in `n_chunks` sub-batches).  With the pose stream the loop is software-pipelined: the
+        segmentation of the next sub-batch is enqueued BEFORE the host waits for this one's detections, so the main stream never idles
+        while the host enqueues the ~100 pose launches.  Exactly `count * n_chunks` segmentation stages and as many pose stages are
+        enqueued, all inside the caller's fences."""
         out = None
+        items = [(i, c) for i in range(first, first + count) for c in range(n_chunks)]
         if not args.overlap:
-            for i in range(first, first + count):
-                out = tail(pipe.run(rgb, depth, S.REALSENSE_META, seed=i))
+            for (i, c) in items:
+                out = tail(pipe.run(rgb[c], depth[c], S.REALSENSE_META, seed=i), (i, c))
             return out
-        h = pipe.begin(rgb) if count else None
-        for i in range(first, first + count):
-            h_next = pipe.begin(rgb) if i + 1 < first + count else None
-            out = tail(pipe.finish(h, rgb, depth, S.REALSENSE_META, seed=i))
+        h = pipe.begin(rgb[items[0][1]]) if items else None
+        for k, (i, c) in enumerate(items):
+            h_next = pipe.begin(rgb[items[k + 1][1]]) if k + 1 < len(items) else None
+            out = tail(pipe.finish(h, rgb[c], depth[c], S.REALSENSE_META, seed=i), (i, c))
             h = h_next
         return out
 
@@ -364,21 +505,23 @@ def main():
                                 "dense peak / 3) or algorithmic bytes per launch / HIP-event time on the launch stream, timed region only; traffic = "
                                 "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), averaged over the kernel's shapes"
                                 + ("; --overlap: the pose stage of the previous step runs beside these kernels on a second stream" if args.overlap else ""))
-        total_frames = args.batch * world * args.steps
+        total_frames = per_rank * world * args.steps
         line = {
             "metric": "RGB-D frames/sec (seg+DenseFusion+2-refine), 640x480 N=1000",
             "value": round(total_frames / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "strong" if args.frames else "weak", "vs_baseline": None,
             # operand type handed to the matrix cores; accumulation and stored activations are fp32.  "bf16x3" = split-bf16
             # (hi + lo, three MFMA products per term, ~2^-16 operand error): the fastest mode that passes the 1e-4 R/t and
             # bit-exact-mask parity tests (tests/test_gpu_pipeline.py); "f32" = exact fp32 MFMA; "bf16" = plain bf16.
             "dtype": args.seg_precision if args.seg_precision == args.pose_precision else
                      "seg:%s pose:%s" % (args.seg_precision, args.pose_precision),
             "data": "synthetic",
-            "config": {"workload": "configs[2]: end-to-end PSPNet-resnet18 segmentation -> mask/CCL/bbox -> 160x160 crop -> "
-                                   "PoseNet(N=1000) -> 2x PoseRefineNet, batch=%d 640x480 frames per GPU" % args.batch,
-                       "frames_per_gpu_per_step": args.batch, "objects_found_last_step": n_found,
+            "config": {"workload": ("configs[3]: %d synthetic 640x480 RGB-D frames per step sharded over the ranks (sub-batches of %d), "
+                                    "one RCCL all_gather of all poses per step; per frame as configs[2]" % (args.frames, args.batch)) if args.frames else
+                                   ("configs[2]: end-to-end PSPNet-resnet18 segmentation -> mask/CCL/bbox -> 160x160 crop -> "
+                                    "PoseNet(N=1000) -> 2x PoseRefineNet, batch=%d 640x480 frames per GPU" % args.batch),
+                       "frames_per_gpu_per_step": per_rank, "objects_found_last_step": n_found,
                        "crop_buckets_last_step": crop_hist,
                        "gflop_per_frame_algorithmic": GFLOP_PER_FRAME, "parallelism": "frames sharded x%d, 1 all_gather of poses/step" % world},
             "achieved_tflops_algorithmic": round(total_frames * GFLOP_PER_FRAME / dt / 1e3, 2),
@@ -397,8 +540,9 @@ def main():
                     return nz[(np.arange(n) * len(nz)) // n] if len(nz) > n else np.pad(nz, (0, n - len(nz)), "wrap")
                 return choose_h[k]
 
-            line["cpu_baseline"], oracle_results = cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=min(16, args.batch))
-            line["parity"] = parity_block(out, oracle_results, frames, seg_sd)
+            last = frames[(n_chunks - 1) * args.batch:]      # `out` is the last sub-batch of the last step
+            line["cpu_baseline"], oracle_results = cpu_baseline(last, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=min(16, args.batch))
+            line["parity"] = parity_block(out, oracle_results, last, seg_sd)
         print(json.dumps(line))
     if dist:
         dist.barrier()

@@ -81,3 +81,23 @@ def test_two_rank_label_generation_equals_single_rank(tmp_path):
     assert got[1][1] is None and np.array_equal(got[0][1], want_out)             # rank 0 aligns and exports
     assert _digests(os.path.join(root, "pc1"), "ball") == _digests(os.path.join(root, "pc2"), "ball")     # every exported file, byte for byte
     assert len(want_fused) > 500 and len(want_out) > 500
+
+
+def test_fuse_chains_equals_fuse_views_per_chain_and_resident_views():
+    """Several chains through one call (open3d_utils.fuse_chains, single rank) give each chain's fuse_views result bit for bit, and views
+    handed over as resident device tensors (u8 label, u16 depth) give the same cloud as the host arrays."""
+    from autoposeestimation_amd import synthetic as S
+    from autoposeestimation_amd.pc_reconstruction import open3d_utils as U
+    cloud = S.bumpy_sphere(120000, 21)
+    chains = [S.label_views(4, seed=c, cloud=cloud) for c in range(3)]
+    kw = dict(voxel_size=2, threshold=10, icp_point2point=True, icp_point2plane=True)
+    multi = U.fuse_chains(chains, S.LABEL_INTR, **kw)
+    assert sorted(multi) == [0, 1, 2]
+    for c, views in enumerate(chains):
+        one, tfs = U.fuse_views(views, S.LABEL_INTR, **kw)
+        assert torch.equal(one._p, multi[c][0]._p)
+        assert all(np.array_equal(a, b) for a, b in zip(tfs, multi[c][1]))
+    resident = [(torch.from_numpy(l).cuda(), torch.from_numpy(d).cuda(), cam) for (l, d, cam) in chains[1]]
+    assert resident[0][1].dtype == torch.uint16
+    r, _ = U.fuse_views(resident, S.LABEL_INTR, **kw)
+    assert torch.equal(r._p, multi[1][0]._p)

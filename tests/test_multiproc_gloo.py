@@ -93,7 +93,12 @@ def _label_worker(rank, world, port, q):
     for chain, owner in ((0, sharding.chain_owner(0, world)), (1, sharding.chain_owner(1, world))):
         res[chain] = sharding.sharded_chain(views, make_set, _order_dependent_fuse, owner, dist)
     sets = sharding.gather_point_sets([(i, views[i]) for i in range(7) if i % world == rank][:4], 7, dist) if world == 2 else None
-    q.put((rank, {k: (None if v is None else v.tolist()) for k, v in res.items()}, len(made), [len(s) for s in sets]))
+    n_single = len(made)
+    # three chains of different length at once: one all-gather, every rank fuses what it owns
+    multi = sharding.sharded_chains([views[:3], views[3:], views[1:6]], make_set, _order_dependent_fuse, dist)
+    res["multi"] = np.array([[k] + v.tolist() for k, v in sorted(multi.items())])
+    res["multi_made"] = np.array([len(made) - n_single])
+    q.put((rank, {k: (None if v is None else v.tolist()) for k, v in res.items()}, n_single, [len(s) for s in sets]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -122,3 +127,11 @@ def test_label_chain_sharding_two_ranks_equals_single_rank():
     assert got[0][1] == 2 * 4 and got[1][1] == 2 * 3
     # the gather returns every set, in global order, with its true (ragged) length on both ranks
     assert got[0][2] == got[1][2] == [len(v) for v in views]
+    # sharded_chains: chains 0 and 2 on rank 0, chain 1 on rank 1, each equal to its single-rank fusion; 12 views split 6 + 6
+    chains = [views[:3], views[3:], views[1:6]]
+    want_multi = [_order_dependent_fuse([v * 2.0 for v in ch]).tolist() for ch in chains]
+    assert got[0][0]["multi"] == [[0.0] + want_multi[0], [2.0] + want_multi[2]]
+    assert got[1][0]["multi"] == [[1.0] + want_multi[1]]
+    assert got[0][0]["multi_made"] == [6] and got[1][0]["multi_made"] == [6]
+    solo = sharding.sharded_chains(chains, lambda v: torch.from_numpy(v * 2.0), _order_dependent_fuse, None)
+    assert [solo[i].tolist() for i in range(3)] == want_multi
