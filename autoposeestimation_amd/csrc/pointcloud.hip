@@ -21,6 +21,10 @@ namespace {
 constexpr int kT = 256;
 typedef unsigned long long u64;
 inline int grid_for(long work, int cap = 4096) { long g = (work + kT - 1) / kT; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
+// the grid-walk kernels (one query per lane, dependent loads) run one wave per workgroup: the label path's clouds hold ~10^4 points,
+// and 64-thread workgroups put them on four times as many CUs
+constexpr int kTW = 64;
+inline int walk_grid(long work, int cap = 16384) { long g = (work + kTW - 1) / kTW; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 struct Mat4 { double m[16]; };
 
@@ -162,54 +166,105 @@ __device__ __forceinline__ int lower_bound(const u64* keys, int n, u64 k)
     return lo;
 }
 
-// visit every grid point in the 27 cells around q: f(sorted_position, squared distance)
+// visit every grid point in the 27 cells around q: f(sorted_position, squared distance).  The nine (x, y) columns are nine ranges of
+// the sorted keys; their nine binary searches advance TOGETHER (nine independent loads in flight per step): one after the other they
+// were ~9 x 14 dependent L2 round trips per query, which is what the small clouds of the label path (10^4 points, a few dozen
+// workgroups) spent their time on.
 template <class F>
 __device__ __forceinline__ void for_neighbours(const Grid& g, const double* q, F f)
 {
     long c[3];
     cell_of(q, g.origin, g.h, c);
-    for (long dx = -1; dx <= 1; ++dx) {
-        const long cx = c[0] + dx;
-        if (cx < 0 || cx > 2097151) continue;
-        for (long dy = -1; dy <= 1; ++dy) {
-            const long cy = c[1] + dy;
-            if (cy < 0 || cy > 2097151) continue;
-            const long z0 = c[2] > 0 ? c[2] - 1 : 0, z1 = c[2] < 2097151 ? c[2] + 1 : 2097151;
-            const u64 k0 = pack_key(cx, cy, z0), k1 = pack_key(cx, cy, z1);   // the three z-cells are contiguous in key order
-            for (int j = lower_bound(g.keys, g.n, k0); j < g.n && g.keys[j] <= k1; ++j) {
-                const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
-                f(j, (ex * ex + ey * ey) + ez * ez);
+    const long z0 = c[2] > 0 ? c[2] - 1 : 0, z1 = c[2] < 2097151 ? c[2] + 1 : 2097151;
+    u64 k0[9], k1[9];
+    int lo[9], hi[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const long cx = c[0] + t / 3 - 1, cy = c[1] + t % 3 - 1;
+        const bool in = cx >= 0 && cx <= 2097151 && cy >= 0 && cy <= 2097151;
+        k0[t] = in ? pack_key(cx, cy, z0) : ~0ull;              // the three z-cells are contiguous in key order
+        k1[t] = in ? pack_key(cx, cy, z1) : 0ull;               // out-of-range column: empty range (k0 > k1)
+        lo[t] = 0;
+        hi[t] = in ? g.n : 0;
+    }
+    for (int span = g.n; span > 0; span >>= 1) {                // ceil(log2(n)) + 1 rounds close every range
+        bool open = false;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (lo[t] < hi[t]) {
+                const int mid = (lo[t] + hi[t]) >> 1;
+                if (g.keys[mid] < k0[t]) lo[t] = mid + 1; else hi[t] = mid;
+                open = true;
             }
+        }
+        if (!open) break;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        while (lo[t] < hi[t]) { const int mid = (lo[t] + hi[t]) >> 1; if (g.keys[mid] < k0[t]) lo[t] = mid + 1; else hi[t] = mid; }
+        for (int j = lo[t]; j < g.n && g.keys[j] <= k1[t]; ++j) {
+            const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
+            f(j, (ex * ex + ey * ey) + ez * ez);
         }
     }
 }
 
-__global__ void radius_count_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ count)
+// Cooperative form for the small clouds of the label path (10^4 points: one query per lane leaves most of the chip idle and every
+// lane walks 27 cells through dependent loads): kG = 32 lanes share a query, lane l < 27 takes cell l of the 3x3x3 block -- one binary
+// search and a short run of points -- and the group reduces with shuffles.
+constexpr int kG = 32;
+
+template <class F>
+__device__ __forceinline__ void for_my_cell(const Grid& g, const double* q, int lane, F f)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
-        int c = 0;
-        for_neighbours(g, q + (size_t)i * 3, [&](int, double d2) { c += d2 < r2 ? 1 : 0; });   // FLANN radius search: d^2 < r^2
-        count[i] = c;
+    long c[3];
+    cell_of(q, g.origin, g.h, c);
+    if (lane >= 27) return;
+    const long cx = c[0] + lane / 9 - 1, cy = c[1] + (lane / 3) % 3 - 1, cz = c[2] + lane % 3 - 1;
+    if (cx < 0 || cx > 2097151 || cy < 0 || cy > 2097151 || cz < 0 || cz > 2097151) return;
+    const u64 key = pack_key(cx, cy, cz);
+    for (int j = lower_bound(g.keys, g.n, key); j < g.n && g.keys[j] == key; ++j) {
+        const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
+        f(j, (ex * ex + ey * ey) + ez * ez);
     }
 }
 
-// `skip` (optional, everywhere below): a device word that, once non-zero, turns the launch into a no-op -- the ICP loop runs a fixed
-// number of enqueued iterations and the device decides when it has converged (icp_step_kernel)
-__global__ void nn1_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx, double* __restrict__ dist2,
-                           const double* __restrict__ skip = nullptr)
+__global__ __launch_bounds__(kT) void radius_count_group_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ count)
+{
+    const int lane = threadIdx.x % kG;
+    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    int c = 0;
+    if (i < nq) for_my_cell(g, q + (size_t)i * 3, lane, [&](int, double d2) { c += d2 < r2 ? 1 : 0; });
+    for (int m = kG / 2; m >= 1; m >>= 1) c += __shfl_xor(c, m, kG);
+    if (i < nq && lane == 0) count[i] = c;
+}
+
+__global__ __launch_bounds__(kT) void nn1_group_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx,
+                                                       double* __restrict__ dist2, const double* __restrict__ skip)
 {
     if (skip && skip[0] != 0.0) return;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
-        double best = r2;
-        unsigned bi = 0xffffffffu;
-        for_neighbours(g, q + (size_t)i * 3, [&](int j, double d2) {
+    const int lane = threadIdx.x % kG;
+    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    double best = r2;
+    unsigned bi = 0xffffffffu;
+    if (i < nq)
+        for_my_cell(g, q + (size_t)i * 3, lane, [&](int j, double d2) {
             const unsigned o = g.order[j];
             if (d2 < best || (d2 == best && bi != 0xffffffffu && o < bi)) { best = d2; bi = o; }   // ties: lowest original index
         });
+    for (int m = kG / 2; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(best, m, kG);
+        const unsigned oi = __shfl_xor(bi, m, kG);
+        if (oi != 0xffffffffu && (bi == 0xffffffffu || ob < best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+    }
+    if (i < nq && lane == 0) {
         idx[i] = bi == 0xffffffffu ? -1 : (int)bi;
         dist2[i] = bi == 0xffffffffu ? 0.0 : best;
     }
 }
+
+// `skip` (optional, in the kernels of the ICP loop): a device word that, once non-zero, turns the launch into a no-op -- the loop runs
+// a fixed number of enqueued iterations and the device decides when it has converged (icp_step_kernel)
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi, fixed 12 sweeps)
 __device__ void smallest_eigvec(double a[3][3], double v[3])
@@ -236,41 +291,97 @@ constexpr int kMaxNN = 64;
 
 // hybrid search: neighbours with d < radius, at most max_nn nearest of them; normal = eigenvector of the smallest
 // eigenvalue of their covariance, flipped towards +z (open3d's default orientation reference); (0,0,1) if < 3 neighbours
-__global__ void normals_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int max_nn, double* __restrict__ normals)
+__device__ void normal_from_selection(const Grid& g, const int* bj, int cnt, double nrm[3])
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
-        double bd[kMaxNN];
-        int bj[kMaxNN];
-        int cnt = 0;
-        for_neighbours(g, q + (size_t)i * 3, [&](int j, double d2) {
-            if (d2 >= r2) return;
-            if (cnt < max_nn) {
-                int k = cnt++;
-                while (k > 0 && bd[k - 1] > d2) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; --k; }
-                bd[k] = d2; bj[k] = j;
-            } else if (bd[max_nn - 1] > d2) {
-                int k = max_nn - 1;
-                while (k > 0 && bd[k - 1] > d2) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; --k; }
-                bd[k] = d2; bj[k] = j;
-            }
-        });
-        double nrm[3] = {0, 0, 1};
-        if (cnt >= 3) {
-            double mu[3] = {0, 0, 0};
-            for (int k = 0; k < cnt; ++k) for (int d = 0; d < 3; ++d) mu[d] += g.sorted[(size_t)bj[k] * 3 + d];
-            for (int d = 0; d < 3; ++d) mu[d] /= (double)cnt;
-            double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-            for (int k = 0; k < cnt; ++k) {
-                double e[3];
-                for (int d = 0; d < 3; ++d) e[d] = g.sorted[(size_t)bj[k] * 3 + d] - mu[d];
-                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] += e[a] * e[b];
-            }
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] /= (double)cnt;
-            smallest_eigvec(C, nrm);
-            const double l = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
-            if (l > 0) for (int d = 0; d < 3; ++d) nrm[d] /= l; else { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; }
-            if (nrm[2] < 0) for (int d = 0; d < 3; ++d) nrm[d] = -nrm[d];
+    nrm[0] = 0; nrm[1] = 0; nrm[2] = 1;
+    if (cnt < 3) return;
+    double mu[3] = {0, 0, 0};
+    for (int k = 0; k < cnt; ++k) for (int d = 0; d < 3; ++d) mu[d] += g.sorted[(size_t)bj[k] * 3 + d];
+    for (int d = 0; d < 3; ++d) mu[d] /= (double)cnt;
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int k = 0; k < cnt; ++k) {
+        double e[3];
+        for (int d = 0; d < 3; ++d) e[d] = g.sorted[(size_t)bj[k] * 3 + d] - mu[d];
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] += e[a] * e[b];
+    }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] /= (double)cnt;
+    smallest_eigvec(C, nrm);
+    const double l = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
+    if (l > 0) for (int d = 0; d < 3; ++d) nrm[d] /= l; else { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; }
+    if (nrm[2] < 0) for (int d = 0; d < 3; ++d) nrm[d] = -nrm[d];
+}
+
+__device__ void normal_serial(const Grid& g, const double* q, double r2, int max_nn, double nrm[3])
+{
+    double bd[kMaxNN];
+    int bj[kMaxNN];
+    int cnt = 0;
+    for_neighbours(g, q, [&](int j, double d2) {
+        if (d2 >= r2) return;
+        if (cnt < max_nn) {
+            int k = cnt++;
+            while (k > 0 && bd[k - 1] > d2) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; --k; }
+            bd[k] = d2; bj[k] = j;
+        } else if (bd[max_nn - 1] > d2) {
+            int k = max_nn - 1;
+            while (k > 0 && bd[k - 1] > d2) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; --k; }
+            bd[k] = d2; bj[k] = j;
         }
+    });
+    normal_from_selection(g, bj, cnt, nrm);
+}
+
+// kG lanes per query (see nn1_group_kernel): the in-radius candidates of the 27 cells go to the group's LDS list, then min(max_nn,
+// candidates) rounds take the smallest (d^2, sorted position) after the last one taken -- the order the serial insertion sort
+// produces (its ties keep the first visited = lower sorted position) -- and lane 0 runs the covariance / eigenvector part on the
+// selection in that order: bitwise the serial result.  More than kNrmCand candidates: lane 0 runs the serial search.
+constexpr int kNrmCand = 224;
+
+__global__ __launch_bounds__(kT) void normals_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int max_nn, double* __restrict__ normals)
+{
+    __shared__ double cand_d[kT / kG][kNrmCand];
+    __shared__ int cand_j[kT / kG][kNrmCand];
+    __shared__ int sel[kT / kG][kMaxNN];
+    __shared__ int ncand[kT / kG];
+    const int lane = threadIdx.x % kG, grp = threadIdx.x / kG;
+    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    if (lane == 0) ncand[grp] = 0;
+    __syncthreads();
+    if (i < nq)
+        for_my_cell(g, q + (size_t)i * 3, lane, [&](int j, double d2) {
+            if (d2 >= r2) return;
+            const int p = atomicAdd(&ncand[grp], 1);
+            if (p < kNrmCand) { cand_d[grp][p] = d2; cand_j[grp][p] = j; }
+        });
+    __syncthreads();
+    const int nc = ncand[grp];
+    const bool coop = i < nq && nc <= kNrmCand;
+    const int cnt = nc < max_nn ? nc : max_nn;
+    if (coop) {
+        double last_d = -1.0;
+        int last_j = -1;
+        for (int r = 0; r < cnt; ++r) {
+            double bd = 1e300;
+            int bj = 0x7fffffff;
+            for (int p = lane; p < nc; p += kG) {
+                const double d = cand_d[grp][p];
+                const int j = cand_j[grp][p];
+                const bool after = d > last_d || (d == last_d && j > last_j);
+                if (after && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
+            }
+            for (int m = kG / 2; m >= 1; m >>= 1) {
+                const double od = __shfl_xor(bd, m, kG);
+                const int oj = __shfl_xor(bj, m, kG);
+                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+            }
+            last_d = bd; last_j = bj;
+            if (lane == 0) sel[grp][r] = bj;
+        }
+    }
+    if (i < nq && lane == 0) {
+        double nrm[3];
+        if (coop) normal_from_selection(g, sel[grp], cnt, nrm);
+        else normal_serial(g, q + (size_t)i * 3, r2, max_nn, nrm);
         for (int d = 0; d < 3; ++d) normals[(size_t)i * 3 + d] = nrm[d];
     }
 }
@@ -332,11 +443,8 @@ __device__ __forceinline__ void knn_insert(double* bd, int& cnt, int k, double d
     }
 }
 
-__global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double* __restrict__ mean)
+__device__ double knn_mean_serial(const Grid& g, const double* q, int k)
 {
-    const int i = blockIdx.x * kT + threadIdx.x;
-    if (i >= g.n) return;
-    const double q[3] = {g.sorted[(size_t)i * 3], g.sorted[(size_t)i * 3 + 1], g.sorted[(size_t)i * 3 + 2]};
     long c[3];
     cell_of(q, g.origin, g.h, c);
     double bd[kMaxNN];
@@ -352,13 +460,15 @@ __global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double
             knn_insert(bd, cnt, k, (ex * ex + ey * ey) + ez * ez);
         }
     };
-    bool done = false;
-    for (long R = 0; R <= kKnnMaxShell && !done; ++R) {
+    // shells 0 and 1 = the 27-cell block, with its nine column searches batched (for_neighbours)
+    for_neighbours(g, q, [&](int, double d2) { knn_insert(bd, cnt, k, d2); });
+    bool done = cnt == k && bd[k - 1] < g.h * g.h * (1.0 - 1e-12);
+    for (long R = 2; R <= kKnnMaxShell && !done; ++R) {
         for (long dx = -R; dx <= R; ++dx)
             for (long dy = -R; dy <= R; ++dy) {
                 const bool edge = dx == -R || dx == R || dy == -R || dy == R;
                 if (edge) run(c[0] + dx, c[1] + dy, c[2] - R, c[2] + R);       // a whole new column of the shell
-                else { run(c[0] + dx, c[1] + dy, c[2] - R, c[2] - R); run(c[0] + dx, c[1] + dy, c[2] + R, c[2] + R); }   // its two caps (R >= 1 here)
+                else { run(c[0] + dx, c[1] + dy, c[2] - R, c[2] - R); run(c[0] + dx, c[1] + dy, c[2] + R, c[2] + R); }   // its two caps
             }
         const double bound = (double)R * g.h;
         done = cnt == k && bd[k - 1] < bound * bound * (1.0 - 1e-12);
@@ -372,7 +482,56 @@ __global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double
     }
     double sum = 0;
     for (int p = 0; p < cnt; ++p) sum += sqrt(bd[p]);
-    mean[g.order[i]] = cnt ? sum / (double)cnt : -1.0;
+    return cnt ? sum / (double)cnt : -1.0;
+}
+
+// kG lanes per query: every lane drops the squared distances of its cell into the group's LDS list; if the 27 cells hold the k
+// nearest for certain (k-th smallest inside one cell size), k rounds of "smallest entry after the last one taken" (each lane scans its
+// share, the group reduces by shuffles) sum them in ascending order -- the same values in the same order as the serial search, so
+// the same bits.  Anything else (sparse neighbourhood, more than kKnnCand candidates) falls back to knn_mean_serial on lane 0.
+constexpr int kKnnCand = 224;
+
+__global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double* __restrict__ mean)
+{
+    __shared__ double cand[kT / kG][kKnnCand];
+    __shared__ int ncand[kT / kG];
+    const int lane = threadIdx.x % kG, grp = threadIdx.x / kG;
+    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    if (lane == 0) ncand[grp] = 0;
+    __syncthreads();
+    double q[3] = {0, 0, 0};
+    if (i < g.n) {
+        for (int d = 0; d < 3; ++d) q[d] = g.sorted[(size_t)i * 3 + d];
+        for_my_cell(g, q, lane, [&](int, double d2) {
+            const int p = atomicAdd(&ncand[grp], 1);
+            if (p < kKnnCand) cand[grp][p] = d2;
+        });
+    }
+    __syncthreads();
+    const int nc = ncand[grp];
+    bool coop = i < g.n && nc >= k && nc <= kKnnCand;
+    double sum = 0, last_d = -1.0;
+    int last_p = -1;
+    if (coop) {
+        for (int r = 0; r < k; ++r) {
+            double bd = 1e300;
+            int bp = 0x7fffffff;
+            for (int p = lane; p < nc; p += kG) {
+                const double d = cand[grp][p];
+                const bool after = d > last_d || (d == last_d && p > last_p);
+                if (after && (d < bd || (d == bd && p < bp))) { bd = d; bp = p; }
+            }
+            for (int m = kG / 2; m >= 1; m >>= 1) {
+                const double od = __shfl_xor(bd, m, kG);
+                const int op = __shfl_xor(bp, m, kG);
+                if (od < bd || (od == bd && op < bp)) { bd = od; bp = op; }
+            }
+            last_d = bd; last_p = bp;
+            sum += sqrt(bd);
+        }
+        coop = last_d < g.h * g.h * (1.0 - 1e-12);          // the k-th nearest is inside the searched block for certain
+    }
+    if (i < g.n && lane == 0) mean[g.order[i]] = coop ? sum / (double)k : knn_mean_serial(g, q, k);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -590,7 +749,7 @@ extern "C" int ape_grid_radius_count_f64(GRID_ARGS, const double* q, int nq, dou
     if (!sorted || !keys || !order || !origin3 || !q || !count || n < 1 || nq < 0 || radius > cell) return APE_EINVAL;
     if (nq == 0) return APE_OK;
     MAKE_GRID;
-    hipLaunchKernelGGL(radius_count_kernel, dim3(grid_for(nq)), dim3(kT), 0, (hipStream_t)stream, g, q, nq, radius * radius, count);
+    hipLaunchKernelGGL(radius_count_group_kernel, dim3(ape::ceil_div((long)nq * kG, (long)kT)), dim3(kT), 0, (hipStream_t)stream, g, q, nq, radius * radius, count);
     return ape::check_launch("ape_grid_radius_count_f64");
 }
 
@@ -599,7 +758,7 @@ extern "C" int ape_grid_nn1_f64(GRID_ARGS, const double* q, int nq, double max_d
     if (!sorted || !keys || !order || !origin3 || !q || !idx || !dist2 || n < 1 || nq < 0 || max_dist > cell) return APE_EINVAL;
     if (nq == 0) return APE_OK;
     MAKE_GRID;
-    hipLaunchKernelGGL(nn1_kernel, dim3(grid_for(nq)), dim3(kT), 0, (hipStream_t)stream, g, q, nq, max_dist * max_dist, idx, dist2);
+    hipLaunchKernelGGL(nn1_group_kernel, dim3(ape::ceil_div((long)nq * kG, (long)kT)), dim3(kT), 0, (hipStream_t)stream, g, q, nq, max_dist * max_dist, idx, dist2, (const double*)nullptr);
     return ape::check_launch("ape_grid_nn1_f64");
 }
 
@@ -609,7 +768,7 @@ extern "C" int ape_grid_normals_f64(GRID_ARGS, const double* q, int nq, double r
         return APE_EINVAL;
     if (nq == 0) return APE_OK;
     MAKE_GRID;
-    hipLaunchKernelGGL(normals_kernel, dim3(grid_for(nq)), dim3(kT), 0, (hipStream_t)stream, g, q, nq, radius * radius, max_nn, normals);
+    hipLaunchKernelGGL(normals_kernel, dim3(ape::ceil_div((long)nq * kG, (long)kT)), dim3(kT), 0, (hipStream_t)stream, g, q, nq, radius * radius, max_nn, normals);
     return ape::check_launch("ape_grid_normals_f64");
 }
 
@@ -624,7 +783,7 @@ extern "C" int ape_grid_knn_mean_dist_f64(GRID_ARGS, int k, double* mean, void* 
 {
     if (!sorted || !keys || !order || !origin3 || !mean || n < 1 || k < 1 || k > kMaxNN || k > n || !(cell > 0)) return APE_EINVAL;
     MAKE_GRID;
-    hipLaunchKernelGGL(knn_mean_grid_kernel, dim3(ape::ceil_div(n, kT)), dim3(kT), 0, (hipStream_t)stream, g, k, mean);
+    hipLaunchKernelGGL(knn_mean_grid_kernel, dim3(ape::ceil_div((long)n * kG, (long)kT)), dim3(kT), 0, (hipStream_t)stream, g, k, mean);
     return ape::check_launch("ape_grid_knn_mean_dist_f64");
 }
 
@@ -838,7 +997,7 @@ extern "C" int ape_icp_run_f64(int kind, GRID_ARGS, double* src, int ns, const d
     MAKE_GRID;
     double* part = (double*)ws;
     auto evaluate = [&]() {
-        hipLaunchKernelGGL(nn1_kernel, dim3(grid_for(ns)), dim3(kT), 0, st, g, (const double*)src, ns, max_dist * max_dist, corr, dist2, (const double*)state);
+        hipLaunchKernelGGL(nn1_group_kernel, dim3(ape::ceil_div((long)ns * kG, (long)kT)), dim3(kT), 0, st, g, (const double*)src, ns, max_dist * max_dist, corr, dist2, (const double*)state);
         if (kind == 0) hipLaunchKernelGGL(p2p_sums_kernel, dim3(nb), dim3(kT), 0, st, (const double*)src, tgt, (const int*)corr, (const double*)dist2, ns, part, (const double*)state);
         else hipLaunchKernelGGL(p2plane_sums_kernel, dim3(nb), dim3(kT), 0, st, (const double*)src, tgt, tgt_normals, (const int*)corr, (const double*)dist2, ns, part, (const double*)state);
         hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(64), 0, st, (const double*)part, nb, nv, sums, (const double*)state);
