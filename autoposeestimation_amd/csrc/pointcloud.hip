@@ -21,10 +21,6 @@ namespace {
 constexpr int kT = 256;
 typedef unsigned long long u64;
 inline int grid_for(long work, int cap = 4096) { long g = (work + kT - 1) / kT; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
-// the grid-walk kernels (one query per lane, dependent loads) run one wave per workgroup: the label path's clouds hold ~10^4 points,
-// and 64-thread workgroups put them on four times as many CUs
-constexpr int kTW = 64;
-inline int walk_grid(long work, int cap = 16384) { long g = (work + kTW - 1) / kTW; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 struct Mat4 { double m[16]; };
 
@@ -166,49 +162,6 @@ __device__ __forceinline__ int lower_bound(const u64* keys, int n, u64 k)
     return lo;
 }
 
-// visit every grid point in the 27 cells around q: f(sorted_position, squared distance).  The nine (x, y) columns are nine ranges of
-// the sorted keys; their nine binary searches advance TOGETHER (nine independent loads in flight per step): one after the other they
-// were ~9 x 14 dependent L2 round trips per query, which is what the small clouds of the label path (10^4 points, a few dozen
-// workgroups) spent their time on.
-template <class F>
-__device__ __forceinline__ void for_neighbours(const Grid& g, const double* q, F f)
-{
-    long c[3];
-    cell_of(q, g.origin, g.h, c);
-    const long z0 = c[2] > 0 ? c[2] - 1 : 0, z1 = c[2] < 2097151 ? c[2] + 1 : 2097151;
-    u64 k0[9], k1[9];
-    int lo[9], hi[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const long cx = c[0] + t / 3 - 1, cy = c[1] + t % 3 - 1;
-        const bool in = cx >= 0 && cx <= 2097151 && cy >= 0 && cy <= 2097151;
-        k0[t] = in ? pack_key(cx, cy, z0) : ~0ull;              // the three z-cells are contiguous in key order
-        k1[t] = in ? pack_key(cx, cy, z1) : 0ull;               // out-of-range column: empty range (k0 > k1)
-        lo[t] = 0;
-        hi[t] = in ? g.n : 0;
-    }
-    for (int span = g.n; span > 0; span >>= 1) {                // ceil(log2(n)) + 1 rounds close every range
-        bool open = false;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (lo[t] < hi[t]) {
-                const int mid = (lo[t] + hi[t]) >> 1;
-                if (g.keys[mid] < k0[t]) lo[t] = mid + 1; else hi[t] = mid;
-                open = true;
-            }
-        }
-        if (!open) break;
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        while (lo[t] < hi[t]) { const int mid = (lo[t] + hi[t]) >> 1; if (g.keys[mid] < k0[t]) lo[t] = mid + 1; else hi[t] = mid; }
-        for (int j = lo[t]; j < g.n && g.keys[j] <= k1[t]; ++j) {
-            const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
-            f(j, (ex * ex + ey * ey) + ez * ez);
-        }
-    }
-}
-
 // Cooperative form for the small clouds of the label path (10^4 points: one query per lane leaves most of the chip idle and every
 // lane walks 27 cells through dependent loads): kG = 32 lanes share a query, lane l < 27 takes cell l of the 3x3x3 block -- one binary
 // search and a short run of points -- and the group reduces with shuffles.
@@ -311,30 +264,10 @@ __device__ void normal_from_selection(const Grid& g, const int* bj, int cnt, dou
     if (nrm[2] < 0) for (int d = 0; d < 3; ++d) nrm[d] = -nrm[d];
 }
 
-__device__ void normal_serial(const Grid& g, const double* q, double r2, int max_nn, double nrm[3])
-{
-    double bd[kMaxNN];
-    int bj[kMaxNN];
-    int cnt = 0;
-    for_neighbours(g, q, [&](int j, double d2) {
-        if (d2 >= r2) return;
-        if (cnt < max_nn) {
-            int k = cnt++;
-            while (k > 0 && bd[k - 1] > d2) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; --k; }
-            bd[k] = d2; bj[k] = j;
-        } else if (bd[max_nn - 1] > d2) {
-            int k = max_nn - 1;
-            while (k > 0 && bd[k - 1] > d2) { bd[k] = bd[k - 1]; bj[k] = bj[k - 1]; --k; }
-            bd[k] = d2; bj[k] = j;
-        }
-    });
-    normal_from_selection(g, bj, cnt, nrm);
-}
-
 // kG lanes per query (see nn1_group_kernel): the in-radius candidates of the 27 cells go to the group's LDS list, then min(max_nn,
-// candidates) rounds take the smallest (d^2, sorted position) after the last one taken -- the order the serial insertion sort
-// produces (its ties keep the first visited = lower sorted position) -- and lane 0 runs the covariance / eigenvector part on the
-// selection in that order: bitwise the serial result.  More than kNrmCand candidates: lane 0 runs the serial search.
+// candidates) rounds take the smallest (d^2, sorted position) after the last one taken -- the order an insertion sort over the cells
+// in key order produces (its ties keep the first visited = lower sorted position) -- and lane 0 runs the covariance / eigenvector
+// part on the selection in that order.  More than kNrmCand candidates: the rounds re-walk each lane's cell instead of the list.
 constexpr int kNrmCand = 224;
 
 __global__ __launch_bounds__(kT) void normals_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int max_nn, double* __restrict__ normals)
@@ -347,41 +280,41 @@ __global__ __launch_bounds__(kT) void normals_kernel(Grid g, const double* __res
     const int i = (blockIdx.x * kT + threadIdx.x) / kG;
     if (lane == 0) ncand[grp] = 0;
     __syncthreads();
-    if (i < nq)
-        for_my_cell(g, q + (size_t)i * 3, lane, [&](int j, double d2) {
+    double qq[3] = {0, 0, 0};
+    if (i < nq) {
+        for (int d = 0; d < 3; ++d) qq[d] = q[(size_t)i * 3 + d];
+        for_my_cell(g, qq, lane, [&](int j, double d2) {
             if (d2 >= r2) return;
             const int p = atomicAdd(&ncand[grp], 1);
             if (p < kNrmCand) { cand_d[grp][p] = d2; cand_j[grp][p] = j; }
         });
+    }
     __syncthreads();
     const int nc = ncand[grp];
-    const bool coop = i < nq && nc <= kNrmCand;
-    const int cnt = nc < max_nn ? nc : max_nn;
-    if (coop) {
-        double last_d = -1.0;
-        int last_j = -1;
-        for (int r = 0; r < cnt; ++r) {
-            double bd = 1e300;
-            int bj = 0x7fffffff;
-            for (int p = lane; p < nc; p += kG) {
-                const double d = cand_d[grp][p];
-                const int j = cand_j[grp][p];
-                const bool after = d > last_d || (d == last_d && j > last_j);
-                if (after && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
-            }
-            for (int m = kG / 2; m >= 1; m >>= 1) {
-                const double od = __shfl_xor(bd, m, kG);
-                const int oj = __shfl_xor(bj, m, kG);
-                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
-            }
-            last_d = bd; last_j = bj;
-            if (lane == 0) sel[grp][r] = bj;
+    const bool listed = nc <= kNrmCand;
+    const int cnt = i < nq ? (nc < max_nn ? nc : max_nn) : 0;
+    double last_d = -1.0;
+    int last_j = -1;
+    for (int r = 0; r < cnt; ++r) {
+        double bd = 1e300;
+        int bj = 0x7fffffff;
+        auto offer = [&](int j, double d) {
+            const bool after = d > last_d || (d == last_d && j > last_j);
+            if (after && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
+        };
+        if (listed) for (int p = lane; p < nc; p += kG) offer(cand_j[grp][p], cand_d[grp][p]);
+        else for_my_cell(g, qq, lane, [&](int j, double d2) { if (d2 < r2) offer(j, d2); });
+        for (int m = kG / 2; m >= 1; m >>= 1) {
+            const double od = __shfl_xor(bd, m, kG);
+            const int oj = __shfl_xor(bj, m, kG);
+            if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
         }
+        last_d = bd; last_j = bj;
+        if (lane == 0) sel[grp][r] = bj;
     }
     if (i < nq && lane == 0) {
         double nrm[3];
-        if (coop) normal_from_selection(g, sel[grp], cnt, nrm);
-        else normal_serial(g, q + (size_t)i * 3, r2, max_nn, nrm);
+        normal_from_selection(g, sel[grp], cnt, nrm);
         for (int d = 0; d < 3; ++d) normals[(size_t)i * 3 + d] = nrm[d];
     }
 }
@@ -423,73 +356,23 @@ __global__ __launch_bounds__(kT) void knn_mean_kernel(const double* __restrict__
     }
 }
 
-// The same through the uniform grid: cells are visited in growing Chebyshev shells around the query's cell; after shell R every
-// unvisited point is at least R*h away, so the search stops once the k-th best distance is inside that bound.  The k smallest squared
-// distances are the same multiset as the brute-force kernel finds and are summed in the same (ascending) order => bitwise equal means.
-// Queries are the grid's own points taken in key order (neighbouring lanes walk neighbouring cells).  Isolated points whose search
-// would pass kKnnMaxShell shells fall back to the scan of all points.
-constexpr int kKnnMaxShell = 6;
+// The same through the uniform grid, kG lanes per query (see nn1_group_kernel; the queries are the grid's own points in key order).
+// For R = 1, 2, 3: the lanes share the cells of the (2R+1)^3 block around the query's cell and drop their squared distances into the
+// group's LDS list; if the block holds the k nearest for certain (k-th smallest inside R cell sizes: every point outside the block is
+// at least R cells away), k rounds of "smallest entry after the last one taken" (each lane scans its share, the group reduces by
+// shuffles) have summed them in ascending order.  Queries that stay unsettled (isolated points, more than kKnnCand candidates) run
+// the same k rounds over ALL points, n / kG per lane and round.  No per-lane sort, no scratch, exact for any cell size: the k
+// smallest squared distances are the multiset the all-pairs kernel finds, summed in ascending order, hence the same bits.
+constexpr int kKnnCand = 448;
 
-__device__ __forceinline__ void knn_insert(double* bd, int& cnt, int k, double d2)
+__device__ __forceinline__ void knn_round_reduce(double& bd, int& bp)
 {
-    if (cnt < k) {
-        int p = cnt++;
-        while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; --p; }
-        bd[p] = d2;
-    } else if (bd[k - 1] > d2) {
-        int p = k - 1;
-        while (p > 0 && bd[p - 1] > d2) { bd[p] = bd[p - 1]; --p; }
-        bd[p] = d2;
+    for (int m = kG / 2; m >= 1; m >>= 1) {
+        const double od = __shfl_xor(bd, m, kG);
+        const int op = __shfl_xor(bp, m, kG);
+        if (od < bd || (od == bd && op < bp)) { bd = od; bp = op; }
     }
 }
-
-__device__ double knn_mean_serial(const Grid& g, const double* q, int k)
-{
-    long c[3];
-    cell_of(q, g.origin, g.h, c);
-    double bd[kMaxNN];
-    int cnt = 0;
-    auto run = [&](long cx, long cy, long z0, long z1) {
-        if (cx < 0 || cx > 2097151 || cy < 0 || cy > 2097151) return;
-        z0 = z0 < 0 ? 0 : z0;
-        z1 = z1 > 2097151 ? 2097151 : z1;
-        if (z0 > z1) return;
-        const u64 k0 = pack_key(cx, cy, z0), k1 = pack_key(cx, cy, z1);
-        for (int j = lower_bound(g.keys, g.n, k0); j < g.n && g.keys[j] <= k1; ++j) {
-            const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
-            knn_insert(bd, cnt, k, (ex * ex + ey * ey) + ez * ez);
-        }
-    };
-    // shells 0 and 1 = the 27-cell block, with its nine column searches batched (for_neighbours)
-    for_neighbours(g, q, [&](int, double d2) { knn_insert(bd, cnt, k, d2); });
-    bool done = cnt == k && bd[k - 1] < g.h * g.h * (1.0 - 1e-12);
-    for (long R = 2; R <= kKnnMaxShell && !done; ++R) {
-        for (long dx = -R; dx <= R; ++dx)
-            for (long dy = -R; dy <= R; ++dy) {
-                const bool edge = dx == -R || dx == R || dy == -R || dy == R;
-                if (edge) run(c[0] + dx, c[1] + dy, c[2] - R, c[2] + R);       // a whole new column of the shell
-                else { run(c[0] + dx, c[1] + dy, c[2] - R, c[2] - R); run(c[0] + dx, c[1] + dy, c[2] + R, c[2] + R); }   // its two caps
-            }
-        const double bound = (double)R * g.h;
-        done = cnt == k && bd[k - 1] < bound * bound * (1.0 - 1e-12);
-    }
-    if (!done) {
-        cnt = 0;
-        for (int j = 0; j < g.n; ++j) {
-            const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
-            knn_insert(bd, cnt, k, (ex * ex + ey * ey) + ez * ez);
-        }
-    }
-    double sum = 0;
-    for (int p = 0; p < cnt; ++p) sum += sqrt(bd[p]);
-    return cnt ? sum / (double)cnt : -1.0;
-}
-
-// kG lanes per query: every lane drops the squared distances of its cell into the group's LDS list; if the 27 cells hold the k
-// nearest for certain (k-th smallest inside one cell size), k rounds of "smallest entry after the last one taken" (each lane scans its
-// share, the group reduces by shuffles) sum them in ascending order -- the same values in the same order as the serial search, so
-// the same bits.  Anything else (sparse neighbourhood, more than kKnnCand candidates) falls back to knn_mean_serial on lane 0.
-constexpr int kKnnCand = 224;
 
 __global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double* __restrict__ mean)
 {
@@ -497,22 +380,35 @@ __global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double
     __shared__ int ncand[kT / kG];
     const int lane = threadIdx.x % kG, grp = threadIdx.x / kG;
     const int i = (blockIdx.x * kT + threadIdx.x) / kG;
-    if (lane == 0) ncand[grp] = 0;
-    __syncthreads();
-    double q[3] = {0, 0, 0};
-    if (i < g.n) {
-        for (int d = 0; d < 3; ++d) q[d] = g.sorted[(size_t)i * 3 + d];
-        for_my_cell(g, q, lane, [&](int, double d2) {
-            const int p = atomicAdd(&ncand[grp], 1);
-            if (p < kKnnCand) cand[grp][p] = d2;
-        });
-    }
-    __syncthreads();
-    const int nc = ncand[grp];
-    bool coop = i < g.n && nc >= k && nc <= kKnnCand;
-    double sum = 0, last_d = -1.0;
-    int last_p = -1;
-    if (coop) {
+    if (i >= g.n) return;                                    // whole groups leave together; the LDS traffic below is per group (one wave
+                                                             // holds two groups: same-wave program order, no block barrier needed)
+    const double q[3] = {g.sorted[(size_t)i * 3], g.sorted[(size_t)i * 3 + 1], g.sorted[(size_t)i * 3 + 2]};
+    long c[3];
+    cell_of(q, g.origin, g.h, c);
+    double sum = 0;
+    bool settled = false;
+    for (int R = 1; R <= 3 && !settled; ++R) {
+        if (lane == 0) ncand[grp] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int S = 2 * R + 1;
+        for (int cc = lane; cc < S * S * S; cc += kG) {
+            const long cx = c[0] + cc / (S * S) - R, cy = c[1] + (cc / S) % S - R, cz = c[2] + cc % S - R;
+            if (cx < 0 || cx > 2097151 || cy < 0 || cy > 2097151 || cz < 0 || cz > 2097151) continue;
+            const u64 key = pack_key(cx, cy, cz);
+            for (int j = lower_bound(g.keys, g.n, key); j < g.n && g.keys[j] == key; ++j) {
+                const double ex = g.sorted[(size_t)j * 3] - q[0], ey = g.sorted[(size_t)j * 3 + 1] - q[1], ez = g.sorted[(size_t)j * 3 + 2] - q[2];
+                const int p = atomicAdd(&ncand[grp], 1);
+                if (p < kKnnCand) cand[grp][p] = (ex * ex + ey * ey) + ez * ez;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nc = ncand[grp];
+        if (nc < k || nc > kKnnCand) { if (nc > kKnnCand) break; continue; }
+        double last_d = -1.0;
+        int last_p = -1;
+        sum = 0;
         for (int r = 0; r < k; ++r) {
             double bd = 1e300;
             int bp = 0x7fffffff;
@@ -521,17 +417,41 @@ __global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double
                 const bool after = d > last_d || (d == last_d && p > last_p);
                 if (after && (d < bd || (d == bd && p < bp))) { bd = d; bp = p; }
             }
-            for (int m = kG / 2; m >= 1; m >>= 1) {
-                const double od = __shfl_xor(bd, m, kG);
-                const int op = __shfl_xor(bp, m, kG);
-                if (od < bd || (od == bd && op < bp)) { bd = od; bp = op; }
-            }
+            knn_round_reduce(bd, bp);
             last_d = bd; last_p = bp;
             sum += sqrt(bd);
         }
-        coop = last_d < g.h * g.h * (1.0 - 1e-12);          // the k-th nearest is inside the searched block for certain
+        const double bound = (double)R * g.h;
+        settled = last_d < bound * bound * (1.0 - 1e-12);
     }
-    if (i < g.n && lane == 0) mean[g.order[i]] = coop ? sum / (double)k : knn_mean_serial(g, q, k);
+    if (!settled) {
+        double last_d = -1.0;
+        int last_p = -1;
+        sum = 0;
+        for (int r = 0; r < k; ++r) {
+            double bd = 1e300;
+            int bp = 0x7fffffff;
+            auto offer = [&](int p, double x, double y, double z) {
+                const double ex = x - q[0], ey = y - q[1], ez = z - q[2];
+                const double d = (ex * ex + ey * ey) + ez * ez;
+                const bool after = d > last_d || (d == last_d && p > last_p);
+                if (after && (d < bd || (d == bd && p < bp))) { bd = d; bp = p; }
+            };
+            int p = lane;
+            for (; p + 3 * kG < g.n; p += 4 * kG) {           // four independent point loads in flight per lane
+                double v[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) for (int d = 0; d < 3; ++d) v[u][d] = g.sorted[(size_t)(p + u * kG) * 3 + d];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) offer(p + u * kG, v[u][0], v[u][1], v[u][2]);
+            }
+            for (; p < g.n; p += kG) offer(p, g.sorted[(size_t)p * 3], g.sorted[(size_t)p * 3 + 1], g.sorted[(size_t)p * 3 + 2]);
+            knn_round_reduce(bd, bp);
+            last_d = bd; last_p = bp;
+            sum += sqrt(bd);
+        }
+    }
+    if (lane == 0) mean[g.order[i]] = sum / (double)k;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -88,10 +88,15 @@ def icp_regression(target, source, voxel_size=5, threshold=100, global_regressio
     return target, source, init_tf
 
 
-def _post_filter(cloud, min_friends, min_dist, nb_neighbors):
+def _post_filter(cloud, min_friends, min_dist, nb_neighbors, voxel_size=None):
     cloud, _ = cloud.remove_radius_outlier(nb_points=min_friends, radius=min_dist)
     std_ratio = np.abs(np.std(np.abs(np.array(cloud.compute_mahalanobis_distance()))))
-    cloud, _ = cloud.remove_statistical_outlier(nb_neighbors=nb_neighbors, std_ratio=std_ratio, cell_hint=min_dist)
+    # search-cell hint for the k-NN (speed only, any value is exact): after the radius filter every point has min_friends neighbours
+    # within min_dist; on a surface voxelised at `voxel_size` the k nearest lie within ~voxel * sqrt(k / pi)
+    hint = float(min_dist)
+    if voxel_size:
+        hint = max(hint, 1.5 * float(voxel_size) * float(np.sqrt(nb_neighbors / np.pi)))
+    cloud, _ = cloud.remove_statistical_outlier(nb_neighbors=nb_neighbors, std_ratio=std_ratio, cell_hint=hint)
     return cloud
 
 
@@ -109,7 +114,7 @@ def align_point_clouds(point_clouds, min_friends, min_dist, nb_neighbors, plot=F
         source = source.transform(init_tf)
         target.points = np.concatenate((np.array(source.points), np.array(target.points)))
         target = target.voxel_down_sample(voxel_size=voxel_size)
-        target = _post_filter(target, min_friends, min_dist, nb_neighbors)
+        target = _post_filter(target, min_friends, min_dist, nb_neighbors, voxel_size)
     return target
 
 
@@ -118,7 +123,7 @@ def get_surface(label, depth_frame, intr, robot2Cam_ft, min_friends, min_dist, n
     statistical filter with std_ratio = std(|mahalanobis|)."""
     surface = _pc.surface_points(label, depth_frame, intr, robot2Cam_ft)
     surface = surface.voxel_down_sample(voxel_size=voxel_size)
-    return _post_filter(surface, min_friends, min_dist, nb_neighbors)
+    return _post_filter(surface, min_friends, min_dist, nb_neighbors, voxel_size)
 
 
 def fuse_surfaces(surfaces, voxel_size=2, threshold=10, voxel_size_out=None, icp_point2point=True, icp_point2plane=False):
