@@ -1,19 +1,33 @@
-"""Drop-in for the evaluation side of DenseFusion/datasets/myDatasetAugmented/dataset.py: `get_bbox` (reference :338-380)
-and `PoseDataset` in **test mode** (`__getitem__` :158-326 without augmentation -- `add_noise=False` is what
-experiments/eval.py:37 uses).  Training-mode augmentation (ColorJitter, random rotation, extra data mixing) is out of
-scope.
+"""Drop-in for DenseFusion/datasets/myDatasetAugmented/dataset.py: `get_bbox` (reference :338-380) and `PoseDataset`
+(`__init__` :24-155, `__getitem__` :158-326) in **test** mode (what experiments/eval.py:37 uses) and in **train** mode with the
+reference's augmentation: viewpoint sub-selection (`p_viewpoints`), extra-data mixing (`p_extra_data`), colour jitter, a random in-plane
+rotation of colour / label / depth with the matching camera rotation, and translation noise (`noise_trans`).
 
-The sample tuple is the reference's: (points[N,3] f32, choose[1,N] i64, img[3,Hc,Wc] f32, target[M,3] f32,
-model_points[M,3] f32, idx[1] i64, intr dict, np_img).  The two unseeded random draws of the reference (the `choose`
-sub-selection :256-260 and the model-point thinning :286-288) use a `numpy.random.Generator` seeded per sample."""
+The sample tuple is the reference's: (points[N,3] f32, choose[1,N] i64, img[3,Hc,Wc] f32, target[M,3] f32, model_points[M,3] f32,
+idx[1] i64[, intr dict, np_img in test mode]).
+
+Random draws.  The reference draws from the GLOBAL `random` / `numpy.random` states (viewpoint shuffle :66, extra-data shuffle :93,
+ColorJitter, `random.uniform(-180, 180)` :211, three `random.uniform` for the translation noise :250, `np.random.shuffle(c_mask)` :257,
+`random.sample(dellist, ...)` :287).  With `reference_rng=True` this class makes exactly those calls in exactly that order, so seeding
+both global generators reproduces the reference's sample stream (`tests/test_pose_dataset_golden.py`, fixture made by running the
+reference's class, `tools/gen_golden_dataset.py`).  By default (`reference_rng=False`) every sample draws from its own
+`numpy.random.Generator` seeded by `(seed, index, epoch-free)`, which makes `ds[i]` reproducible regardless of access order.
+
+Colour jitter: torchvision (0.6.1 in the reference's README) is third-party and absent from the reference tree; `ColorJitterPIL`
+restates its published PIL path (`transforms.ColorJitter.get_params` + `functional.adjust_{brightness,contrast,saturation,hue}`)
+-- parity unpinned for the jitter itself, everything around it is pinned with the jitter injected (`trancolor=`).
+
+Model clouds: this file's own `.xyz` parser (:121-137) drops the LAST CHARACTER of every line's z value (`readline()[1:-2]` then
+`[:-1]`), unlike pipeline/utils.py:667-684; restated as is, because the training targets of the reference are built from it."""
 import json
 import os
+import random
 
 import numpy as np
 import torch
+from PIL import Image, ImageEnhance
 
 from autoposeestimation_amd.data_generation import sample_io as io
-from autoposeestimation_amd.pipeline.utils import read_xyz_cloud
 
 border_list = [-1, 40, 80, 120, 160, 200, 240, 280, 320, 360, 400, 440, 480, 520, 560, 600, 640, 680]
 img_width = 480
@@ -49,17 +63,140 @@ def get_bbox(label):
     return rmin, rmax, cmin, cmax
 
 
+def read_xyz_dataset(path, to_meter=True):
+    """the reference dataset's own `.xyz` parser (dataset.py:121-137), quirk included: `line[1:-2]` strips '[' and ']\\n', then
+    `[:-1]` drops one more character -- the last digit of z"""
+    pts = []
+    with open(path) as f:
+        while True:
+            line = f.readline()[1:-2]
+            if not line:
+                break
+            xyz = [float(v) / 1000 if to_meter else float(v) for v in line[:-1].split(" ") if v != ""]
+            pts.append([xyz[0], xyz[1], xyz[2]])
+    return np.array(pts)
+
+
+class ColorJitterPIL:
+    """torchvision 0.6.1 `transforms.ColorJitter(brightness, contrast, saturation, hue)` on PIL images (published algorithm: factors
+    from `random.uniform`, the four adjustments in `random.shuffle`d order; brightness / contrast / saturation through
+    `PIL.ImageEnhance`, hue as a uint8 shift of the H channel in HSV)."""
+
+    def __init__(self, brightness=0.0, contrast=0.0, saturation=0.0, hue=0.0):
+        self.brightness = (max(0.0, 1 - brightness), 1 + brightness) if brightness else None
+        self.contrast = (max(0.0, 1 - contrast), 1 + contrast) if contrast else None
+        self.saturation = (max(0.0, 1 - saturation), 1 + saturation) if saturation else None
+        self.hue = (-hue, hue) if hue else None
+
+    @staticmethod
+    def adjust_hue(img, hue_factor):
+        mode = img.mode
+        if mode in {"L", "1", "I", "F"}:
+            return img
+        h, s, v = img.convert("HSV").split()
+        np_h = np.array(h, dtype=np.uint8)
+        np_h += np.uint8(int(hue_factor * 255) & 0xFF)           # `np.uint8(hue_factor * 255)` of the original: truncate, wrap mod 256
+        return Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert(mode)
+
+    def params(self, uniform=random.uniform, shuffle=random.shuffle):
+        ops = []
+        if self.brightness is not None:
+            ops.append(("brightness", uniform(*self.brightness)))
+        if self.contrast is not None:
+            ops.append(("contrast", uniform(*self.contrast)))
+        if self.saturation is not None:
+            ops.append(("saturation", uniform(*self.saturation)))
+        if self.hue is not None:
+            ops.append(("hue", uniform(*self.hue)))
+        shuffle(ops)
+        return ops
+
+    @classmethod
+    def apply(cls, img, ops):
+        for name, f in ops:
+            if name == "brightness":
+                img = ImageEnhance.Brightness(img).enhance(f)
+            elif name == "contrast":
+                img = ImageEnhance.Contrast(img).enhance(f)
+            elif name == "saturation":
+                img = ImageEnhance.Color(img).enhance(f)
+            else:
+                img = cls.adjust_hue(img, f)
+        return img
+
+    def __call__(self, img, uniform=random.uniform, shuffle=random.shuffle):
+        return self.apply(img, self.params(uniform, shuffle))
+
+
+class _GlobalDraws:
+    """the reference's generators: module-level `random` and `numpy.random`"""
+    uniform = staticmethod(random.uniform)
+    shuffle_list = staticmethod(random.shuffle)
+    shuffle_array = staticmethod(np.random.shuffle)
+
+    @staticmethod
+    def sample(n, k):
+        return random.sample([j for j in range(n)], k)
+
+
+class _SeededDraws:
+    def __init__(self, *key):
+        self.g = np.random.default_rng([int(k) & 0x7fffffff for k in key])
+
+    def uniform(self, a, b):
+        return float(self.g.uniform(a, b))
+
+    def shuffle_list(self, x):
+        order = self.g.permutation(len(x))
+        x[:] = [x[i] for i in order]
+
+    def shuffle_array(self, x):
+        self.g.shuffle(x)
+
+    def sample(self, n, k):
+        return self.g.choice(n, size=k, replace=False).tolist()
+
+
 class PoseDataset(torch.utils.data.Dataset):
     def __init__(self, mode, num_pt, add_noise, noise_trans, refine, data_set_name, root, show_sample=False, to_meter=True,
-                 label_mode="new_pred", p_extra_data=0.0, p_viewpoints=1.0, seed=0):
-        if mode != "test" or add_noise:
-            raise NotImplementedError("only the evaluation form (mode='test', add_noise=False) is provided; training is out of scope")
+                 label_mode="new_pred", p_extra_data=0.0, p_viewpoints=1.0, seed=0, reference_rng=False, trancolor=None):
+        if mode not in ("train", "test"):
+            raise ValueError("mode must be 'train' or 'test'")
         ds = os.path.join(root, "label_generator/data_sets/pose_estimation", data_set_name)
         self.mode, self.to_meter, self.num_pt, self.label_mode, self.refine, self.seed = mode, to_meter, num_pt, label_mode, refine, seed
+        self.add_noise, self.noise_trans, self.show_sample = add_noise, noise_trans, show_sample
+        self.p_extra_data, self.p_viewpoints, self.reference_rng = p_extra_data, p_viewpoints, reference_rng
         self.root = os.path.join(root, "data_generation/data")
         self.label_root = os.path.join(root, "label_generator/data")
-        with open(os.path.join(ds, "test_data_list.txt")) as f:
+        draws = _GlobalDraws if reference_rng else _SeededDraws(seed, 0x5eed)
+        with open(os.path.join(ds, "train_data_list.txt" if mode == "train" else "test_data_list.txt")) as f:
             self.list = [ln.strip() for ln in f if ln.strip()]
+        self.n_extra_samples, self.extra_data = 0, []
+        if mode == "train":
+            # viewpoint sub-selection (:57-74): the ids of the FIRST directory's samples are the view points
+            start_l = self.list[0].split("/")[1]
+            viewpoint_ids = []
+            for ln in self.list:
+                if ln.split("/")[1] != start_l:
+                    break
+                viewpoint_ids.append(ln[-6:])
+            viewpoint_ids = np.array(viewpoint_ids)
+            draws.shuffle_array(viewpoint_ids)
+            viewpoints = viewpoint_ids[:int(len(viewpoint_ids) * self.p_viewpoints)]
+            self.list = [ln for ln in self.list if ln[-6:] in viewpoints]
+            if self.p_extra_data >= 0:                           # :77-97 (the reference's test is >= 0, so the list file must exist)
+                ids = [int(v) for v in viewpoints]
+                with open(os.path.join(ds, "extra_train_data_list.txt")) as f:
+                    for ln in (x.strip() for x in f):
+                        if ln and io.read_meta(os.path.join(self.root, os.path.dirname(ln)), os.path.basename(ln))["view_point_id"] in ids:
+                            self.extra_data.append(ln)
+                self.len_extra_data = len(self.extra_data)
+                self.extra_data_ids = np.arange(self.len_extra_data)
+                draws.shuffle_array(self.extra_data_ids)
+                self.extra_data_index = 0
+                self.n_extra_samples = int(len(self.list) * p_extra_data)
+        self.len_data = len(self.list)
+        self.length = self.len_data + self.n_extra_samples
         self.class_id_names, self.cld, self.symmetry_obj_idx = [], {}, []
         with open(os.path.join(ds, "classes.txt")) as f:
             for class_id, name in enumerate(ln.strip() for ln in f if ln.strip()):
@@ -73,10 +210,12 @@ class PoseDataset(torch.utils.data.Dataset):
                             if bool(json.load(mf).get("symmetric", False)):
                                 self.symmetry_obj_idx.append(class_id)
                         break
-                self.cld[class_id] = read_xyz_cloud(os.path.join(root, "pc_reconstruction/data", name, "{}.xyz".format(name)), to_meter)
+                self.cld[class_id] = read_xyz_dataset(os.path.join(root, "pc_reconstruction/data", name, "{}.xyz".format(name)), to_meter)
         self.num_classes = len(self.class_id_names)
+        self.trancolor = trancolor if trancolor is not None else ColorJitterPIL(0.2, 0.2, 0.2, 0.05)
         self.num_pt_mesh = 1000
-        self.length = len(self.list)
+        self.minimum_num_pt = 50
+        self.front_num = 2
 
     def __len__(self):
         return self.length
@@ -88,27 +227,55 @@ class PoseDataset(torch.utils.data.Dataset):
         return self.num_pt_mesh
 
     def __getitem__(self, index):
-        rel = self.list[index]
+        draws = _GlobalDraws if self.reference_rng else _SeededDraws(self.seed, index)
+        if index < self.len_data:
+            rel, lmode = self.list[index], self.label_mode
+        elif index < self.length:
+            # extra samples are handed out round-robin from the (filtered) extra list (:176-192); note the reference indexes
+            # `extra_data[extra_data_index]`, not the shuffled ids
+            rel, lmode = self.extra_data[self.extra_data_index], "new_pred"
+            self.extra_data_index += 1
+            if self.extra_data_index >= self.len_extra_data:
+                self.extra_data_ids = np.arange(self.len_extra_data)
+                (_GlobalDraws if self.reference_rng else _SeededDraws(self.seed, index, 1)).shuffle_array(self.extra_data_ids)
+                self.extra_data_index = 0
+        else:
+            raise ValueError
         d, sid = os.path.dirname(rel), os.path.basename(rel)
-        img = io.read_color(os.path.join(self.root, d), sid)
-        depth = io.read_depth(os.path.join(self.root, d), sid)
+        img = Image.open(os.path.join(self.root, d, "{}.color.png".format(sid)))
+        depth = Image.open(os.path.join(self.root, d, "{}.depth.png".format(sid)))
         image_meta = io.read_meta(os.path.join(self.root, d), sid)
-        label = io.read_label(os.path.join(self.label_root, d), sid, self.label_mode)
+        label = Image.open(os.path.join(self.label_root, d, "{}.{}.label.png".format(sid, lmode)))
         with open(os.path.join(self.label_root, d, "{}.meta.json".format(sid))) as f:
             meta = json.load(f)
         intr = image_meta["intr"]
         obj = self.class_id_names.index(meta["cls_name"])
-        cam2object = np.dot(np.array(meta["cam2robot"]).reshape(4, 4), np.array(meta["robot2object"]).reshape(4, 4))
-        target_r, target_t = cam2object[:3, :3], cam2object[:3, 3] / (1000 if self.to_meter else 1)
+        cam2robot = np.array(meta["cam2robot"]).reshape(4, 4)
+        if self.add_noise:
+            if isinstance(self.trancolor, ColorJitterPIL):
+                img = self.trancolor(img, draws.uniform, draws.shuffle_list)
+            else:
+                img = self.trancolor(img)
+            angle = draws.uniform(-180, 180)                     # :211-217: in-plane rotation, PIL's default nearest resampling
+            a = np.deg2rad(angle)
+            augment_rotation = np.identity(4)
+            augment_rotation[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]   # euler2mat(0, 0, a) = Rz(a)
+            img, label, depth = img.rotate(angle), label.rotate(angle), depth.rotate(angle)
+            cam2robot = np.dot(np.linalg.inv(augment_rotation), cam2robot)
+        cam2object = np.dot(cam2robot, np.array(meta["robot2object"]).reshape(4, 4))
+        target_r, target_t = cam2object[:3, :3], cam2object[:3, 3]
+        if self.to_meter:
+            target_t = target_t / 1000
+        img, label, depth = np.array(img), np.array(label), np.array(depth)
         mask_label = label == 255
         rmin, rmax, cmin, cmax = get_bbox(mask_label)
         mask = mask_label * (depth != 0)
-        rng = np.random.default_rng([self.seed, index])
+        add_t = np.array([draws.uniform(-self.noise_trans, self.noise_trans) for _ in range(3)]) if self.add_noise else None
         choose = mask[rmin:rmax, cmin:cmax].flatten().nonzero()[0]
         if len(choose) > self.num_pt:
             c_mask = np.zeros(len(choose), dtype=int)
             c_mask[:self.num_pt] = 1
-            rng.shuffle(c_mask)
+            draws.shuffle_array(c_mask)
             choose = choose[c_mask.nonzero()]
         else:
             choose = np.pad(choose, (0, self.num_pt - len(choose)), "wrap")
@@ -120,12 +287,16 @@ class PoseDataset(torch.utils.data.Dataset):
         if not self.to_meter:
             pt2 = pt2 * 1000
         cloud = np.concatenate(((cols - intr["ppx"]) * pt2 / intr["fx"], (rows - intr["ppy"]) * pt2 / intr["fy"], pt2), axis=1)
+        if self.add_noise:
+            cloud = np.add(cloud, add_t)
         cld = self.cld[obj]
-        keep = np.sort(rng.choice(len(cld), size=self.num_pt_mesh, replace=False)) if len(cld) > self.num_pt_mesh else np.arange(len(cld))
-        model_points = cld[keep]
-        target = np.dot(model_points, target_r.T) + target_t
+        dellist = draws.sample(len(cld), len(cld) - self.num_pt_mesh) if len(cld) > self.num_pt_mesh else []   # (the reference raises below 1000)
+        model_points = np.delete(cld, dellist, axis=0)
+        target = np.dot(model_points, target_r.T)
+        target = np.add(target, target_t + add_t) if self.add_noise else np.add(target, target_t)
         img_masked = np.transpose(img[:, :, :3], (2, 0, 1))[:, rmin:rmax, cmin:cmax].astype(np.float32)
         img_n = (torch.from_numpy(img_masked) - torch.from_numpy(_MEAN)[:, None, None]) / torch.from_numpy(_STD)[:, None, None]
-        return (torch.from_numpy(cloud.astype(np.float32)), torch.LongTensor(choose[None].astype(np.int64)), img_n,
-                torch.from_numpy(target.astype(np.float32)), torch.from_numpy(model_points.astype(np.float32)),
-                torch.LongTensor([int(obj)]), intr, img.copy())
+        out = (torch.from_numpy(cloud.astype(np.float32)), torch.LongTensor(choose[None].astype(np.int64)), img_n,
+               torch.from_numpy(target.astype(np.float32)), torch.from_numpy(model_points.astype(np.float32)),
+               torch.LongTensor([int(obj)]))
+        return out + (intr, img.copy()) if self.mode == "test" else out

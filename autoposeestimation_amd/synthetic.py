@@ -240,3 +240,69 @@ def label_views(n_views, seed=0, cloud=None, distance=500.0):
         depth = render_depth(cloud, cam)
         views.append(((depth != 0).astype(np.uint8) * 255, depth, cam))
     return views
+
+
+def pose_dataset_tree(root, data_set_name="synth", n_view=5, n_extra=3, seed=3):
+    """A small pose-estimation data set in the reference's on-disk layout (data_generation/getData.py:177-221,
+    label_generator/create_labels.py:422-429, create_pointcloud.py:373-376, make_train_and_test_dataset): two classes (the second
+    symmetric), `n_view` view-point samples each under `<cls>/foreground`, `n_extra` extra samples under `<cls>/extra`, label PNGs in
+    all three label modes, pose-label JSONs, `.xyz` model clouds (1200 points, mm) and the list files.  Deterministic in `seed`;
+    shared by tools/gen_golden_dataset.py (which runs the REFERENCE's PoseDataset on it) and tests/test_pose_dataset_golden.py."""
+    import json
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    classes = ["objA", "objB"]
+    ds = os.path.join(root, "label_generator/data_sets/pose_estimation", data_set_name)
+    os.makedirs(ds, exist_ok=True)
+    train, test, extra = [], [], []
+    for ci, cls in enumerate(classes):
+        cloud = (rng.uniform(-40, 40, (1200, 3)) * [1.0, 0.7, 0.5]).round(3)
+        os.makedirs(os.path.join(root, "pc_reconstruction/data", cls), exist_ok=True)
+        with open(os.path.join(root, "pc_reconstruction/data", cls, cls + ".xyz"), "w") as f:
+            for item in cloud:
+                f.write("%s\n" % item)                          # numpy's repr of the point, as create_pointcloud.py:373-376 writes it
+        for sub, n in (("foreground", n_view), ("extra", n_extra)):
+            ddir = os.path.join(root, "data_generation/data", cls, sub)
+            ldir = os.path.join(root, "label_generator/data", cls, sub)
+            os.makedirs(ddir, exist_ok=True)
+            os.makedirs(ldir, exist_ok=True)
+            for i in range(n):
+                sid = "%06d" % i
+                h, w = 480, 640
+                r0, c0 = int(rng.integers(60, 250)), int(rng.integers(80, 380))
+                hh, ww = int(rng.integers(70, 150)), int(rng.integers(70, 170))
+                yy, xx = np.mgrid[0:h, 0:w]
+                inside = (((yy - r0 - hh / 2) / (hh / 2)) ** 2 + ((xx - c0 - ww / 2) / (ww / 2)) ** 2) < 1
+                rgb = (rng.integers(0, 60, (h, w, 3)) + 90).astype(np.uint8)
+                rgb[inside] = (CLASS_COLOURS[ci] * 0.8).astype(np.uint8) + rng.integers(0, 40, (int(inside.sum()), 3)).astype(np.uint8)
+                depth = np.full((h, w), 620, np.uint16) + (xx // 40).astype(np.uint16)
+                depth[inside] = (560 + 25 * np.sin(xx[inside] / 17.0) + 15 * np.cos(yy[inside] / 13.0)).astype(np.uint16)
+                depth[rng.random((h, w)) < 0.03] = 0
+                Image.fromarray(rgb).save(os.path.join(ddir, sid + ".color.png"))
+                Image.fromarray(depth).save(os.path.join(ddir, sid + ".depth.png"))
+                meta = {"intr": dict(REALSENSE_META["intr"]), "depth_scale": 0.001, "symmetric": bool(ci == 1), "view_point_id": i % n_view,
+                        "robot2endEff_tf": np.eye(4).flatten().tolist(), "hand_eye_calibration": np.eye(4).flatten().tolist(),
+                        "object_pose": np.eye(4).flatten().tolist()}
+                with open(os.path.join(ddir, sid + ".meta.json"), "w") as f:
+                    json.dump(meta, f)
+                lab = inside.astype(np.uint8) * 255
+                for mode in ("gen", "pred", "new_pred"):
+                    Image.fromarray(lab).save(os.path.join(ldir, "%s.%s.label.png" % (sid, mode)))
+                cam2robot = rigid(rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-3, 3), tuple(rng.uniform(-50, 50, 3)))
+                robot2object = rigid(rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1), tuple(rng.uniform(-30, 30, 2)) + (float(rng.uniform(500, 650)),))
+                with open(os.path.join(ldir, sid + ".meta.json"), "w") as f:
+                    json.dump({"cls_name": cls, "cam2robot": cam2robot.flatten().tolist(), "robot2object": robot2object.flatten().tolist()}, f)
+                rel = "%s/%s/%s" % (cls, sub, sid)
+                if sub == "extra":
+                    extra.append(rel)
+                elif i == n - 1:
+                    test.append(rel)
+                else:
+                    train.append(rel)
+    with open(os.path.join(ds, "classes.txt"), "w") as f:
+        f.write("".join(c + "\n" for c in classes))
+    for name, items in (("train_data_list.txt", train), ("test_data_list.txt", test), ("extra_train_data_list.txt", extra)):
+        with open(os.path.join(ds, name), "w") as f:
+            f.write("".join(x + "\n" for x in items))
+    return classes, train, test, extra
