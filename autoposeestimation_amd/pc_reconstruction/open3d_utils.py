@@ -159,13 +159,18 @@ def fuse_views(views, intr, voxel_size=2, threshold=10, min_friends=20, min_dist
     from autoposeestimation_amd import sharding
     make_set, fuse = _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point,
                                     icp_point2plane)
-    res = sharding.sharded_chain(list(views), make_set, fuse, owner, dist)
+    res = sharding.sharded_chain(list(views), make_set, fuse, owner, dist, load=_load_view)
     return res if res is not None else (None, None)
+
+
+def _load_view(view):
+    """a callable view decodes its files (host threads, ahead of the GPU: sharding.prefetched); arrays / tensors pass through"""
+    return view() if callable(view) else view
 
 
 def _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point, icp_point2plane):
     def make_set(view):
-        label, depth, robot2cam = view() if callable(view) else view       # a callable decodes its files only on the rank that owns the view
+        label, depth, robot2cam = view() if callable(view) else view       # (already decoded when it came through _load_view)
         return get_surface(label, depth, intr, robot2cam, min_friends, min_dist, nb_neighbors, voxel_size)._p
 
     def fuse(sets):
@@ -189,7 +194,7 @@ def fuse_chains(chains, intr, voxel_size=2, threshold=10, min_friends=20, min_di
     from autoposeestimation_amd import sharding
     make_set, fuse = _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point,
                                     icp_point2plane)
-    return sharding.sharded_chains([list(v) for v in chains], make_set, fuse, dist)
+    return sharding.sharded_chains([list(v) for v in chains], make_set, fuse, dist, load=_load_view)
 
 
 import torch  # noqa: E402

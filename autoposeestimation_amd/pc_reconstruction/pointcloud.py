@@ -7,6 +7,7 @@ scipy/numpy restatement (oracle/pointcloud_oracle.py) plus recover-a-known-trans
 Points live on the GPU as a contiguous float64 [n,3] tensor; `np.array(pcd.points)` / `np.asarray(pcd.points)` copies to
 the host like open3d's Vector3dVector does; assigning `pcd.points = array` uploads.  No CPU fallback."""
 import ctypes
+import threading
 import math
 import os
 
@@ -319,6 +320,7 @@ def _point_to_plane(s):
 
 
 ICP_STATS = None          # bench.py --workload label sets a dict here: registrations, evaluations, point pairs, (start, end) events
+_ICP_STATS_LOCK = threading.Lock()     # registrations of different chains run on different host threads (sharding.run_side_by_side)
 _ICP_CHUNK = 6            # iterations enqueued per device round trip; the reference's criteria (1e-2 relative) stop after 2-4
 
 
@@ -367,11 +369,12 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
         if ICP_STATS is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
-            ICP_STATS["registrations"] += 1
-            ICP_STATS["evaluations"] += int(out[1]) + 1
-            ICP_STATS["pairs"] += (int(out[1]) + 1) * ns
-            ICP_STATS["kind%d" % estimation_method.kind] = ICP_STATS.get("kind%d" % estimation_method.kind, 0) + (int(out[1]) + 1) * ns
-            ICP_STATS["events"].append((ev0, ev1))
+            with _ICP_STATS_LOCK:
+                ICP_STATS["registrations"] += 1
+                ICP_STATS["evaluations"] += int(out[1]) + 1
+                ICP_STATS["pairs"] += (int(out[1]) + 1) * ns
+                ICP_STATS["kind%d" % estimation_method.kind] = ICP_STATS.get("kind%d" % estimation_method.kind, 0) + (int(out[1]) + 1) * ns
+                ICP_STATS["events"].append((ev0, ev1))
         return RegistrationResult(out[5:21].reshape(4, 4).copy(), float(out[2]), float(out[3]), int(out[4]))
 
     def evaluate():

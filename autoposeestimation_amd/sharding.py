@@ -8,6 +8,8 @@ order-dependent (create_pointcloud.py:288-312), so a chain is owned by ONE rank 
 per-view work (decode, `get_surface` incl. its filters): every rank pre-processes its `shard_range` of the chain's views and ONE
 padded all-gather (`gather_point_sets`) hands the variable-length surfaces to the owner, which registers them in view order --
 bit-identical to the single-rank chain because the surfaces are the same arrays in the same order."""
+import os
+
 import numpy as np
 import torch
 
@@ -91,18 +93,72 @@ def gather_point_sets(local_sets, n_total, dist=None):
     return out
 
 
-def sharded_chain(items, make_set, fuse, owner, dist=None):
+def prefetched(items, load, workers=8, window=32):
+    """`load(item)` for every item, in order, computed up to `window` items ahead on `workers` host threads (PNG decode and file reads
+    release the GIL): the host-side decode of the next views runs while the GPU works on the current one."""
+    if load is None:
+        yield from items
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        pending, it = deque(), iter(items)
+        for item in it:
+            pending.append(ex.submit(load, item))
+            if len(pending) >= window:
+                break
+        while pending:
+            out = pending.popleft().result()
+            for item in it:
+                pending.append(ex.submit(load, item))
+                break
+            yield out
+
+
+def run_side_by_side(jobs, workers=None):
+    """[job() for job in jobs] with up to `workers` of them in flight, each on its own host thread AND its own HIP stream: the label
+    path's units (views, chains) are chains of tiny dependent kernels with a host read-back here and there -- one of them leaves the
+    GPU idle most of the time, several side by side fill it (ctypes calls and the blocking copies release the GIL).  Every job starts
+    after the caller's stream (its inputs are ready) and is synchronised before its result is handed back; results keep job order.
+    Falls back to a plain loop without a GPU (gloo tests) or for a single job."""
+    if workers is None:
+        workers = int(os.environ.get("APE_SIDE_WORKERS", "3"))     # measured on one MI355X (200-view label bench): 1: 429, 2: 524, 3: 588, 4: 459 views/s
+                                                                   # -- the jobs' Python halves share the GIL, more threads only contend
+    if len(jobs) <= 1 or workers <= 1 or not torch.cuda.is_available():
+        return [job() for job in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+    dev = torch.cuda.current_device()
+    parent = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(parent)
+
+    def run(job):
+        torch.cuda.set_device(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            out = job()
+        side.synchronize()
+        return out
+
+    with ThreadPoolExecutor(max_workers=min(workers, len(jobs))) as ex:
+        return list(ex.map(run, jobs))
+
+
+def sharded_chain(items, make_set, fuse, owner, dist=None, load=None):
     """One chain: `items` (its views, in fusion order) -> make_set(item) for this rank's shard_range of them -> one padded all-gather
-    -> `fuse(list of point arrays in item order)` on the owner rank only (None elsewhere)."""
+    -> `fuse(list of point arrays in item order)` on the owner rank only (None elsewhere).  `load`: optional host-side stage
+    (decode) run ahead on threads, make_set then receives load(item)."""
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     lo, hi = shard_range(len(items), rank, world)
-    local = [(i, make_set(items[i])) for i in range(lo, hi)]
+    loaded = list(prefetched(items[lo:hi], load))
+    local = list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
     sets = gather_point_sets(local, len(items), dist)
     return fuse(sets) if rank == owner else None
 
 
-def sharded_chains(chains, make_set, fuse, dist=None):
+def sharded_chains(chains, make_set, fuse, dist=None, load=None):
     """Several chains at once: `chains` = list of item lists.  The per-item work of ALL chains is spread over the ranks as one flat
     list (balanced even when chains differ in length), ONE padded all-gather distributes the sets, and then every rank fuses the
     chains it owns (`chain_owner`) -- the sequential, order-dependent parts of different chains run side by side on different GPUs,
@@ -112,11 +168,13 @@ def sharded_chains(chains, make_set, fuse, dist=None):
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     flat = [(ci, item) for ci, items in enumerate(chains) for item in items]
     lo, hi = shard_range(len(flat), rank, world)
-    local = [(i, make_set(flat[i][1])) for i in range(lo, hi)]
+    loaded = list(prefetched([f[1] for f in flat[lo:hi]], load))
+    local = list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
     sets = gather_point_sets(local, len(flat), dist)
-    out, pos = {}, 0
+    mine, pos = [], 0
     for ci, items in enumerate(chains):
         if chain_owner(ci, world) == rank:
-            out[ci] = fuse(sets[pos:pos + len(items)])
+            mine.append((ci, sets[pos:pos + len(items)]))
         pos += len(items)
-    return out
+    fused = run_side_by_side([lambda part=part: fuse(part) for _, part in mine])       # this rank's chains, side by side
+    return {ci: res for (ci, _), res in zip(mine, fused)}
