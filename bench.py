@@ -317,8 +317,8 @@ def label_main(args, rank, world, device, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps (default 40: about 1.5 s of GPU work at 64 frames per step)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--frames", type=int, default=0,
                     help="BASELINE configs[3]: a step = this many frames in TOTAL, sharded over the ranks (strong scaling; each rank "
