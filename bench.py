@@ -464,6 +464,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
 
+    # With the software-pipelined loop the pose stage of the previous batch runs BESIDE the timed kernels on a second stream, so their
+    # HIP-event durations in the timed region include what the co-running launches cost them (throughput goes up, every kernel takes
+    # longer).  A short single-stream pass AFTER the timed region (not part of `value`) times the same five kernels alone; both sets
+    # are reported (`frac` / `avg_launch_us` = timed region, `isolated_*` = alone).
+    iso_summ = None
+    if args.overlap and top_only:
+        pipe_iso = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
+        E.PROFILE = E.LaunchProfile(only=top_only)
+        for i in range(3):
+            for c in range(n_chunks):
+                tail(pipe_iso.run(rgb[c], depth[c], S.REALSENSE_META, seed=i), (10 ** 6 + i, c))
+        fence()
+        iso_summ = E.PROFILE.summary()
+        E.PROFILE = None
+
     if rank == 0:
         summ = prof.summary()
         by_shape = prof.summary(by_shape=True)
@@ -479,6 +494,13 @@ def main():
                  "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3), "avg_launch_algorithmic_mb": round(alg_b / 1e6, 1),
                  "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / alg_b, 2),
                  "share_of_step_time": round(sec / dt, 3)}
+            if iso_summ and label in iso_summ:
+                di = iso_summ[label]
+                sec_i = di["ms"] * 1e-3
+                ach_i = (di["bytes"] / sec_i / 1e9) if bound == "hbm" else (di["flop"] / sec_i / 1e12)
+                e["isolated_avg_launch_us"] = round(di["ms"] / di["launches"] * 1e3, 1)
+                e["isolated_achieved"] = round(ach_i, 2)
+                e["isolated_frac"] = round(ach_i / peak, 4)
             if shapes:
                 e["shapes"] = shapes
             return e
@@ -504,7 +526,9 @@ def main():
             roofline["note"] = ("achieved = algorithmic flop (2*M*Cout*KH*KW*Cin; a split-bf16 kernel issues 3 MFMAs per product, so its peak is the bf16 "
                                 "dense peak / 3) or algorithmic bytes per launch / HIP-event time on the launch stream, timed region only; traffic = "
                                 "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), averaged over the kernel's shapes"
-                                + ("; --overlap: the pose stage of the previous step runs beside these kernels on a second stream" if args.overlap else ""))
+                                + ("; the loop is software-pipelined (pose stage of the previous batch on a second stream beside these kernels), so the "
+                                   "timed-region durations include the co-running launches; isolated_* = the same kernels in a single-stream pass "
+                                   "of 3 steps after the timed region" if args.overlap else ""))
         total_frames = per_rank * world * args.steps
         line = {
             "metric": "RGB-D frames/sec (seg+DenseFusion+2-refine), 640x480 N=1000",
