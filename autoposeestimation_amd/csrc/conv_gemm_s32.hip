@@ -46,7 +46,8 @@ struct GemmS32Args {
     int bias_bstride, rows_per_image;
     int out_fmt, res_fmt;   // APE_FMT_F32 / APE_FMT_S32
     int m_tiles, n_tiles, nk;
-    int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads
+    int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads;
+                            // 16: per-workgroup k-tile rotation (valid results; tested against L2 hot-spotting on the shared weight lines: +-0)
 };
 
 __device__ __forceinline__ float act_fn(float v, int act, float alpha)
@@ -142,22 +143,25 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
         const int row = (wave * NB + i) * 8 + (lane >> 3);
         vb[i] = (unsigned)(row * a.K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
     }
+    // experiment (dbg bit 16): every workgroup starts its k-loop at a different k-tile (sum order changes, results stay valid)
+    const int krot = (a.dbg & 16) ? (m_tile * 5 + n_tile * 3) % a.nk : 0;
+    auto koff = [&](int kt) { const int k = kt + krot; return (k >= a.nk ? k - a.nk : k) * 128; };
     auto dma_a = [&](int kt, int slot_bytes) {        // 4 pieces per wave into A ring slot `slot_bytes` / A_STAGE
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], koff(kt), 0, 0);
     };
     auto dma_a_piece = [&](int kt, int slot_bytes, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], kt * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], koff(kt), 0, 0);
     };
     auto dma_b_piece = [&](int kt, int stage, int i) {
         if (i < NB)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], koff(kt), 0, 0);
     };
     auto dma_b = [&](int kt, int stage) {             // NB pieces per wave
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], koff(kt), 0, 0);
     };
 
     // ---- fragment addresses: lane (frow, fc) reads chunk fc (hi) / 4 + fc (lo) of row frow of a 16-row block ----------------
