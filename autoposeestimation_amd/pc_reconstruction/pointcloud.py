@@ -52,6 +52,8 @@ class PointCloud:
         self.device = torch.device(device)
         self._p = torch.zeros(0, 3, dtype=_D, device=self.device)
         self._n = None   # normals
+        self._epoch = 0  # bumped by every in-place change of the coordinates (transform): invalidates the cached search grid
+        self._gcache = None
         if points is not None:
             self.points = points
 
@@ -121,6 +123,7 @@ class PointCloud:
     # -- rigid motions (in place, return self like open3d) ------------------------------------------------------------
     def transform(self, T):
         if len(self):
+            self._epoch += 1
             T, ptr = _host16(T)
             rc = _lib.lib().ape_transform_points_f64(_lib.dptr(self._p, _D), _lib.dptr(self._n), len(self), ptr, _st())
             _lib.check(rc, "ape_transform_points_f64")
@@ -156,6 +159,16 @@ class PointCloud:
         return out
 
     def _grid(self, cell):
+        """search grid of this cloud for cell size `cell`; the last one is kept while the coordinates stay the same tensor, unchanged
+        (icp_regression registers two estimators against the same target)"""
+        c = self._gcache
+        if c is not None and c[0] is self._p and c[1] == float(cell) and c[2] == self._epoch:
+            return c[3]
+        g = self._build_grid(cell)
+        self._gcache = (self._p, float(cell), self._epoch, g)
+        return g
+
+    def _build_grid(self, cell):
         n = len(self)
         g = {"sorted": torch.empty(n, 3, dtype=_D, device=self.device),
              "keys": torch.empty(n, dtype=torch.int64, device=self.device),
