@@ -28,6 +28,7 @@ SIGNATURES = {
     "ape_convert_s32": [_P, _P, _c.c_long, _I, _I, _P],
     "ape_conv_gemm_s32_supported": [_P],
     "ape_conv_gemm_s32_debug": [_I],
+    "ape_conv3x3_halo_s32_debug": [_I],
     "ape_conv_gemm_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
     "ape_conv_gemm_bf16_fmt": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "ape_adaptive_avgpool_multi_nhwc_fmt": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],

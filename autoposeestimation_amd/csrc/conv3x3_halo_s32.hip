@@ -38,6 +38,7 @@ struct HaloS32Args {
     int bias_bstride;
     int out_fmt, res_fmt;
     int tiles_x, tiles_y, n_tiles;
+    int dbg;                // ape_conv3x3_halo_s32_debug: 1 = static priority 1 for waves 4-7 (results unchanged)
 };
 
 __device__ __forceinline__ float act_h(float v, int act, float alpha)
@@ -227,6 +228,9 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // one wave of every SIMD pair at priority 1 for the whole kernel pays in the GEMM kernel (conv_gemm_s32.hip, -1.5 .. -3 %) but not
+    // here (+-0 .. +1 % on all six layer shapes, tools/mb_halo_s32.py): off unless the debug bit asks for it
+    if ((a.dbg & 1) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     // ---- prologue: the whole first image and the first three weight tiles --------------------------------------------------------
     dma_a_rows_xp(0, 0, 0, I, I0{});
     dma_a_rows_xp(0, 0, 0, I, I1{});
@@ -412,6 +416,9 @@ bool halo_s32_supported(const ape_conv_params& p)
 
 }  // namespace
 
+static int g_halo_s32_dbg = 0;
+extern "C" int ape_conv3x3_halo_s32_debug(int bits) { g_halo_s32_dbg = bits; return APE_OK; }
+
 extern "C" int ape_conv3x3_halo_s32_supported(const ape_conv_params* params) { return params && halo_s32_supported(*params) ? 1 : 0; }
 
 extern "C" int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
@@ -425,6 +432,7 @@ extern "C" int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const
     if (residual && (p.roff + p.Cout > p.ldr || p.ldr % 4 || p.roff % 4 || (res_fmt == APE_FMT_S32 && p.ldr % 32))) return APE_EINVAL;
     if (p.B == 0) return APE_OK;
     HaloS32Args a;
+    a.dbg = g_halo_s32_dbg;
     a.x = (const char*)x_s32; a.w = (const char*)w_s32k; a.bias = bias; a.res = (const char*)residual; a.y = (char*)y;
     a.B = p.B; a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Cout = p.Cout;
     a.ldx = p.ldx; a.xoff = p.xoff; a.ldy = p.ldy; a.yoff = p.yoff; a.ldr = p.ldr; a.roff = p.roff;

@@ -47,7 +47,8 @@ struct GemmS32Args {
     int out_fmt, res_fmt;   // APE_FMT_F32 / APE_FMT_S32
     int m_tiles, n_tiles, nk;
     int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads;
-                            // 16: per-workgroup k-tile rotation (valid results; tested against L2 hot-spotting on the shared weight lines: +-0)
+                            // 16: per-workgroup k-tile rotation (valid results; tested against L2 hot-spotting on the shared weight lines: +-0);
+                            // 32: no static priority for waves 4-7
 };
 
 __device__ __forceinline__ float act_fn(float v, int act, float alpha)
@@ -238,6 +239,11 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     // barrier needs tile t+1 landed: B(t+1) was issued one k-tile ago, A(t+1) two k-tiles ago, and the only younger pieces are the
     // four of A(t+2) => vmcnt(4), never 0 in the steady state: up to 96 KB per CU are in flight across the barrier.
     const int nk = a.nk;
+    // Waves 4-7 share their SIMDs with waves 0-3 and would otherwise run every phase in step with them; one of each pair at priority 1
+    // for the whole loop lets that wave's MFMA rows go out ahead while its partner's reads and waits fill in behind (cdna_hip_programming.md
+    // T5, static form): -1.5 .. -3 % on the three segmentation GEMM shapes, any asymmetric choice (prio 1 / 3, either half) alike.
+    // dbg bit 32 switches it off.
+    if (!(a.dbg & 32) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     dma_a(0, 0);
     dma_b(0, 0);
     if (nk > 1) { dma_a(1, A_STAGE); dma_b(1, 1); }

@@ -101,6 +101,7 @@ int ape_pack_weights_s32k(const float* w, void* out, int cout, int K, void* stre
 /* x[rows][C] f32 -> y[rows][C] S32 (to_s32 = 1) or back (to_s32 = 0: hi + lo); C % 32 == 0.  Tests and format boundaries only. */
 int ape_convert_s32(const void* x, void* y, long rows, int C, int to_s32, void* stream);
 int ape_conv_gemm_s32_supported(const ape_conv_params* params_host);
+int ape_conv3x3_halo_s32_debug(int bits);   /* 1 = with a static wave priority for waves 4-7 (tools/mb_halo_s32.py A/B); results unchanged */
 int ape_conv_gemm_s32_debug(int bits);   /* timing ablations (tools/mb_gemm_s32.py); 0 = off, anything else breaks the results */
 int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
                       int out_fmt, const ape_conv_params* params_host, void* stream);

@@ -13,7 +13,14 @@ for name, b, h, w, cin, cout, dil in shapes:
     xs = E.S32.from_f32(x)
     conv = E.Conv(torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5, torch.randn(cout), 1, dil, dil, E.ACT_RELU, device="cuda", precision="bf16x3")
     out = torch.empty(b, h, w, cout, device="cuda")
-    arms = {"halo (fp32 in)": lambda: conv(x, out=out), "halo_s32 -> f32": lambda: conv(xs, out=out), "halo_s32 -> s32": lambda: conv(xs, out=out, out_fmt=E.FMT_S32)}
+    from autoposeestimation_amd import _lib
+
+    def noprio():
+        _lib.lib().ape_conv3x3_halo_s32_debug(1)
+        conv(xs, out=out, out_fmt=E.FMT_S32)
+        _lib.lib().ape_conv3x3_halo_s32_debug(0)
+    arms = {"halo (fp32 in)": lambda: conv(x, out=out), "halo_s32 -> f32": lambda: conv(xs, out=out), "halo_s32 -> s32": lambda: conv(xs, out=out, out_fmt=E.FMT_S32),
+            "  -> s32, static priority": noprio}
     for f in arms.values():
         f()
     torch.cuda.synchronize()
