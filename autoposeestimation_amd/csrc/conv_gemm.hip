@@ -238,6 +238,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     };
 
     const int nk = a.nk;
+    // 8-wave blocks: dbg bit 8 = static priority 1 for waves 4-7 (cf. conv_gemm_s32.hip)
+    if (NT == 512 && (a.dbg & 8) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     load_tiles();
     store_tiles(0);
     load_tiles();

@@ -84,7 +84,7 @@ PROFILE = None   # set to a LaunchProfile() to time conv launches
 PRECISIONS = ("f32", "bf16x3", "bf16")
 USE_HALO_KERNEL = True    # route eligible 3x3 convs of the bf16 paths to the LDS-halo kernel (conv3x3_halo.hip)
 USE_GEMM_KERNEL = os.environ.get("APE_USE_GEMM_KERNEL", "1") != "0"    # route Cin % 32 == 0 layers the halo kernel does not take to conv_gemm.hip (else conv_bf16.hip)
-GEMM_VARIANT = 0          # 0 = chosen from the shape; 1..4 force a block shape (tools/microbench_generic.py)
+GEMM_VARIANT = int(os.environ.get("APE_GEMM_VARIANT", "0"))          # 0 = chosen from the shape; 1..4 force a block shape (tools/microbench_generic.py)
 
 
 FMT_F32, FMT_S32 = 0, 1
