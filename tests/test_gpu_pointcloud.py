@@ -193,6 +193,49 @@ def test_icp_device_loop_degenerate_inputs():
     assert abs(np.linalg.det(a.transformation[:3, :3]) - 1) < 1e-12
 
 
+def test_icp_device_solve_random_small_systems():
+    """One update (max_iteration = 1) on many small random pairings -- generic, nearly planar, badly scaled -- device Jacobi SVD /
+    6x6 elimination against the host LAPACK solve on the same sums; for collinear sources (rotation about the line is free) only a
+    proper rotation and the same residual are required."""
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    rng = np.random.default_rng(77)
+    c1 = PC.ICPConvergenceCriteria(0.0, 0.0, 1)
+    for case in range(36):
+        n = int(rng.choice([3, 4, 6, 10, 60]))
+        kind = case % 3                                  # 0 generic, 1 nearly planar, 2 anisotropic scale
+        pts = rng.standard_normal((n, 3)) * 10.0
+        if kind == 1:
+            pts[:, 2] *= 1e-6
+        if kind == 2:
+            pts *= [3.0, 1.0, 1e-3]
+        pts += np.arange(n)[:, None] * 200.0 * np.array([1.0, 0, 0])       # 200 apart along x: the nearest neighbour is the own partner
+        pts += rng.uniform(-500, 500, 3)
+        c = pts.mean(0)
+        T = _rot(*rng.uniform(-0.002, 0.002, 3), rng.uniform(-0.5, 0.5, 3))
+        src = (pts - c - T[:3, 3]) @ T[:3, :3] + c                          # pts = R (src - c) + c + t: a small motion about the centroid
+        target = PC.PointCloud(pts)
+        nrm = rng.standard_normal((n, 3))
+        target._n = __import__("torch").from_numpy(nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).cuda()
+        for est in (PC.TransformationEstimationPointToPoint(), PC.TransformationEstimationPointToPlane()):
+            if est.kind == 1 and n < 6:
+                continue
+            a = PC.registration_icp(PC.PointCloud(src), target, 50.0, np.eye(4), est, c1)
+            b = PC.registration_icp(PC.PointCloud(src), target, 50.0, np.eye(4), est, c1, host_solve=True)
+            assert a.correspondence_count == b.correspondence_count == n
+            R = a.transformation[:3, :3]
+            assert abs(np.linalg.det(R) - 1) < 1e-9 and np.allclose(R @ R.T, np.eye(3), atol=1e-9), (case, est.kind)
+            scale = max(1.0, np.abs(pts).max())
+            if est.kind == 0:
+                # both solve the same least-squares problem: compare the residual they reach (the minimiser is unique unless rank-deficient)
+                ra = np.linalg.norm(src @ a.transformation[:3, :3].T + a.transformation[:3, 3] - pts)
+                rb = np.linalg.norm(src @ b.transformation[:3, :3].T + b.transformation[:3, 3] - pts)
+                assert abs(ra - rb) <= 1e-9 * scale, (case, ra, rb)
+                if kind == 0 and n >= 4:
+                    np.testing.assert_allclose(a.transformation, b.transformation, atol=1e-9 * scale)
+            else:
+                np.testing.assert_allclose(a.transformation, b.transformation, rtol=0, atol=1e-6 * scale)
+
+
 def test_get_surface_and_sequential_fusion():
     """BASELINE config 5 in miniature: views of a known object rendered through the pin-hole model from perturbed camera
     poses; the reported robot2cam of every view after the first is off by a small rigid error that ICP must absorb."""
