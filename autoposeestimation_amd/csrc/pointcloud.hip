@@ -794,7 +794,11 @@ __device__ void svd3_rotation(const double C[3][3], double R[3][3])
         const int o = ord[j];
         for (int k = 0; k < 3; ++k) { W[k][j] = V[k][o]; U[k][j] = sig[o] > 0 ? A[k][o] / sig[o] : 0.0; }
     }
-    const double tiny = 1e-13 * (sig[ord[0]] > 0 ? sig[ord[0]] : 1.0);
+    if (!(sig[ord[0]] > 0)) {                             // zero covariance (all pairs coincide with their centroids): no rotation to find
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = i == j ? 1.0 : 0.0;
+        return;
+    }
+    const double tiny = 1e-13 * sig[ord[0]];
     if (sig[ord[1]] <= tiny) {                            // rank <= 1: complete U with any orthonormal pair
         double e[3] = {fabs(U[0][0]) < 0.9 ? 1.0 : 0.0, fabs(U[0][0]) < 0.9 ? 0.0 : 1.0, 0.0};
         double d = e[0] * U[0][0] + e[1] * U[1][0] + e[2] * U[2][0];
