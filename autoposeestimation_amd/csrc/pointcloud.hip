@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kT) void nn1_group_kernel(Grid g, const double* __r
 }
 
 // `skip` (optional, in the kernels of the ICP loop): a device word that, once non-zero, turns the launch into a no-op -- the loop runs
-// a fixed number of enqueued iterations and the device decides when it has converged (icp_step_kernel)
+// a fixed number of enqueued iterations and the device decides when it has converged (icp_step)
 
 // smallest-eigenvalue eigenvector of a symmetric 3x3 (cyclic Jacobi, fixed 12 sweeps)
 __device__ void smallest_eigvec(double a[3][3], double v[3])
@@ -753,8 +753,9 @@ extern "C" int ape_select_points_f64(const double* pts, const uint8_t* keep, int
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ICP iteration entirely on the device (open3d 0.9 RegistrationICP as called at pc_reconstruction/open3d_utils.py:96-117): the
 // correspondence search and the 17 / 29 reduced sums were device work already; here the 3x3 SVD (Umeyama, point-to-point) / the 6x6
-// solve (point-to-plane), the composition T <- update . T, the fitness / rmse bookkeeping and the convergence test run in a
-// one-thread kernel between them, so a registration needs ONE device-to-host copy (its result) instead of one per iteration.
+// solve (point-to-plane), the composition T <- update . T, the fitness / rmse bookkeeping and the convergence test run on the tail of
+// the reduction kernel (icp_reduce_step_kernel), so a registration needs ONE device-to-host copy (its result) instead of one per
+// iteration, and an iteration is three launches: [apply the pending update +] correspondence search, partial sums, reduce + step.
 // state[40]: [0] done, [1] updates applied, [2] fitness, [3] inlier rmse, [4] correspondences, [5..20] T (row major), [21..36] the
 // last update, [37] 1 = converged by the relative criteria, 2 = too few correspondences, 3 = iteration limit.
 namespace {
@@ -840,8 +841,7 @@ __device__ bool solve6(double M[6][7])
     return true;
 }
 
-__global__ void icp_step_kernel(int kind, const double* __restrict__ s, double* __restrict__ st, int ns, double rel_fitness, double rel_rmse,
-                                int max_iteration)
+__device__ void icp_step(int kind, const double* s, double* __restrict__ st, int ns, double rel_fitness, double rel_rmse, int max_iteration)
 {
     if (st[0] != 0.0) return;
     const double n_corr = floor(s[0] + 0.5);
@@ -890,13 +890,52 @@ __global__ void icp_step_kernel(int kind, const double* __restrict__ s, double* 
     st[1] += 1.0;
 }
 
-__global__ void icp_transform_kernel(double* __restrict__ pts, int n, const double* __restrict__ st)
+// last stage of the sums reduction (one thread per reduced value, fixed order over the workgroup partials) with the ICP step on its
+// tail: thread 0 runs icp_step on the totals it finds in LDS -- one launch instead of two per iteration
+__global__ __launch_bounds__(64) void icp_reduce_step_kernel(const double* __restrict__ part, int g, int nv, double* __restrict__ sums, int kind,
+                                                             double* __restrict__ st, int ns, double rel_fitness, double rel_rmse, int max_iteration)
 {
     if (st[0] != 0.0) return;
-    const double* T = st + 21;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
-        for (int r = 0; r < 3; ++r) pts[i * 3 + r] = ((T[r * 4] * x + T[r * 4 + 1] * y) + T[r * 4 + 2] * z) + T[r * 4 + 3];
+    __shared__ double tot[32];
+    const int v = threadIdx.x;
+    if (v < nv) { double a = 0; for (int b = 0; b < g; ++b) a += part[b * nv + v]; tot[v] = a; sums[v] = a; }
+    __syncthreads();
+    if (v == 0) icp_step(kind, tot, st, ns, rel_fitness, rel_rmse, max_iteration);
+}
+
+// correspondence search of the ICP loop with the pending update applied on the way: the query is moved by state[21..36] (the update the
+// previous step computed), written back, and searched -- kG lanes per query as in nn1_group_kernel (every lane moves its copy)
+__global__ __launch_bounds__(kT) void icp_move_nn1_kernel(Grid g, double* __restrict__ src, int nq, double r2, int* __restrict__ idx,
+                                                          double* __restrict__ dist2, const double* __restrict__ st, int apply)
+{
+    if (st[0] != 0.0) return;
+    const int lane = threadIdx.x % kG;
+    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    double q[3] = {0, 0, 0};
+    if (i < nq) {
+        const double x = src[(size_t)i * 3], y = src[(size_t)i * 3 + 1], z = src[(size_t)i * 3 + 2];
+        q[0] = x; q[1] = y; q[2] = z;
+        if (apply) {
+            const double* T = st + 21;
+            for (int r = 0; r < 3; ++r) q[r] = ((T[r * 4] * x + T[r * 4 + 1] * y) + T[r * 4 + 2] * z) + T[r * 4 + 3];
+        }
+    }
+    double best = r2;
+    unsigned bi = 0xffffffffu;
+    if (i < nq)
+        for_my_cell(g, q, lane, [&](int j, double d2) {
+            const unsigned o = g.order[j];
+            if (d2 < best || (d2 == best && bi != 0xffffffffu && o < bi)) { best = d2; bi = o; }
+        });
+    for (int m = kG / 2; m >= 1; m >>= 1) {
+        const double ob = __shfl_xor(best, m, kG);
+        const unsigned oi = __shfl_xor(bi, m, kG);
+        if (oi != 0xffffffffu && (bi == 0xffffffffu || ob < best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+    }
+    if (i < nq && lane == 0) {
+        if (apply) { src[(size_t)i * 3] = q[0]; src[(size_t)i * 3 + 1] = q[1]; src[(size_t)i * 3 + 2] = q[2]; }
+        idx[i] = bi == 0xffffffffu ? -1 : (int)bi;
+        dist2[i] = bi == 0xffffffffu ? 0.0 : best;
     }
 }
 
@@ -905,7 +944,8 @@ __global__ void icp_transform_kernel(double* __restrict__ pts, int n, const doub
 /* Enqueue `n_iter` ICP iterations (kind 0 point-to-point, 1 point-to-plane) with everything on the device; see the block comment above.
  * `src` [ns][3] is the source ALREADY transformed by the initial guess and is updated in place; `state` [40] doubles on the device: the
  * caller zeroes it and writes the initial T into state[5..20] before the FIRST call of a registration (first_call = 1 also runs the
- * evaluation that precedes open3d's loop), and reads it back (one copy) after each call: state[0] != 0 means finished.  Grid arguments:
+ * evaluation that precedes open3d's loop and the step that computes the first update), and reads it back (one copy) after each call:
+ * state[0] != 0 means finished.  An iteration = apply the pending update, evaluate, step; `max_iteration` of them exhaust the limit.  Grid arguments:
  * the target's search grid from ape_grid_build_f64 (cell >= max_dist).  ws: n-blocks x 29 doubles as for ape_icp_sums_f64. */
 extern "C" int ape_icp_run_f64(int kind, GRID_ARGS, double* src, int ns, const double* tgt, const double* tgt_normals, double max_dist,
                                double rel_fitness, double rel_rmse, int max_iteration, int n_iter, int first_call, int* corr, double* dist2,
@@ -920,17 +960,14 @@ extern "C" int ape_icp_run_f64(int kind, GRID_ARGS, double* src, int ns, const d
     hipStream_t st = (hipStream_t)stream;
     MAKE_GRID;
     double* part = (double*)ws;
-    auto evaluate = [&]() {
-        hipLaunchKernelGGL(nn1_group_kernel, dim3(ape::ceil_div((long)ns * kG, (long)kT)), dim3(kT), 0, st, g, (const double*)src, ns, max_dist * max_dist, corr, dist2, (const double*)state);
+    auto block = [&](int apply) {         // [move +] search, sums, reduce + step: three launches
+        hipLaunchKernelGGL(icp_move_nn1_kernel, dim3(ape::ceil_div((long)ns * kG, (long)kT)), dim3(kT), 0, st, g, src, ns, max_dist * max_dist, corr, dist2,
+                           (const double*)state, apply);
         if (kind == 0) hipLaunchKernelGGL(p2p_sums_kernel, dim3(nb), dim3(kT), 0, st, (const double*)src, tgt, (const int*)corr, (const double*)dist2, ns, part, (const double*)state);
         else hipLaunchKernelGGL(p2plane_sums_kernel, dim3(nb), dim3(kT), 0, st, (const double*)src, tgt, tgt_normals, (const int*)corr, (const double*)dist2, ns, part, (const double*)state);
-        hipLaunchKernelGGL(reduce_stage2, dim3(1), dim3(64), 0, st, (const double*)part, nb, nv, sums, (const double*)state);
+        hipLaunchKernelGGL(icp_reduce_step_kernel, dim3(1), dim3(64), 0, st, (const double*)part, nb, nv, sums, kind, state, ns, rel_fitness, rel_rmse, max_iteration);
     };
-    if (first_call) evaluate();
-    for (int it = 0; it < n_iter; ++it) {
-        hipLaunchKernelGGL(icp_step_kernel, dim3(1), dim3(1), 0, st, kind, (const double*)sums, state, ns, rel_fitness, rel_rmse, max_iteration);
-        hipLaunchKernelGGL(icp_transform_kernel, dim3(grid_for(ns)), dim3(kT), 0, st, src, ns, (const double*)state);
-        evaluate();
-    }
+    if (first_call) block(0);
+    for (int it = 0; it < n_iter; ++it) block(1);
     return ape::check_launch("ape_icp_run_f64");
 }

@@ -334,7 +334,7 @@ def _point_to_plane(s):
 
 ICP_STATS = None          # bench.py --workload label sets a dict here: registrations, evaluations, point pairs, (start, end) events
 _ICP_STATS_LOCK = threading.Lock()     # registrations of different chains run on different host threads (sharding.run_side_by_side)
-_ICP_CHUNK = 6            # iterations enqueued per device round trip; the reference's criteria (1e-2 relative) stop after 2-4
+_ICP_CHUNK = 5            # iterations enqueued per device round trip (3 launches each); the reference's criteria (1e-2) stop after 2-4
 
 
 def registration_icp(source, target, max_correspondence_distance, init=None, estimation_method=None, criteria=None, host_solve=False):
@@ -363,7 +363,7 @@ def registration_icp(source, target, max_correspondence_distance, init=None, est
         st0 = np.zeros(40)
         st0[5:21] = T.reshape(-1)
         state = torch.from_numpy(st0).to(dev)
-        left, first, chunk = int(criteria.max_iteration) + 1, 1, _ICP_CHUNK     # +1: the step that notices the iteration limit
+        left, first, chunk = int(criteria.max_iteration), 1, _ICP_CHUNK         # the first call's block already holds one step
         if ICP_STATS is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()

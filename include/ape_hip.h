@@ -306,8 +306,9 @@ int ape_grid_knn_mean_dist_f64(const double* sorted, const unsigned long long* k
 int ape_icp_sums_f64(int kind, const double* src, const double* tgt, const double* tgt_normals, const int* corr,
                      const double* dist2, int n, double* out, void* ws, size_t ws_bytes, void* stream);
 /* registration_icp's LOOP on the device (open3d_utils.py:96-117; open3d 0.9 RegistrationICP): `n_iter` iterations of
- * [step: fitness / rmse / convergence test, Umeyama 3x3 SVD (kind 0) or 6x6 solve (kind 1), T <- update . T] -> transform src by the
- * update -> correspondence search -> reduced sums, enqueued at once; every launch is a no-op once state[0] != 0.  `src` is the
+ * [move src by the pending update + correspondence search] -> partial sums -> [reduce + step: fitness / rmse / convergence test, Umeyama
+ * 3x3 SVD (kind 0) or 6x6 solve (kind 1), T <- update . T], three launches each, enqueued at once; every launch is a no-op once
+ * state[0] != 0.  first_call = 1 prepends the evaluation before open3d's loop and the step that computes the first update.  `src` is the
  * source already moved by the initial guess, updated in place.  state[40] doubles on the device: [0] done, [1] updates applied,
  * [2] fitness, [3] inlier rmse, [4] correspondences, [5..20] T row major, [21..36] last update, [37] stop reason (1 converged,
  * 2 too few correspondences, 3 iteration limit), [38] internal.  Before the first call of a registration (first_call = 1) the caller
