@@ -75,7 +75,9 @@ class FramePipeline:
         for k, (hc, wc) in enumerate(uniq.tolist()):
             ids = np.nonzero(inv == k)[0]
             sub = obj_np[ids]
-            both = torch.from_numpy(np.ascontiguousarray(np.concatenate([sub, sub[:, [0, 2, 4]]], 1))).to(dev)   # one small H2D
+            # one small H2D, from pinned memory and non-blocking: a pageable copy would park the host until the stream (the pose stream
+            # still busy with the previous batch) reaches it
+            both = torch.from_numpy(np.ascontiguousarray(np.concatenate([sub, sub[:, [0, 2, 4]]], 1))).pin_memory().to(dev, non_blocking=True)
             objs, rects = both[:, :6].contiguous(), both[:, 6:9].contiguous()
             choose, n_cand = E.choose_points(objmap, depth, objs, self.num_points, seed)
             if choose_override is not None:
@@ -98,7 +100,7 @@ class FramePipeline:
                     E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
             if single:
                 return pose, n_cand, choose
-            ids_t = torch.from_numpy(ids.astype(np.int64)).to(dev)
+            ids_t = torch.from_numpy(ids.astype(np.int64)).pin_memory().to(dev, non_blocking=True)
             pose_all.index_copy_(0, ids_t, pose)
             ncand_all.index_copy_(0, ids_t, n_cand)
             choose_all.index_copy_(0, ids_t, choose)
