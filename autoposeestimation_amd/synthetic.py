@@ -226,20 +226,35 @@ def render_depth(points, cam2robot, intr=LABEL_INTR, h=480, w=640):
     return depth.astype(np.uint16)
 
 
-def label_views(n_views, seed=0, cloud=None, distance=500.0):
-    """`n_views` (label u8, depth u16, robot2cam 4x4) of the bumpy sphere from camera poses on a cap around it (the arc pattern of
-    robot_controller/robot_path/viewpointsPath2.json reduced to its geometry: the camera looks at the object from 500 mm, tilted by
-    up to +-1 rad about y and +-0.5 rad about x)"""
+def label_views(n_views, seed=0, cloud=None, distance=500.0, poses=None):
+    """`n_views` (label u8, depth u16, robot2cam 4x4) of the bumpy sphere.  `poses` = robot2cam matrices to render from (the reference's
+    own capture path: `capture_path()`); without them the cameras sit on a cap around the object (looking at it from `distance` mm,
+    tilted by up to +-1 rad about y and +-0.5 rad about x, drawn from `seed`)."""
     cloud = bumpy_sphere(300000, 21) if cloud is None else cloud
     rng = np.random.default_rng(seed)
     views = []
-    for _ in range(n_views):
-        ang_y, ang_x = rng.uniform(-1.0, 1.0), rng.uniform(-0.5, 0.5)
-        cam = rigid(np.pi, 0.0, 0.0, tuple(LABEL_CENTRE + [0, 0, distance]))
-        cam = rigid(0, 0, 0, tuple(LABEL_CENTRE)) @ rigid(ang_x, ang_y, 0.0, (0, 0, 0)) @ rigid(0, 0, 0, tuple(-LABEL_CENTRE)) @ cam
+    for i in range(n_views):
+        if poses is not None:
+            cam = np.asarray(poses[i % len(poses)], dtype=np.float64)
+        else:
+            ang_y, ang_x = rng.uniform(-1.0, 1.0), rng.uniform(-0.5, 0.5)
+            cam = rigid(np.pi, 0.0, 0.0, tuple(LABEL_CENTRE + [0, 0, distance]))
+            cam = rigid(0, 0, 0, tuple(LABEL_CENTRE)) @ rigid(ang_x, ang_y, 0.0, (0, 0, 0)) @ rigid(0, 0, 0, tuple(-LABEL_CENTRE)) @ cam
         depth = render_depth(cloud, cam)
         views.append(((depth != 0).astype(np.uint8) * 255, depth, cam))
     return views
+
+
+def capture_path():
+    """(robot2cam[164, 4, 4], focus[3]): the camera poses of the reference's capture run (robot_controller/robot_path/
+    viewpointsPath2.json through the hand-eye calibration) and the point its optical axes meet in, from the committed fixture
+    tests/golden/viewpoints_path2.npz (tools/gen_golden_viewpoints.py); None when the fixture is absent."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "viewpoints_path2.npz")
+    if not os.path.exists(path):
+        return None
+    d = np.load(path)
+    return d["robot2cam"], d["focus"]
 
 
 def pose_dataset_tree(root, data_set_name="synth", n_view=5, n_extra=3, seed=3):

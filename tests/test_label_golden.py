@@ -130,3 +130,22 @@ def test_gpu_relabel_frames_match_reference_run():
             assert np.array_equal(labels[i], want[i]), i
     assert (stats["bs_copied"], stats["no_depth_overlap"], stats["not_in_center"]) == \
         (int(g["rl_log_bs_copied"]), int(g["rl_log_no_depth"]), int(g["rl_log_not_centre"]))
+
+
+def test_capture_path_fixture_is_a_camera_orbit():
+    """tests/golden/viewpoints_path2.npz (the reference's capture path through its hand-eye calibration, tools/gen_golden_viewpoints.py):
+    164 rigid camera poses whose optical axes meet near one point -- what bench.py --workload label renders its views from."""
+    import numpy as np
+    from autoposeestimation_amd import synthetic as S
+    poses, focus = S.capture_path()
+    assert poses.shape == (164, 4, 4) and focus.shape == (3,)
+    R = poses[:, :3, :3]
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-9) and np.allclose(np.linalg.det(R), 1.0, atol=1e-9)
+    assert np.allclose(poses[:, 3], [0, 0, 0, 1])
+    to_focus = focus - poses[:, :3, 3]
+    dist = np.linalg.norm(to_focus, axis=1)
+    assert 300 < dist.min() and dist.max() < 1200
+    cosang = np.einsum("ij,ij->i", to_focus / dist[:, None], poses[:, :3, 2])
+    assert np.median(cosang) > 0.99 and cosang.min() > 0.9          # every camera looks at the turntable
+    views = S.label_views(2, cloud=S.bumpy_sphere(60000, 21, centre=focus), poses=[poses[0], poses[100]])
+    assert all((d != 0).sum() > 2000 for _, d, _ in views)

@@ -1,0 +1,50 @@
+"""Single-frame latency of the live path (FramePipeline.run on ONE 640x480 frame: what main.py's 'Run Live Prediction' does per frame),
+host wall clock from resident inputs to the pose on the host.  python tools/mb_latency.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from autoposeestimation_amd import synthetic as S  # noqa: E402
+from autoposeestimation_amd.pipeline.utils import FramePipeline  # noqa: E402
+
+dev = torch.device("cuda", 0)
+frames = bench.make_frames(4, 0)
+fit = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 + 60 * c + 90 * k), size=(126, 126)) for c in range(1, 4) for k in range(2)]
+seg, est, ref, *_ = bench.build_models(dev, fit)
+for m in (seg, est, ref):
+    m.set_precision("bf16x3")
+pipe = FramePipeline(seg, est, ref, bench.CLASSES, num_points=1000, refine_mode="live_compat", pose_stream=False)
+for b in (1, 4):
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames[:b]])).to(dev)
+    depth = torch.from_numpy(np.stack([f[1] for f in frames[:b]])).to(dev)
+    for _ in range(5):
+        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=0)
+        out["pose"].cpu()
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(30):
+        t0 = time.perf_counter()
+        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+        p = out["pose"].cpu()
+        ts.append(time.perf_counter() - t0)
+    ts = np.sort(ts) * 1e3
+    print("batch %d: median %.2f ms  min %.2f ms  (%d objects)" % (b, ts[len(ts) // 2], ts[0], len(out["objects"])))
+
+if os.environ.get("APE_LAT_PROFILE"):
+    import cProfile
+    import pstats
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames[:1]])).to(dev)
+    depth = torch.from_numpy(np.stack([f[1] for f in frames[:1]])).to(dev)
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(20):
+        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+        out["pose"].cpu()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    # GPU time of one frame: events around a run whose launches were all enqueued (host far ahead is impossible at B=1, so this is wall)
