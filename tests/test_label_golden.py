@@ -140,7 +140,7 @@ def test_capture_path_fixture_is_a_camera_orbit():
     poses, focus = S.capture_path()
     assert poses.shape == (164, 4, 4) and focus.shape == (3,)
     R = poses[:, :3, :3]
-    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-9) and np.allclose(np.linalg.det(R), 1.0, atol=1e-9)
+    assert np.allclose(R @ R.transpose(0, 2, 1), np.eye(3), atol=1e-5) and np.allclose(np.linalg.det(R), 1.0, atol=1e-5)   # (the stored calibration is orthonormal to 3e-7)
     assert np.allclose(poses[:, 3], [0, 0, 0, 1])
     to_focus = focus - poses[:, :3, 3]
     dist = np.linalg.norm(to_focus, axis=1)
