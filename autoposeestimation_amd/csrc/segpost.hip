@@ -208,6 +208,11 @@ __global__ void seg_stats_kernel(const uint8_t* __restrict__ label, const float*
         if (lh[i]) atomicAdd(&hist[(long)b * C + i], lh[i]);
 }
 
+__global__ void seg_zero_stats_kernel(unsigned long long* __restrict__ sum, unsigned int* __restrict__ cnt, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { sum[i] = 0ull; cnt[i] = 0u; }
+}
+
 __global__ void seg_small_init_kernel(unsigned int* hist, unsigned long long* best_key, int* best_root, int* tight, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,11 +566,9 @@ extern "C" int ape_seg_components_scored(const uint8_t* label, const float* scor
     unsigned int* hist = (unsigned int*)ws;                       ws += (size_t)B * C * 4;
     int* best_root = (int*)ws;                                    ws += (size_t)B * C * 4;
     int* tight = (int*)ws;
-    if (hipMemsetAsync(sum, 0, npix * 8, st) != hipSuccess || hipMemsetAsync(cnt, 0, npix * 4, st) != hipSuccess) {
-        ape::set_last_error("hipMemsetAsync");
-        return APE_ELAUNCH;
-    }
     const int g = grid_for(npix);
+    // (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph did not re-zero these on replay -- tools/probes/graph_probe.py)
+    hipLaunchKernelGGL(seg_zero_stats_kernel, dim3(g), dim3(kT), 0, st, sum, cnt, npix);
     const int BC = B * C;
     hipLaunchKernelGGL(seg_small_init_kernel, dim3(ape::ceil_div(BC, kT)), dim3(kT), 0, st, hist, best_key, best_root, tight, BC);
     hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(kT), 0, st, label, L, W, npix);

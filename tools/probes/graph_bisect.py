@@ -1,0 +1,49 @@
+"""Where does a replayed graph of the segmentation stage diverge from the eager run on a SECOND input?  (development probe)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from autoposeestimation_amd import engine as E, synthetic as S  # noqa: E402
+
+dev = torch.device("cuda", 0)
+frames = bench.make_frames(2, 0)
+fit = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 + 60 * c + 90 * k), size=(126, 126)) for c in range(1, 4) for k in range(2)]
+seg, est, ref, *_ = bench.build_models(dev, fit)
+seg.set_precision("bf16x3")
+rgb = torch.from_numpy(np.stack([f[0] for f in frames[:1]])).to(dev)
+rgb2 = torch.from_numpy(np.stack([f[0] for f in frames[1:2]])).to(dev)
+rects = torch.zeros(1, 3, dtype=torch.int32, device=dev)
+
+
+def stage(x, upto):
+    x4 = E.preprocess_u8(x, rects, 480, 640, div255=True)
+    if upto == 0:
+        return (x4,)
+    if upto == 1:
+        f = seg.features(x4) if hasattr(seg, "features") else None
+        return tuple(t.t if isinstance(t, E.S32) else t for t in (f if isinstance(f, (tuple, list)) else (f,)) if t is not None)
+    return seg.label_score_nhwc(x4, double_softmax=True)
+
+
+for upto in (0, 1, 2):
+    try:
+        for _ in range(2):
+            stage(rgb, upto)
+        torch.cuda.synchronize()
+        static = rgb.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = stage(static, upto)
+        for name, src in (("input 1", rgb), ("input 2", rgb2)):
+            static.copy_(src)
+            g.replay()
+            torch.cuda.synchronize()
+            ref_o = stage(src, upto)
+            torch.cuda.synchronize()
+            print("stage", upto, name, [bool(torch.equal(a, b)) for a, b in zip(outs, ref_o)])
+    except Exception as e:          # noqa: BLE001
+        print("stage", upto, "failed:", type(e).__name__, str(e)[:200])

@@ -1,0 +1,77 @@
+"""Can the segmentation stage (ctypes launches on torch's current stream) be captured in a HIP graph and replayed?  Checks equality
+with the eager run and times both at batch 1.  python tools/probes/graph_probe.py"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from autoposeestimation_amd import synthetic as S  # noqa: E402
+from autoposeestimation_amd.pipeline.utils import FramePipeline  # noqa: E402
+
+dev = torch.device("cuda", 0)
+frames = bench.make_frames(2, 0)
+fit = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 + 60 * c + 90 * k), size=(126, 126)) for c in range(1, 4) for k in range(2)]
+seg, est, ref, *_ = bench.build_models(dev, fit)
+for m in (seg, est, ref):
+    m.set_precision("bf16x3")
+pipe = FramePipeline(seg, est, ref, bench.CLASSES, num_points=1000, refine_mode="live_compat", pose_stream=False)
+rgb = torch.from_numpy(np.stack([f[0] for f in frames[:1]])).to(dev)
+rgb2 = torch.from_numpy(np.stack([f[0] for f in frames[1:2]])).to(dev)
+for _ in range(3):
+    objmap, det = pipe.segment(rgb)
+torch.cuda.synchronize()
+static = rgb.clone()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    g_objmap, g_det = pipe.segment(static)
+torch.cuda.synchronize()
+for src in (rgb, rgb2):
+    static.copy_(src)
+    g.replay()
+    torch.cuda.synchronize()
+    e_objmap, e_det = pipe.segment(src)
+    torch.cuda.synchronize()
+    print("graph == eager:", torch.equal(g_objmap, e_objmap), torch.equal(g_det, e_det), "detections", int((e_det[:, 1:, 0] != 0).sum()))
+
+
+def t(f, n=50):
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        f()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def eager():
+    pipe.segment(rgb)
+
+
+def graph():
+    static.copy_(rgb)
+    g.replay()
+
+
+print("segmentation stage at batch 1: eager %.3f ms, graph %.3f ms" % (t(eager), t(graph)))
+
+# diagnosis of a replay on a second input
+static.copy_(rgb2)
+g.replay()
+torch.cuda.synchronize()
+a_obj, a_det = g_objmap.clone(), g_det.clone()
+e_obj, e_det = pipe.segment(rgb2)
+e_obj2, e_det2 = pipe.segment(rgb2)
+torch.cuda.synchronize()
+print("eager twice equal:", torch.equal(e_obj, e_obj2), torch.equal(e_det, e_det2))
+print("objmap differing px:", int((a_obj != e_obj).sum()), "of", a_obj.numel(), " det graph:", a_det[a_det[..., 0] != 0].tolist(), " det eager:", e_det[e_det[..., 0] != 0].tolist())
+static.copy_(rgb)
+g.replay()
+torch.cuda.synchronize()
+e_obj, e_det = pipe.segment(rgb)
+print("back to input 1: equal", torch.equal(g_objmap, e_obj), torch.equal(g_det, e_det))
