@@ -50,6 +50,13 @@ class PsPNetSegmentor(PSPNet):
         """x4[B,H,W,4] -> (label u8[B,H,W], score f32[B,H,W]): features -> fused head (final conv rows 0..classes-1 in exact
         fp32 + softmax(+softmax) + argmax); the logits tensor of `logits_nhwc` is never materialised."""
         pl = self.plan()
+        b, h, w, _ = x4.shape
+        # the kernels index a tensor with 32 bits: the largest of the pass is the full-resolution 64-channel map up_3 reads / the head
+        # consumes (B x H x W x 64 elements; 109 frames of 480x640).  Larger batches go through in slices.
+        max_b = max(1, ((1 << 31) - 1) // (h * w * 64))
+        if b > max_b:
+            parts = [self.label_score_nhwc(x4[i:i + max_b], double_softmax) for i in range(0, b, max_b)]
+            return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
         if self.classes > 16:
             return E.seg_argmax(self.logits_nhwc(x4), self.classes, double_softmax)
         return pl.label_score(x4, self._head_w, self._head_b, double_softmax)
