@@ -1,0 +1,65 @@
+"""bench.py's contract, checked end to end: the three workloads run as the driver runs them (a child process, one JSON line on stdout)
+and the line carries every field the contract names, with consistent values."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                     # ONE JSON line
+    return json.loads(lines[0])
+
+
+def _common(d, steps, warmup):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_default_line_has_roofline_cpu_baseline_and_parity():
+    d = _run("--steps", "2", "--warmup", "1")
+    _common(d, 2, 1)
+    assert d["unit"] == "frames/s" and d["scaling"] == "weak" and d["dtype"] == "bf16x3"
+    assert abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+    ks = d["roofline"]["kernels"]
+    assert len(ks) == 5 and d["roofline"]["kernel"] == ks[0]["kernel"]
+    for k in ks:
+        assert k["launches"] > 0 and k["avg_launch_us"] > 0 and 0 < k["frac"] < 1 and k["shapes"] and "isolated_frac" in k
+        assert sum(s["launches"] for s in k["shapes"]) == k["launches"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "single_thread_value", "cpu_model"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0
+    p = d["parity"]
+    assert p["frames"] >= 8 and p["max_dq"] <= 1e-4 and p["max_dt"] <= 1e-4 and p["mask_diff_px_outside_tie_band"] == 0 and p["objects_not_matched"] == 0
+
+
+def test_frames_1024_line():
+    d = _run("--frames", "256", "--batch", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    _common(d, 1, 1)
+    assert d["scaling"] == "strong" and d["config"]["frames_per_gpu_per_step"] == 256 and "configs[3]" in d["config"]["workload"]
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+
+
+def test_label_line():
+    d = _run("--workload", "label", "--steps", "1", "--warmup", "1")
+    _common(d, 1, 1)
+    assert d["unit"] == "views/s" and d["scaling"] == "strong" and d["dtype"] == "f64" and "configs[4]" in d["config"]["workload"]
+    assert d["icp"]["registrations_per_s"] > 0 and d["icp"]["point_pairs_per_s"] > 0
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["unit"] == "views/s"
+    assert d["parity"]["gpu_points"] == d["parity"]["oracle_points"] and d["parity"]["max_nn_distance_mm"] < 1e-6
