@@ -63,3 +63,24 @@ def test_label_line():
     assert d["icp"]["registrations_per_s"] > 0 and d["icp"]["point_pairs_per_s"] > 0
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["unit"] == "views/s"
     assert d["parity"]["gpu_points"] == d["parity"]["oracle_points"] and d["parity"]["max_nn_distance_mm"] < 1e-6
+
+
+def test_bench_under_torch_distributed_run_exercises_rccl():
+    """the launch line the driver uses for N > 1, here with one rank: init_process_group('nccl'), the per-step all_gather of the poses,
+    the barrier + all_reduce(MAX) of the timing"""
+    port = 29500 + os.getpid() % 400
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    _common(d, 2, 1)
+    assert "1 all_gather" in d["config"]["parallelism"]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port + 1), os.path.join(REPO, "bench.py"), "--gpus", "1", "--workload", "label", "--steps", "1",
+                          "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["unit"] == "views/s" and d["n_gpus"] == 1
