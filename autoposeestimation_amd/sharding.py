@@ -41,6 +41,11 @@ def gather_results(local, dist=None):
     """all_gather of equally-shaped per-rank result blocks -> [world * frames_per_rank, max_obj, 8] in rank order."""
     if dist is None or not dist.is_initialized():
         return local
+    if dist.get_backend() != "nccl" and local.is_cuda:            # gloo gathers host tensors (CPU tests, single-GPU rehearsals)
+        host = local.contiguous().cpu()
+        parts = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, host)
+        return torch.cat(parts, 0).to(local.device)
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local.contiguous())
     return torch.cat(parts, 0)

@@ -384,13 +384,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # One rank per GPU.  Rehearsal mode (APE_DIST_BACKEND=gloo): several ranks may share the GPUs that exist -- a single-GPU box can then
+    # run the driver's N = 2 launch line through every multi-rank code path (rank-dependent frames, collectives, max-over-ranks timing);
+    # its number means nothing, and RCCL itself needs one GPU per rank.
+    backend = os.environ.get("APE_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or "RANK" in os.environ:       # under torch.distributed.run the RCCL path is exercised even for one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.workload == "label":
         return label_main(args, rank, world, device, dist)
 

@@ -84,3 +84,27 @@ def test_bench_under_torch_distributed_run_exercises_rccl():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
     assert d["unit"] == "views/s" and d["n_gpus"] == 1
+
+
+@pytest.mark.parametrize("flags", [("--steps", "2", "--warmup", "1"), ("--frames", "256", "--steps", "1", "--warmup", "1"),
+                                   ("--workload", "label", "--steps", "1", "--warmup", "1")])
+def test_two_rank_rehearsal_on_one_gpu(flags):
+    """The driver's N = 2 launch line with both ranks on the one GPU of the box (APE_DIST_BACKEND=gloo: RCCL needs a GPU per rank):
+    rank-dependent frames / view shards, the collectives of every step, max-over-ranks timing, rank 0's single line."""
+    port = 29900 + os.getpid() % 90
+    env = dict(os.environ, APE_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--no-cpu-baseline", *flags],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1                              # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    if "--workload" in flags:
+        assert d["unit"] == "views/s" and "2 ranks" in d["config"]["parallelism"]
+    elif "--frames" in flags:
+        assert d["scaling"] == "strong" and d["config"]["frames_per_gpu_per_step"] == 128
+    else:
+        assert d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 64 and d["config"]["objects_found_last_step"] == 64
+        assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
