@@ -135,3 +135,24 @@ def test_label_chain_sharding_two_ranks_equals_single_rank():
     assert got[0][0]["multi_made"] == [6] and got[1][0]["multi_made"] == [6]
     solo = sharding.sharded_chains(chains, lambda v: torch.from_numpy(v * 2.0), _order_dependent_fuse, None)
     assert [solo[i].tolist() for i in range(3)] == want_multi
+
+
+def test_prefetched_keeps_order_and_propagates_errors():
+    import time
+    import pytest
+    from autoposeestimation_amd.sharding import prefetched, run_side_by_side
+
+    def load(x):
+        time.sleep(0.002 * (7 - x % 7))                  # later items finish first
+        if x == 41:
+            raise KeyError("bad item")
+        return x * x
+
+    assert list(prefetched(list(range(40)), load, workers=6, window=9)) == [x * x for x in range(40)]
+    assert list(prefetched([3, 1, 2], None)) == [3, 1, 2]
+    assert list(prefetched([], load)) == []
+    with pytest.raises(KeyError):
+        list(prefetched(list(range(36, 45)), load, workers=3, window=4))
+    # without a GPU (this test), or for one job, the jobs simply run in order
+    assert run_side_by_side([lambda i=i: i + 1 for i in range(5)]) == [1, 2, 3, 4, 5]
+    assert run_side_by_side([]) == []
