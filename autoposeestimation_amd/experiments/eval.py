@@ -1,6 +1,11 @@
 """Drop-in for the ADD-S evaluation harness experiments/eval.py (reference `eval` :32-99): estimator -> Loss (refine=True, so
 no KNN at the estimator stage, loss.py:40) -> `iteration` x (refiner -> Loss_refine, ADD-S through the k-NN arithmetic for
-symmetric objects) -> `dis < 0.02 m` bucket per class.  Everything after the PNG decode runs on the GPU."""
+symmetric objects) -> `dis < 0.02 m` bucket per class.  Everything after the PNG decode runs on the GPU.
+
+Multi-GPU: the samples are independent, so with `dist=` (an initialised torch.distributed) every rank evaluates
+its contiguous `shard_range` of the test set and ONE all-reduce of the per-class `(sum of dis, count < 2 cm, count)` table (float64)
+plus one gather of the per-sample distances gives every rank the reference's result dict -- the same numbers as the single-rank
+loop up to the float64 summation order of `dis` (the counts are exact)."""
 import numpy as np
 import torch
 
@@ -10,14 +15,17 @@ from autoposeestimation_amd.DenseFusion.lib.loss_refiner import Loss_refine
 
 
 def eval(num_points, refine_start, data_set_name, show_sample, label_mode, p_extra_data, p_viewpoints, estimator, w, refiner,  # noqa: A001
-         iteration, workers, classes, root=".", verbose=False):
+         iteration, workers, classes, root=".", verbose=False, dist=None):
+    from autoposeestimation_amd.sharding import shard_range
     results = {cls: {"<2": 0, ">=2": 0, "dis": []} for cls in classes}
     dataset = PoseDataset("test", num_points, False, 0.0, refine_start, data_set_name, root, show_sample=show_sample,
                           label_mode=label_mode, p_extra_data=p_extra_data, p_viewpoints=p_viewpoints)
     criterion = Loss(dataset.get_num_points_mesh(), dataset.get_sym_list())
     criterion_refine = Loss_refine(dataset.get_num_points_mesh(), dataset.get_sym_list())
     dists = []
-    for j in range(len(dataset)):
+    sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    lo, hi = shard_range(len(dataset), dist.get_rank(), dist.get_world_size()) if sharded else (0, len(dataset))
+    for j in range(lo, hi):
         points, choose, img, target, model_points, idx, intr, np_img = dataset[j]
         cls_key = classes[int(idx[0])]
         points, choose, img = points.unsqueeze(0).cuda(), choose.unsqueeze(0).cuda(), img.unsqueeze(0).cuda()
@@ -33,9 +41,28 @@ def eval(num_points, refine_start, data_set_name, show_sample, label_mode, p_ext
         results[cls_key]["dis"].append(dists[-1])
         if verbose:
             print("sample {}/{}| dis: {}, average ADD-s: {}".format(j, len(dataset), np.round(dists[-1], 5), np.round(np.mean(dists), 5)))
-    for key, v in results.items():
-        n = v[">=2"] + v["<2"]
-        results[key]["p"] = np.round(v["<2"] / n * 100, 2) if n else 0.0
-        results[key]["dis_all"] = list(v["dis"])
-        results[key]["dis"] = np.round(np.mean(v["dis"]), 5) if v["dis"] else float("nan")
-    return results
+    return merge_results(results, classes, dist if sharded else None)
+
+
+def merge_results(results, classes, dist=None):
+    """Per-class `{"<2", ">=2", "dis": [per-sample distances]}` of this rank's samples -> the reference's result dict
+    (`p` = percentage below 2 cm, `dis` = mean distance rounded to 5 places, experiments/eval.py:94-98) over ALL ranks' samples:
+    one all-reduce (SUM) of the `[classes, 3]` float64 table `(sum of dis, count < 2 cm, count)` and one gather of the distance lists
+    (rank order = sample order, so `dis_all` equals the single-rank list)."""
+    table = torch.tensor([[float(np.sum(results[c]["dis"], dtype=np.float64)) if results[c]["dis"] else 0.0, float(results[c]["<2"]),
+                           float(results[c]["<2"] + results[c][">=2"])] for c in classes], dtype=torch.float64).reshape(len(classes), 3)
+    lists = {c: list(results[c]["dis"]) for c in classes}
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = table.to(dev)
+        dist.all_reduce(t)
+        table = t.cpu()
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, lists)
+        lists = {c: [d for part in parts for d in part[c]] for c in classes}
+    out = {}
+    for k, c in enumerate(classes):
+        s, less, n = float(table[k, 0]), int(round(float(table[k, 1]))), int(round(float(table[k, 2])))
+        out[c] = {"<2": less, ">=2": n - less, "p": np.round(less / n * 100, 2) if n else 0.0, "dis_all": lists[c],
+                  "dis": np.round(s / n, 5) if n else float("nan")}
+    return out

@@ -103,8 +103,10 @@ def load_point_cloud(object_name, save_dir, root, reference_point=np.array([0, 0
     `dist` (an initialised torch.distributed module; one process per GPU, shared file system): the rotation directories are the
     CHAINS -- directory i is fused by rank i % world -- the decode + get_surface work of all chains' views is spread over all ranks
     (each rank reads only the PNGs of its share; ONE padded all-gather), the owners then fuse their directories side by side
-    (open3d_utils.fuse_chains), the per-directory clouds go to rank 0 with one more gather, and rank 0 aligns and exports (it alone returns the cloud; the others return None).  `rng` must then be seeded identically
-    on all ranks (the view selection draws from it)."""
+    (open3d_utils.fuse_chains), the per-directory clouds go to rank 0 with one more gather, and rank 0 aligns and exports (it alone
+    returns the cloud; the others return None).  The view selection draws from `rng` on rank 0 ONLY and is broadcast, so the ranks
+    cannot disagree about which views a flat index means (an unseeded or differently seeded `rng` per rank would otherwise mix
+    different views into one cloud without any error).  Every view carries its own meta['intr'] like the reference loop (:55)."""
     from autoposeestimation_amd import sharding
     from autoposeestimation_amd.data_generation import sample_io as io
     dist_on = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
@@ -118,37 +120,52 @@ def load_point_cloud(object_name, save_dir, root, reference_point=np.array([0, 0
     pcd_path = os.path.join(save_dir, object_name)
     os.makedirs(pcd_path, exist_ok=True)
     n = len([f for f in os.listdir(os.path.join(object_label_path, dirs[0])) if ".{}.label.png".format(mode) in f])
-    chains, tfs = [], []
+    chains, tfs, all_metas = [], [], []
     for di, d in enumerate(dirs):
-        metas = [io.read_meta(os.path.join(data_path, d), "{:06d}".format(i)) for i in range(n)]
-        cams = np.array([io.robot2cam(m)[:3, 3] for m in metas])
+        all_metas.append([io.read_meta(os.path.join(data_path, d), "{:06d}".format(i)) for i in range(n)])
+    selection = None
+    if rank == 0:
+        selection = [[int(i) for i in get_view_distribution(np.array([io.robot2cam(m)[:3, 3] for m in metas]), n_viewpoints, rng)]
+                     for metas in all_metas]
+    if dist_on:
+        box = [selection]
+        dist.broadcast_object_list(box, src=0)
+        selection = box[0]
+    intr = None
+    for di, d in enumerate(dirs):
+        metas = all_metas[di]
         views, tf = [], None
-        for idx in get_view_distribution(cams, n_viewpoints, rng):
+        for idx in selection[di]:
             meta = metas[idx]
             tf = np.array(meta.get("object_pose"), dtype=np.float64).reshape(4, 4)[:3, :3]
 
             def decode(sid="{:06d}".format(idx), meta=meta, d=d):
                 return (io.read_label(os.path.join(object_label_path, d), sid, mode), io.read_depth(os.path.join(data_path, d), sid),
-                        io.robot2cam(meta))
+                        io.robot2cam(meta), meta.get("intr"))
             views.append(decode)
-        intr = metas[0].get("intr")
+        intr = metas[0].get("intr") if intr is None else intr         # default for views without their own (each view carries its own)
         chains.append(views)
         tfs.append(tf)
     # all directories at once: per-view work of every chain over all ranks, one all-gather, then the owners fuse side by side
     fused = utils.fuse_chains(chains, intr, voxel_size=voxel_size, threshold=threshold, min_friends=min_friends, min_dist=min_dist,
                               nb_neighbors=nb_neighbors, icp_point2point=icp_point2point, icp_point2plane=icp_point2plane,
                               dist=dist if dist_on else None)
-    mine = []
-    for di in sorted(fused):
-        cloud, _ = fused[di]
-        if cloud is None:
-            raise ValueError("no valid surface in %s/%s" % (object_name, dirs[di]))
-        if tfs[di] is not None:
-            cloud.rotate(R=np.asarray(tfs[di], dtype=np.float64)[:3, :3], center=True)        # as fuse_direction (reference :320)
-        pc.write_point_cloud(os.path.join(pcd_path, "{}.pcd".format(dirs[di])), cloud)
-        pc.write_point_cloud(os.path.join(pcd_path, "{}.ply".format(dirs[di])), cloud)
-        mine.append((di, cloud._p))
-    sets = sharding.gather_point_sets(mine, len(dirs), dist if dist_on else None)
+    def export_mine():
+        mine = []
+        for di in sorted(fused):
+            cloud, _ = fused[di]
+            if cloud is None:
+                raise ValueError("no valid surface in %s/%s" % (object_name, dirs[di]))
+            if tfs[di] is not None:
+                cloud.rotate(R=np.asarray(tfs[di], dtype=np.float64)[:3, :3], center=True)        # as fuse_direction (reference :320)
+            pc.write_point_cloud(os.path.join(pcd_path, "{}.pcd".format(dirs[di])), cloud)
+            pc.write_point_cloud(os.path.join(pcd_path, "{}.ply".format(dirs[di])), cloud)
+            mine.append((di, cloud._p))
+        return mine
+
+    # an empty directory is an error on EVERY rank (the owner alone raising would leave the others in the gather below)
+    mine = sharding.guarded(dist if dist_on else None, export_mine, "the per-directory export of load_point_cloud")
+    sets = sharding.gather_point_sets(mine, len(dirs), dist if dist_on else None, owners=[0] * len(dirs) if dist_on else None)
     if rank != 0:
         return None
     point_clouds = [pc.PointCloud(p) for p in sets]

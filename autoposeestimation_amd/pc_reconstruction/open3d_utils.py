@@ -170,8 +170,10 @@ def _load_view(view):
 
 def _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point, icp_point2plane):
     def make_set(view):
-        label, depth, robot2cam = view() if callable(view) else view       # (already decoded when it came through _load_view)
-        return get_surface(label, depth, intr, robot2cam, min_friends, min_dist, nb_neighbors, voxel_size)._p
+        view = view() if callable(view) else view                           # (already decoded when it came through _load_view)
+        label, depth, robot2cam = view[:3]
+        view_intr = view[3] if len(view) > 3 and view[3] is not None else intr   # a view may carry its own meta['intr'] (reference create_pointcloud.py:55)
+        return get_surface(label, depth, view_intr, robot2cam, min_friends, min_dist, nb_neighbors, voxel_size)._p
 
     def fuse(sets):
         dev = torch.device("cuda", torch.cuda.current_device())

@@ -6,8 +6,10 @@ Works with any torch.distributed backend (RCCL on the GPU box, gloo in the CPU t
 Label generation (BASELINE configs[4]): inside one (object, rotation-directory) CHAIN the fusion is sequential and
 order-dependent (create_pointcloud.py:288-312), so a chain is owned by ONE rank (`chain_owner`); what shards inside a chain is the
 per-view work (decode, `get_surface` incl. its filters): every rank pre-processes its `shard_range` of the chain's views and ONE
-padded all-gather (`gather_point_sets`) hands the variable-length surfaces to the owner, which registers them in view order --
-bit-identical to the single-rank chain because the surfaces are the same arrays in the same order."""
+grouped exchange (`gather_point_sets(owners=...)`: a small all-gather of the counts, then packed point-to-point messages) hands the
+variable-length surfaces to the rank that owns the chain -- and to no other -- which registers them in view order: bit-identical to
+the single-rank chain because the surfaces are the same arrays in the same order.  Every per-rank stage ends in `all_ranks_ok`, so
+an exception on one rank is raised on all of them instead of leaving the others blocked in the next collective."""
 import os
 
 import numpy as np
@@ -60,17 +62,53 @@ def _dist_device(dist):
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def gather_point_sets(local_sets, n_total, dist=None):
+def all_ranks_ok(dist, error=None, what="a collective stage"):
+    """Make a per-rank failure COLLECTIVE: every rank passes `error` (the exception it caught, or None), one tiny all-reduce (MAX) of
+    the failure flags, and if any rank failed EVERY rank raises -- the failing ranks their own exception, the others a RuntimeError
+    naming the ranks.  Without it a rank that raises before a collective leaves the others blocked in that collective for ever."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if error is not None:
+            raise error
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    flags = torch.zeros(world, dtype=torch.int32, device=_dist_device(dist))
+    if error is not None:
+        flags[rank] = 1
+    dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    failed = [r for r in range(world) if int(flags[r])]
+    if error is not None:
+        raise error
+    if failed:
+        raise RuntimeError("%s failed on rank(s) %s; rank %d stops with them" % (what, failed, rank))
+
+
+def guarded(dist, fn, what="a collective stage"):
+    """fn() on this rank, then `all_ranks_ok`: either every rank returns its result or every rank raises."""
+    try:
+        out, err = fn(), None
+    except Exception as e:      # noqa: BLE001 -- re-raised on this rank by all_ranks_ok, announced to the others
+        out, err = None, e
+    all_ranks_ok(dist, err, what)
+    return out
+
+
+def gather_point_sets(local_sets, n_total, dist=None, owners=None):
     """local_sets: [(global_index, points[n_i, 3] float64 tensor or ndarray)] this rank produced; n_total: number of sets over all
-    ranks (each rank holds at most ceil(n_total / world) of them, cf. shard_range).  Returns the list of all n_total point arrays
-    (float64 tensors on the collective's device) in global-index order, on EVERY rank: one small all_gather of the (index, count)
-    table and ONE all_gather of the surfaces padded to [sets_per_rank, Pmax, 3]."""
+    ranks (each rank holds at most ceil(n_total / world) of them, cf. shard_range).  Returns the list of the n_total point arrays
+    (float64 tensors on the collective's device) in global-index order.
+
+    `owners` = None: every rank receives every set (one small all_gather of the (index, count) table and ONE all_gather of the
+    surfaces padded to [sets_per_rank, Pmax, 3]).
+    `owners[gi]` = the rank that consumes set gi ("to the rank owning the chain"): after the table all_gather each
+    producer sends, per destination rank, ONE packed `[sum of counts, 3]` float64 message with the sets that rank owns (grouped
+    point-to-point: `batch_isend_irecv`, at most world - 1 sends and world - 1 receives per rank, nothing padded, nothing sent
+    to ranks that do not need it); entries of the result that this rank does not own are None."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         out = [None] * n_total
         for gi, pts in local_sets:
             out[gi] = torch.as_tensor(pts, dtype=torch.float64)
         return out
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     dev = _dist_device(dist)
     per_rank = -(-n_total // world)
     if len(local_sets) > per_rank:
@@ -81,13 +119,55 @@ def gather_point_sets(local_sets, n_total, dist=None):
     tables = [torch.empty_like(table) for _ in range(world)]
     dist.all_gather(tables, table)
     tables = torch.stack(tables).cpu().numpy()                       # [world, per_rank, 2]
+    out = [None] * n_total
+    if owners is not None:
+        if len(owners) != n_total:
+            raise ValueError("owners must name a rank for each of the %d sets" % n_total)
+        mine = {gi: torch.as_tensor(pts, dtype=torch.float64).to(dev).reshape(-1, 3) for gi, pts in local_sets}
+        ops, recv_bufs, keep = [], {}, []
+        for dst in range(world):                                     # what this rank produced and `dst` consumes, in table order
+            if dst == rank:
+                continue
+            part = [mine[int(gi)] for gi, _ in tables[rank] if gi >= 0 and owners[int(gi)] == dst]
+            rows = sum(len(p) for p in part)
+            if rows:
+                msg = torch.cat(part, 0).contiguous()
+                keep.append(msg)
+                ops.append(dist.P2POp(dist.isend, msg, dst))
+        for src in range(world):                                     # what `src` produced and this rank consumes
+            if src == rank:
+                continue
+            rows = sum(int(cnt) for gi, cnt in tables[src] if gi >= 0 and owners[int(gi)] == rank)
+            if rows:
+                recv_bufs[src] = torch.empty(rows, 3, dtype=torch.float64, device=dev)
+                ops.append(dist.P2POp(dist.irecv, recv_bufs[src], src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        seen = set()
+        for src in range(world):
+            pos = 0
+            for gi, cnt in tables[src]:
+                gi, cnt = int(gi), int(cnt)
+                if gi < 0:
+                    continue
+                seen.add(gi)
+                if owners[gi] != rank:
+                    continue
+                if src == rank:
+                    out[gi] = mine[gi].clone()
+                else:
+                    out[gi] = recv_bufs[src][pos:pos + cnt].clone() if cnt else torch.empty(0, 3, dtype=torch.float64, device=dev)
+                    pos += cnt
+        if len(seen) != n_total:
+            raise RuntimeError("gather_point_sets: some of the %d sets were produced by no rank" % n_total)
+        return out
     pmax = max(1, int(tables[..., 1].max()))
     buf = torch.zeros(per_rank, pmax, 3, dtype=torch.float64, device=dev)
     for k, (gi, pts) in enumerate(local_sets):
         buf[k, :len(pts)] = torch.as_tensor(pts, dtype=torch.float64).to(dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf)
-    out = [None] * n_total
     for r in range(world):
         for k in range(per_rank):
             gi, cnt = int(tables[r, k, 0]), int(tables[r, k, 1])
@@ -157,10 +237,14 @@ def sharded_chain(items, make_set, fuse, owner, dist=None, load=None):
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     lo, hi = shard_range(len(items), rank, world)
-    loaded = list(prefetched(items[lo:hi], load))
-    local = list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
-    sets = gather_point_sets(local, len(items), dist)
-    return fuse(sets) if rank == owner else None
+
+    def produce():
+        loaded = list(prefetched(items[lo:hi], load))
+        return list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
+
+    local = guarded(dist, produce, "the per-view stage of a sharded chain")         # a rank that fails here must not strand the others in the gather
+    sets = gather_point_sets(local, len(items), dist, owners=[owner] * len(items))
+    return guarded(dist, lambda: fuse(sets) if rank == owner else None, "the fusion of a sharded chain")
 
 
 def sharded_chains(chains, make_set, fuse, dist=None, load=None):
@@ -173,13 +257,18 @@ def sharded_chains(chains, make_set, fuse, dist=None, load=None):
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     flat = [(ci, item) for ci, items in enumerate(chains) for item in items]
     lo, hi = shard_range(len(flat), rank, world)
-    loaded = list(prefetched([f[1] for f in flat[lo:hi]], load))
-    local = list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
-    sets = gather_point_sets(local, len(flat), dist)
+
+    def produce():
+        loaded = list(prefetched([f[1] for f in flat[lo:hi]], load))
+        return list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
+
+    local = guarded(dist, produce, "the per-view stage of the sharded chains")
+    sets = gather_point_sets(local, len(flat), dist, owners=[chain_owner(ci, world) for ci, _ in flat])     # each surface to its chain's owner only
     mine, pos = [], 0
     for ci, items in enumerate(chains):
         if chain_owner(ci, world) == rank:
             mine.append((ci, sets[pos:pos + len(items)]))
         pos += len(items)
-    fused = run_side_by_side([lambda part=part: fuse(part) for _, part in mine])       # this rank's chains, side by side
+    fused = guarded(dist, lambda: run_side_by_side([lambda part=part: fuse(part) for _, part in mine]),       # this rank's chains, side by side
+                    "the fusion stage of the sharded chains")
     return {ci: res for (ci, _), res in zip(mine, fused)}

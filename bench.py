@@ -51,6 +51,21 @@ def pmc_traffic(kernel):
     return None
 
 
+def ranks_seen(rank, device, dist):
+    """[(rank, device index, device uuid, device name)] of every rank, all-gathered over the job's process group: evidence in the line
+    that an N-GPU run really had N distinct GPUs behind its ranks (one process per GPU)."""
+    try:
+        props = torch.cuda.get_device_properties(device)
+        mine = [int(rank), int(device.index), str(getattr(props, "uuid", "")), props.name]
+    except Exception as e:      # noqa: BLE001 -- evidence only, never a reason to fail the bench
+        mine = [int(rank), int(device.index), "unknown (%s)" % type(e).__name__, "unknown"]
+    if dist is None or not dist.is_initialized():
+        return [mine]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, mine)
+    return parts
+
+
 def make_frame(rank, i):
     fid = rank * 100003 + i
     rng = np.random.default_rng(fid)
@@ -67,7 +82,7 @@ def select_frames(batch, rank, pipe, device):
     ("one painted object per frame => one 160x160 crop").  The frozen random segmentor leaves a stray 40x40 blob or clips a border row
     (crop 120x160) in about 1 of 100 of the random frames; such frames are skipped during set-up (untimed) so that every rank carries
     the same work (weak scaling).  Rank 0's first 64 candidates all qualify, so its batch is make_frames(64, 0)."""
-    frames, nxt = [], 0
+    frames, nxt, skipped = [], 0, 0
     while len(frames) < batch:
         cand = [make_frame(rank, nxt + k) for k in range(64)]
         nxt += 64
@@ -78,11 +93,14 @@ def select_frames(batch, rank, pipe, device):
         for o in objects:
             per_frame.setdefault(o[0], []).append((o[3] - o[2], o[5] - o[4]))
         for k, f in enumerate(cand):
-            if per_frame.get(k) == [(160, 160)] and len(frames) < batch:
-                frames.append(f)
+            if len(frames) < batch:
+                if per_frame.get(k) == [(160, 160)]:
+                    frames.append(f)
+                else:
+                    skipped += 1
         if nxt > 64 * 50:
             raise RuntimeError("synthetic frame selection does not converge")
-    return frames
+    return frames, skipped
 
 
 def build_models(device, frames_for_fit):
@@ -146,13 +164,25 @@ def _cpu_info():
     return model, phys, usable
 
 
-def cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=16):
+def _cpu_quota():
+    """CPUs the cgroup lets this process use at once (cpu.max quota / period), None = unlimited / unknown"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=16, n_frames_all=64):
     """The oracle (CPU restatement of pipeline/utils.py:410-641, pinned by the reference goldens) timed on the host cores on a bounded
     sample of the SAME frames.  The reference path is batch-1 Python + torch CPU and does not scale with intra-op threads (one frame
     on 128 threads is SLOWER than on one), so the fair multi-core figure runs independent frames side by side: W single-threaded
     workers (W = the CPUs of a one-GPU box share, at most 16), `n_frames` frames.  Also reported: one frame on one thread.
-    Reported baseline only -- never part of `value`.  `gpu_choose(frame, class, nz, n)` injects the GPU run's point selection (the
-    reference draws it from an unseeded shuffle), so the oracle results double as the checker of the `parity` block."""
+    SURVEY.md 8d asks for "all physical cores" beside the single-thread figure: a second leg runs the REMAINING frames of the sample
+    (up to `n_frames_all` in total) with one single-threaded worker per physical core the process may use (capped by the frames left)
+    -> `all_cores_value`.  Reported baseline only -- never part of `value`.  `gpu_choose(frame, class, nz, n)` injects the GPU run's
+    point selection (the reference draws it from an unseeded shuffle), so the oracle results of BOTH legs double as the checker of
+    the `parity` block."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import densefusion_oracle as O
     model, phys, usable = _cpu_info()
@@ -174,13 +204,26 @@ def cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=16):
     with ThreadPoolExecutor(max_workers=workers) as ex:
         results = dict(zip(range(n_frames), ex.map(run, range(n_frames))))
     dt = time.time() - t
+    # second leg: the rest of the sample on every physical core this process may use
+    n_all = max(0, min(n_frames_all, len(frames)) - n_frames)
+    workers_all = max(1, min(phys or usable or 1, usable or 1, n_all)) if n_all else 0
+    all_cores = None
+    if n_all and workers_all > workers:
+        t = time.time()
+        with ThreadPoolExecutor(max_workers=workers_all) as ex:
+            results.update(zip(range(n_frames, n_frames + n_all), ex.map(run, range(n_frames, n_frames + n_all))))
+        dt_all = time.time() - t
+        all_cores = {"value": round(n_all / dt_all, 4), "cores": workers_all, "frames": n_all}
     torch.set_num_threads(old_threads)
     found = sum(len(r) for r in results.values())
     return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": workers, "kind": "port",
-            "single_thread_value": round(1.0 / dt1, 4), "cpu_model": model, "physical_cores": phys, "usable_cpus": usable,
-            "sample": "%d of the benchmark's 640x480 frames (%d objects found) through oracle/densefusion_oracle.full_prediction "
-                      "(torch CPU fp32), %d single-threaded workers side by side; single_thread_value = 1 frame on 1 thread"
-                      % (n_frames, found, workers)}, results
+            "single_thread_value": round(1.0 / dt1, 4), "all_cores_value": None if all_cores is None else all_cores["value"],
+            "all_cores": all_cores, "cpu_model": model, "physical_cores": phys, "usable_cpus": usable, "cgroup_cpu_quota": _cpu_quota(),
+            "sample": "%d of the benchmark's 640x480 frames through oracle/densefusion_oracle.full_prediction (torch CPU fp32), %d "
+                      "single-threaded workers side by side; single_thread_value = 1 frame on 1 thread; all_cores_value = %s "
+                      "(%d objects found over both legs)"
+                      % (n_frames, workers, "not run" if all_cores is None else "%d further frames of the batch on %d single-threaded "
+                         "workers (one per physical core the process may use)" % (n_all, workers_all), found)}, results
 
 
 def parity_block(out, oracle_results, frames, seg_sd):
@@ -190,8 +233,9 @@ def parity_block(out, oracle_results, frames, seg_sd):
     import torch.nn.functional as F
     objmap = out["objmap"].cpu().numpy()
     pose = out["pose"].cpu().numpy()
-    max_dq = max_dt = 0.0
-    diff_px = diff_outside = missing = 0
+    max_dq = max_dt = adds_delta = adds_gpu_sum = adds_cpu_sum = 0.0
+    diff_px = diff_outside = missing = n_adds = 0
+    dev = out["pose"].device
     for fi, want in oracle_results.items():
         mine = {CLASSES[o[1] - 1]: k for k, o in enumerate(out["objects"]) if o[0] == fi}
         missing += len(set(want) ^ set(mine))
@@ -211,9 +255,35 @@ def parity_block(out, oracle_results, frames, seg_sd):
             q = pose[k, :4] if np.dot(pose[k, :4], w["rotation"]) >= 0 else -pose[k, :4]
             max_dq = max(max_dq, float(np.abs(q - w["rotation"]).max()))
             max_dt = max(max_dt, float(np.abs(pose[k, 4:] - w["position"]).max()))
-    return {"frames": len(oracle_results), "max_dq": max_dq, "max_dt": max_dt, "tolerance": 1e-4, "mask_diff_px": diff_px,
+            # ADD-S of both poses against ONE seeded ground-truth placement of the class's 1000-point model cloud (0.1 m cube,
+            # SURVEY.md 8d; DenseFusion/tools/eval_linemod.py:118-130): the build's through its own HIP k-NN / ADD-S kernel, the
+            # restatement's through the oracle's CPU arithmetic.  Ground truth = the oracle pose turned by 3 degrees about a seeded
+            # axis and moved by 3 mm, so both distances are millimetres, not zero.
+            rng = np.random.default_rng([77, int(fi), int(cls)])
+            axis = rng.standard_normal(3)
+            axis /= np.linalg.norm(axis)
+            half = np.deg2rad(3.0) / 2
+            dq = np.concatenate([[np.cos(half)], np.sin(half) * axis])
+            R_gt = O.quaternion_matrix(np.asarray(w["rotation"], np.float64))[:3, :3] @ O.quaternion_matrix(dq)[:3, :3]
+            step = rng.standard_normal(3)
+            t_gt = np.asarray(w["position"], np.float64) + 0.003 * step / np.linalg.norm(step)
+            model = S.model_cloud(cls)
+            target = (model.astype(np.float64) @ R_gt.T + t_gt).astype(np.float32)
+            g_dis, _, _ = E.adds_dis(torch.from_numpy(pose[k:k + 1, :4].astype(np.float32)).to(dev), torch.from_numpy(pose[k:k + 1, 4:].astype(np.float32)).to(dev),
+                                     None, torch.from_numpy(model).to(dev), torch.from_numpy(target).to(dev), True, want_std=False)
+            pred = (model @ O.quaternion_matrix(np.asarray(w["rotation"], np.float64))[:3, :3].T + np.asarray(w["position"], np.float64)).astype(np.float32)
+            tt, pp = torch.from_numpy(target).t().contiguous(), torch.from_numpy(pred).t().contiguous()
+            inds = O.knn1(tt.unsqueeze(0), pp.unsqueeze(0)).view(-1) - 1
+            c_dis = float(torch.mean(torch.norm(pp.t() - tt.t()[inds], dim=1)))
+            g = float(g_dis[0])
+            adds_delta, adds_gpu_sum, adds_cpu_sum, n_adds = max(adds_delta, abs(g - c_dis)), adds_gpu_sum + g, adds_cpu_sum + c_dis, n_adds + 1
+    return {"frames": len(oracle_results), "max_dq": max_dq, "max_dt": max_dt, "tolerance": 1e-4,
+            "adds_delta_m": adds_delta, "adds_mean_gpu_m": adds_gpu_sum / max(n_adds, 1), "adds_mean_oracle_m": adds_cpu_sum / max(n_adds, 1),
+            "adds_objects": n_adds, "mask_diff_px": diff_px,
             "mask_diff_px_outside_tie_band": diff_outside, "objects_not_matched": missing,
-            "note": "mask pixels may differ only where the oracle's own top-2 class probabilities are closer than 1e-4 (arg-max near-ties)"}
+            "note": "mask pixels may differ only where the oracle's own top-2 class probabilities are closer than 1e-4 (arg-max near-ties); "
+                    "adds_delta_m = max |ADD-S(GPU pose, HIP k-NN/ADD-S kernel) - ADD-S(oracle pose, CPU restatement)| against one seeded "
+                    "ground-truth placement of the 1000-point 0.1 m-cube model cloud (eval_linemod.py:118-130), bar 1e-4 m"}
 
 
 def kernel_peak(label):
@@ -328,6 +398,7 @@ def label_main(args, rank, world, device, dist):
                                        "rendered from %s, resident in HBM" % (n_views, n_chains, per_chain, view_source),
                            "parallelism": "per-view get_surface over %d ranks, 1 padded all_gather/step, chain i fused on rank i %% %d" % (world, world),
                            "fused_points_last_step": int(fused_pts)},
+                "ranks_seen": args.ranks_seen, "distinct_gpus": len({tuple(r[1:3]) for r in args.ranks_seen}),
                 "icp": {"registrations_per_s": round(regs / dt, 1), "evaluations_per_registration": round(evals / max(regs, 1), 2),
                         "point_pairs_per_s": round(pairs / dt, 0)},
                 "roofline": {"kernel": "ICP registration (icp_step + icp_transform + nn1 + p2p/p2plane sums per evaluation)", "bound": "hbm",
@@ -368,6 +439,11 @@ def main():
                          "point-cloud fusion + point-to-plane ICP over --views synthetic views, sharded across the ranks")
     ap.add_argument("--views", type=int, default=200, help="--workload label: views per step (one (object, direction) chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfiltered-frames", action="store_true",
+                    help="time the first --batch random frames of each rank as they come (about 1 in 100 carries a stray blob or a clipped "
+                         "120x160 crop) instead of selecting frames with exactly one 160x160 detection (configs[2], the default)")
+    ap.add_argument("--baseline-frames", type=int, default=64,
+                    help="frames of the batch the CPU baseline / parity leg runs (all-cores leg; the 16-worker leg uses the first 16 of them)")
     ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
                     help="(default) pose stage of step i on a second HIP stream beside the segmentation of step i+1 (software-pipelined "
                          "loop, every step still does all of its work inside the fences): +4 %% frames/s; the per-kernel event timings "
@@ -399,6 +475,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    args.ranks_seen = ranks_seen(rank, device, dist)
     if args.workload == "label":
         return label_main(args, rank, world, device, dist)
 
@@ -422,12 +499,14 @@ def main():
     seg.set_precision(args.seg_precision)
     est.set_precision(args.pose_precision)
     ref.set_precision(args.pose_precision)
-    frames = select_frames(per_rank, rank, FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat"), device)
+    if args.unfiltered_frames:
+        frames, skipped = make_frames(per_rank, rank), 0
+    else:
+        frames, skipped = select_frames(per_rank, rank, FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat"), device)
     rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device).split(args.batch)        # inputs resident in HBM
     depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device).split(args.batch)
-    # --overlap: the pose stage of step i runs on a second HIP stream beside the segmentation of step i+1 (the timed region ends
-    # with torch.cuda.synchronize(), which waits for both streams; every step still does all of its work).  Off by default: the
-    # live per-kernel timings of the roofline leg should be the kernels' own.
+    # --overlap (the default): the pose stage of step i runs on a second HIP stream beside the segmentation of step i+1 (the timed
+    # region ends with torch.cuda.synchronize(), which waits for both streams; every step still does all of its work).
     pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap)
     from autoposeestimation_amd.sharding import gather_results
 
@@ -594,9 +673,14 @@ def main():
                                     "PoseNet(N=1000) -> 2x PoseRefineNet, batch=%d 640x480 frames per GPU" % args.batch),
                        "frames_per_gpu_per_step": per_rank, "objects_found_last_step": n_found,
                        "crop_buckets_last_step": crop_hist,
+                       "frame_selection": ("the rank's first %d random synthetic frames as they come" % per_rank) if args.unfiltered_frames else
+                                          "one 160x160 detection per frame (configs[2]): random candidates whose segmentation gives a stray blob "
+                                          "or a border-clipped crop are skipped during set-up, untimed (--unfiltered-frames times them all)",
+                       "candidates_skipped": skipped,
                        "gflop_per_frame_algorithmic": GFLOP_PER_FRAME, "parallelism": "frames sharded x%d, 1 all_gather of poses/step" % world},
             "achieved_tflops_algorithmic": round(total_frames * GFLOP_PER_FRAME / dt / 1e3, 2),
             "overlap": bool(args.overlap),
+            "ranks_seen": args.ranks_seen, "distinct_gpus": len({tuple(r[1:3]) for r in args.ranks_seen}),
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
@@ -612,7 +696,8 @@ def main():
                 return choose_h[k]
 
             last = frames[(n_chunks - 1) * args.batch:]      # `out` is the last sub-batch of the last step
-            line["cpu_baseline"], oracle_results = cpu_baseline(last, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=min(16, args.batch))
+            line["cpu_baseline"], oracle_results = cpu_baseline(last, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=min(16, args.batch),
+                                                                n_frames_all=min(args.baseline_frames, args.batch))
             line["parity"] = parity_block(out, oracle_results, last, seg_sd)
         print(json.dumps(line))
     if dist:

@@ -47,13 +47,23 @@ def test_default_line_has_roofline_cpu_baseline_and_parity():
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["value"] > 0
     p = d["parity"]
     assert p["frames"] >= 8 and p["max_dq"] <= 1e-4 and p["max_dt"] <= 1e-4 and p["mask_diff_px_outside_tie_band"] == 0 and p["objects_not_matched"] == 0
+    # BASELINE's metric is "frames/sec ...; ADD-S delta" (SURVEY.md 8d): |ADD-S(build) - ADD-S(CPU restatement)| <= 1e-4 m on the 1000-point model cloud
+    assert p["adds_objects"] >= 8 and p["adds_delta_m"] <= 1e-4 and 1e-3 < p["adds_mean_oracle_m"] < 2e-2
+    assert p["frames"] == 64 and c["all_cores"] is None or c["all_cores"]["cores"] > c["cores"]      # the all-physical-cores leg ran when the box has them
+    assert d["ranks_seen"] == [[0, 0, d["ranks_seen"][0][2], d["ranks_seen"][0][3]]] and d["distinct_gpus"] == 1
+    assert "one 160x160 detection per frame" in d["config"]["frame_selection"] and d["config"]["candidates_skipped"] >= 0
 
 
 def test_frames_1024_line():
-    d = _run("--frames", "256", "--batch", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    """BASELINE configs[3] at its own size: 1024 frames per step (16 sub-batches of 64 on the one GPU), parity block kept (the oracle
+    runs 16 frames of the last sub-batch)"""
+    d = _run("--frames", "1024", "--batch", "64", "--steps", "1", "--warmup", "1", "--baseline-frames", "16")
     _common(d, 1, 1)
-    assert d["scaling"] == "strong" and d["config"]["frames_per_gpu_per_step"] == 256 and "configs[3]" in d["config"]["workload"]
-    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    assert d["scaling"] == "strong" and d["config"]["frames_per_gpu_per_step"] == 1024 and "configs[3]" in d["config"]["workload"]
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    p = d["parity"]
+    assert p["frames"] == 16 and p["max_dq"] <= 1e-4 and p["max_dt"] <= 1e-4 and p["mask_diff_px_outside_tie_band"] == 0 and p["objects_not_matched"] == 0
+    assert p["adds_delta_m"] <= 1e-4
 
 
 def test_label_line():

@@ -156,3 +156,152 @@ def test_prefetched_keeps_order_and_propagates_errors():
     # without a GPU (this test), or for one job, the jobs simply run in order
     assert run_side_by_side([lambda i=i: i + 1 for i in range(5)]) == [1, 2, 3, 4, 5]
     assert run_side_by_side([]) == []
+
+
+# ---- more ranks than two, uneven shards (CPU rehearsal of the 8-GPU node: gloo, tiny clouds) ------------------------------------------
+def _spawn(worker, world, port_base, *args, timeout=120):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = port_base + os.getpid() % 150
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(timeout)
+        assert p.exitcode == 0
+    return dict(got)
+
+
+def _uneven_worker(rank, world, port, q, n_frames, chain_lens):
+    import numpy as np
+    from autoposeestimation_amd import sharding
+    from autoposeestimation_amd.experiments.eval import merge_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # frames: this rank's (uneven) share, padded to the largest share for the single equally-shaped all_gather
+    lo, hi = shard_range(n_frames, rank, world)
+    per_rank = -(-n_frames // world)
+    objects = [(f - lo, 1 + f % 3, 0, 0, 0, 0) for f in range(lo, hi) if f % 5 != 4]
+    pose = torch.stack([_fake_pose(lo + o[0]) for o in objects]) if objects else torch.zeros(0, 7, dtype=torch.float64)
+    full = gather_results(pack_results(per_rank, objects, pose, max_obj=1), dist)
+    # label chains of different lengths: per-view work over all ranks, each surface to its chain's owner only
+    views = _views(sum(chain_lens))
+    chains, pos = [], 0
+    for n in chain_lens:
+        chains.append(views[pos:pos + n])
+        pos += n
+    made = []
+
+    def make_set(v):
+        made.append(len(v))
+        return torch.from_numpy(v * 2.0)
+
+    multi = sharding.sharded_chains(chains, make_set, _order_dependent_fuse, dist)
+    # owner-only exchange: set gi goes to rank (gi * 3) % world and to nobody else
+    n_sets = len(views)
+    slo, shi = shard_range(n_sets, rank, world)
+    owners = [(gi * 3) % world for gi in range(n_sets)]
+    got_sets = sharding.gather_point_sets([(gi, views[gi]) for gi in range(slo, shi)], n_sets, dist, owners=owners)
+    sets_ok = all((s is None) == (owners[gi] != rank) and (s is None or np.array_equal(s.numpy(), views[gi])) for gi, s in enumerate(got_sets))
+    # ADD-S evaluation: every rank's per-class buckets -> the all-reduced (sum dis, n < 2 cm, n) table
+    classes = ["a", "b", "c"]
+    local = {c: {"<2": 0, ">=2": 0, "dis": []} for c in classes}
+    elo, ehi = shard_range(29, rank, world)
+    for j in range(elo, ehi):
+        d = 0.001 * (1 + (j * 7) % 40)
+        local[classes[j % 3]]["dis"].append(d)
+        local[classes[j % 3]]["<2" if d < 0.02 else ">=2"] += 1
+    merged = merge_results(local, classes, dist)
+    q.put((rank, {"full": full, "multi": {k: v.tolist() for k, v in multi.items()}, "made": len(made), "sets_ok": sets_ok,
+                  "merged": {c: (merged[c]["<2"], merged[c][">=2"], float(merged[c]["dis"]), float(merged[c]["p"]), merged[c]["dis_all"]) for c in classes}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_uneven(world, n_frames, chain_lens, port_base):
+    import numpy as np
+    from autoposeestimation_amd import sharding
+    from autoposeestimation_amd.experiments.eval import merge_results
+    got = _spawn(_uneven_worker, world, port_base, n_frames, chain_lens)
+    per_rank = -(-n_frames // world)
+    for r in range(world):
+        full = got[r]["full"]
+        assert full.shape == (world * per_rank, 1, 8)
+        for rr in range(world):
+            lo, hi = shard_range(n_frames, rr, world)
+            for f in range(lo, hi):
+                row = full[rr * per_rank + f - lo, 0]
+                if f % 5 == 4:
+                    assert not row.any()
+                else:
+                    assert row[0] == 1 + f % 3 and torch.allclose(row[1:], _fake_pose(f).float())
+            assert not full[rr * per_rank + hi - lo:(rr + 1) * per_rank].any()        # the padding of a short share stays empty
+        assert got[r]["sets_ok"]
+    views = _views(sum(chain_lens))
+    chains, pos = [], 0
+    for n in chain_lens:
+        chains.append(views[pos:pos + n])
+        pos += n
+    want = [_order_dependent_fuse([v * 2.0 for v in ch]).tolist() for ch in chains]
+    owned = {}
+    for r in range(world):
+        for ci, v in got[r]["multi"].items():
+            assert sharding.chain_owner(ci, world) == r and ci not in owned
+            owned[ci] = v
+    assert [owned[ci] for ci in range(len(chains))] == want                          # every chain fused exactly once, bit-identical
+    assert sum(got[r]["made"] for r in range(world)) == len(views)                   # every view pre-processed exactly once
+    assert max(got[r]["made"] for r in range(world)) - min(got[r]["made"] for r in range(world)) <= 1
+    classes = ["a", "b", "c"]
+    local = {c: {"<2": 0, ">=2": 0, "dis": []} for c in classes}
+    for j in range(29):
+        d = 0.001 * (1 + (j * 7) % 40)
+        local[classes[j % 3]]["dis"].append(d)
+        local[classes[j % 3]]["<2" if d < 0.02 else ">=2"] += 1
+    single = merge_results(local, classes, None)
+    for r in range(world):
+        for c in classes:
+            less, more, dis, p, dis_all = got[r]["merged"][c]
+            assert (less, more) == (single[c]["<2"], single[c][">=2"]) and p == float(single[c]["p"])
+            assert abs(dis - float(single[c]["dis"])) <= 1e-5 and sorted(dis_all) == sorted(single[c]["dis_all"])
+            assert np.isclose(np.mean(dis_all), np.mean(single[c]["dis_all"]))
+
+
+def test_three_ranks_uneven_frames_views_and_chains():
+    _check_uneven(3, 10, [3, 4, 2, 5], 30100)          # 10 frames over 3 ranks (4 + 3 + 3), 14 views (5 + 5 + 4), 4 chains (2 + 1 + 1)
+
+
+def test_eight_ranks_uneven_frames_views_and_chains():
+    _check_uneven(8, 13, [2, 1, 3, 2, 1, 2, 3, 1, 2, 2], 30300)      # fewer frames than 2 per rank, 19 views, 10 chains over 8 ranks
+
+
+def _failing_worker(rank, world, port, q):
+    from autoposeestimation_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    views = _views(6)
+
+    def make_set(v):
+        if rank == 1:
+            raise KeyError("bad view on rank 1")
+        return torch.from_numpy(v)
+
+    try:
+        sharding.sharded_chains([views[:3], views[3:]], make_set, _order_dependent_fuse, dist)
+        outcome = "returned"
+    except KeyError:
+        outcome = "own error"
+    except RuntimeError as e:
+        outcome = "told: " + str(e)
+    q.put((rank, outcome))
+    dist.barrier()                      # every rank is still alive and in step: nobody is stuck in the gather
+    dist.destroy_process_group()
+
+
+def test_a_failure_on_one_rank_is_raised_on_every_rank():
+    got = _spawn(_failing_worker, 3, 30500)
+    assert got[1] == "own error"
+    for r in (0, 2):
+        assert got[r].startswith("told:") and "rank(s) [1]" in got[r]
