@@ -7,8 +7,14 @@
 //     (`buffer_load_dwordx4 ... lds`, 1 KB = 8 pixels (rows) x 128 B per wave-instruction); pixels outside the image and rows past
 //     Cout lie outside the buffer descriptors' range and arrive as zeros;
 //   * the halo lives in a RING OF 32 IMAGE ROWS (24 pixels x 128 B each): the (16 + 2d)-row image of chunk c+1 is streamed in while
-//     chunk c is multiplied -- 16 - 2d rows at once, d rows after its taps ky = 0, d after ky = 1, 2d during its last tap -- so the
-//     first 16 rows are there when chunk c ends, for every dilation (a second whole image does not fit beside the weights for d = 4);
+//     chunk c is multiplied -- its first 16 - 2d rows (ring rows the current image does not use) during taps 1 and 2, d rows after the
+//     taps ky = 0 (tap 3), d after ky = 1 (tap 6) -- and its LAST 2d rows, which land on rows the current chunk's final tap still
+//     reads, only in tap 0 of chunk c+1 itself, i.e. behind the barrier that closes that final tap (they are first read for ky = 1,
+//     from tap 2's second phase on, two closing barriers later).  A second whole image does not fit beside the weights for d = 4;
+//   * PERSISTENT workgroups: one per CU walks the tiles  blockIdx, + gridDim, ...; the chunk stream simply continues into the next
+//     tile's first chunk, so only a workgroup's FIRST tile pays the prologue (image + three weight tiles), and a tile's epilogue
+//     (residual tile requested up front, stores fire-and-forget) is followed at once by the next tile's taps, whose operands are
+//     already in LDS / registers;
 //   * the weights of the next taps sit in a ring of four 16 KB tiles, issued three taps ahead;
 //   * the fragments of tap t+1 are read from LDS (pinned inline asm, cf. conv_gemm_s32.hip) into a second register set while the
 //     48 MFMAs of tap t run; one barrier per tap, counted vmcnt (never 0 in the steady state).
@@ -38,7 +44,8 @@ struct HaloS32Args {
     int bias_bstride;
     int out_fmt, res_fmt;
     int tiles_x, tiles_y, n_tiles;
-    int dbg;                // ape_conv3x3_halo_s32_debug: 1 = static priority 1 for waves 4-7 (results unchanged)
+    int dbg;                // ape_conv3x3_halo_s32_debug: 1 = static priority 1 for waves 4-7, 2 = one workgroup per tile instead of the
+                            // persistent walk (results unchanged by either); timing-only ablations: 4 = no epilogue stores, 8 = no residual loads
 };
 
 __device__ __forceinline__ float act_h(float v, int act, float alpha)
@@ -105,23 +112,36 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     constexpr int I = TS + 2 * D;       // image rows of one chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // ---- the tile walk: logical tile ids are dealt to the XCDs in contiguous runs (bijective remap of the dispatch id); a persistent
+    // workgroup takes dispatch ids blockIdx, + gridDim, ... -- all on its own XCD's run, and (the host sizes the grid so) all with the
+    // same channel tile n_tile, so neighbouring workgroups keep sharing one spatial tile's halo through their XCD's L2
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int nwg = a.B * tiles_per_img * a.n_tiles;
-    const int orig = blockIdx.x;
-    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-    const int n_tile = logical % a.n_tiles;
-    const int mt = logical / a.n_tiles;
-    const int b = mt / tiles_per_img, trem = mt - b * tiles_per_img;
-    const int y0 = (trem / a.tiles_x) * TS, x0 = (trem % a.tiles_x) * TS;
-    const int n0 = n_tile * 128;
+    const int q = nwg / 8, r = nwg % 8;
+    const int grid = (int)gridDim.x;
+    const int my_tiles = (nwg - 1 - (int)blockIdx.x) / grid + 1;
+    int cur_b, cur_y0, cur_x0, n0;
+    auto decode = [&](int orig, int& tb, int& ty0, int& tx0, int& tn0) {
+        const int xcd = orig % 8;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        const int n_tile = logical % a.n_tiles;
+        const int mt = logical / a.n_tiles;
+        tb = mt / tiles_per_img;
+        const int trem = mt - tb * tiles_per_img;
+        ty0 = (trem / a.tiles_x) * TS;
+        tx0 = (trem % a.tiles_x) * TS;
+        tn0 = n_tile * 128;
+    };
+    int cur_orig = blockIdx.x;
+    decode(cur_orig, cur_b, cur_y0, cur_x0, n0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int nchunks = a.Cin / 32;
     const int K = 9 * a.Cin;
-    const int ntaps = nchunks * 9;
+    const int total_chunks = my_tiles * nchunks;
+    const int total_taps = total_chunks * 9;
 
     // ---- DMA sources ---------------------------------------------------------------------------------------------------------
     const long x_bytes = (long)a.B * a.H * a.W * a.ldx * 4;
@@ -129,26 +149,33 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.w + (long)n0 * K * 4), 0, (int)(w_bytes > 0x7FFFFFFFL ? 0x7FFFFFFFu : (unsigned)w_bytes), 0x00020000);
+    // the tile whose image is being streamed in ("DMA tile"): the current tile until its last chunk's tap 0, then the next one.
     // a halo piece = 8 pixels of one image row: lanes 8 j .. 8 j + 7 fetch pixel j's 128-B line, chunks permuted by the column swizzle
+    int dma_b = cur_b, dma_y0 = cur_y0;
     unsigned lane_x[3];
+    auto set_dma_tile = [&](int tb, int ty0, int tx0) {
+        dma_b = tb;
+        dma_y0 = ty0;
 #pragma unroll
-    for (int xp = 0; xp < 3; ++xp) {
-        const int hx = xp * 8 + (lane >> 3);
-        const int gx = x0 - D + hx;
-        const bool ok = hx < TS + 2 * D && (unsigned)gx < (unsigned)a.W;
-        lane_x[xp] = ok ? (unsigned)((gx * a.ldx + a.xoff) * 4 + (((lane & 7) ^ ((hx >> 1) & 7)) * 16)) : 0x80000000u;
-    }
+        for (int xp = 0; xp < 3; ++xp) {
+            const int hx = xp * 8 + (lane >> 3);
+            const int gx = tx0 - D + hx;
+            const bool ok = hx < TS + 2 * D && (unsigned)gx < (unsigned)a.W;
+            lane_x[xp] = ok ? (unsigned)((gx * a.ldx + a.xoff) * 4 + (((lane & 7) ^ ((hx >> 1) & 7)) * 16)) : 0x80000000u;
+        }
+    };
+    set_dma_tile(cur_b, cur_y0, cur_x0);
     unsigned vb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 8 + (lane >> 3);
         vb[i] = (unsigned)(row * K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
     }
-    // piece `p` of image rows [r0, ..) of chunk `c` (row = r0 + p / 3, x-piece = p % 3), written to ring row (ring0 + row) & 31
+    // piece (row, x-piece xp) of channel chunk `c` of the DMA tile's image, written to ring row (ring0 + row) & 31
     auto dma_a_piece = [&](int c, int ring0, int row, int xp) {      // xp: a literal at every call site
-        const int gy = y0 - D + row;
+        const int gy = dma_y0 - D + row;
         const bool row_ok = (unsigned)gy < (unsigned)a.H;
-        const unsigned row_off = (unsigned)(((b * a.H + (row_ok ? gy : 0)) * a.W) * a.ldx * 4 + c * 128);
+        const unsigned row_off = (unsigned)(((dma_b * a.H + (row_ok ? gy : 0)) * a.W) * a.ldx * 4 + c * 128);
         unsigned voff = lane_x[xp] + row_off;
         if (!row_ok) voff = 0xFFFFFFFFu;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + ((ring0 + row) & (RING_ROWS - 1)) * ROW_B + xp * 1024), 16, voff, 0, 0, 0);
@@ -165,12 +192,12 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         }
         return n;
     };
-    auto dma_b_tap = [&](int tg) {        // the weights of global tap tg = chunk * 9 + tap: k-group tap * nchunks + chunk, ring slot tg & 3
-        const int c = tg / 9, tap = tg - c * 9;
+    // the weights of tap `tap` of channel chunk `c` (k-group tap * nchunks + c) into ring slot `slot`
+    auto dma_b_tap = [&](int c, int tap, int slot) {
         const int g = tap * nchunks + c;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + A_BYTES + (tg & (B_RING - 1)) * B_TILE + (wave * 2 + i) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + A_BYTES + slot * B_TILE + (wave * 2 + i) * 1024), 16,
                                                      vb[i], g * 128, 0, 0);
     };
 
@@ -188,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     const unsigned b_lane[2] = {(unsigned)(A_BYTES + (wn * 64 + frow) * 128 + ((fc ^ swb) * 16)),
                                 (unsigned)(A_BYTES + (wn * 64 + frow) * 128 + (((4 + fc) ^ swb) * 16))};
     u32x4 Ah[2][2][2], Bf[2][4][2];     // Ah[half][pixel row in the half][plane] (one tap's rows 0,1 | 2,3); Bf[set][channel block][plane]
-    // read: pixel rows 2 half, 2 half + 1 of (image at ring0, tap) and weight blocks 2 half, 2 half + 1 of global tap tgb into B set `bset`
+    // read: pixel rows 2 half, 2 half + 1 of (image at ring0, tap) and weight blocks 2 half, 2 half + 1 of ring slot (tgb & 3) into B set `bset`
     auto read_half = [&](auto half_c, auto bset_c, int ring0, int tap, int tgb) {
         constexpr int half = decltype(half_c)::value, bset = decltype(bset_c)::value;
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -199,13 +226,16 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         ds_read_half<2 * half>(Ah[half], Bf[bset], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
     };
     f32x4 acc[4][4];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
-    // 48 MFMAs of one tap on register set `set`; hook(i) runs (pinned) after pixel row i: the DMA pieces go out between the rows
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+    // 12 MFMAs of pixel row i of one tap on register set `set`
     auto mfma_row = [&](auto set_c, auto ic) {
         constexpr int set = decltype(set_c)::value, i = decltype(ic)::value;
 #pragma unroll
@@ -231,13 +261,13 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     // one wave of every SIMD pair at priority 1 for the whole kernel pays in the GEMM kernel (conv_gemm_s32.hip, -1.5 .. -3 %) but not
     // here (+-0 .. +1 % on all six layer shapes, tools/mb_halo_s32.py): off unless the debug bit asks for it
     if ((a.dbg & 1) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
-    // ---- prologue: the whole first image and the first three weight tiles --------------------------------------------------------
+    // ---- prologue (a workgroup's first tile only): the whole first image and the first three weight tiles --------------------------
     dma_a_rows_xp(0, 0, 0, I, I0{});
     dma_a_rows_xp(0, 0, 0, I, I1{});
     dma_a_rows_xp(0, 0, 0, I, I2{});
-    dma_b_tap(0);
-    if (ntaps > 1) dma_b_tap(1);
-    if (ntaps > 2) dma_b_tap(2);
+    dma_b_tap(0, 0, 0);
+    if (total_taps > 1) dma_b_tap(0, 1, 1);
+    if (total_taps > 2) dma_b_tap(0, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_half(I0{}, I0{}, 0, 0, 0);
@@ -251,17 +281,17 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
 
     // ---- one tap = two phases of 24 MFMAs (pixel rows 0,1 | 2,3 against the four weight blocks of B set P).  While a phase runs, the
     // fragments of the NEXT phase are read: phase 0 fetches this tap's rows 2,3 and weight blocks 0,1 of tap t+1 (into the other B
-    // set), phase 1 fetches rows 0,1 and weight blocks 2,3 of tap t+1.  The DMA pieces of the next image (rows [ar0, ar0 + arn) of
-    // chunk c+1, ring position ring_next) and the weights of tap t+3 go out between the MFMA rows.  The closing barrier makes the
-    // weights of tap t+2 (issued one tap ago) and every older piece visible: only what this tap issued may still be in flight.
-    auto tap_body = [&](auto set_c, int c, int tap, int ring_cur, int ring_next, int ar0, int arn) {
+    // set), phase 1 fetches rows 0,1 and weight blocks 2,3 of tap t+1 (across a chunk or tile seam: of the next image's tap 0).  The
+    // DMA pieces (image rows [ar0, ar0 + arn) of chunk dc, ring position dring) and the weights of tap t+3 go out between the MFMA
+    // rows.  The closing barrier makes the weights of tap t+2 (issued one tap ago) and every older piece visible: only what this tap
+    // issued may still be in flight.
+    //   tg = flattened tap index over all of this workgroup's chunks; (c, tap) = chunk in the tile, tap in the chunk
+    auto tap_body = [&](auto set_c, int tg, int c, int tap, bool last_of_tile, int ring_cur, int ring_next, int dc, int dring, int ar0, int arn) __attribute__((always_inline)) {
         constexpr int P = decltype(set_c)::value;
-        const int tg = c * 9 + tap;
-        const bool has_next = tg + 1 < ntaps;
         const bool wrap = tap == 8;
         const int nring = wrap ? ring_next : ring_cur, ntap = wrap ? 0 : tap + 1;
-        const bool more_a = c + 1 < nchunks && arn > 0;
-        const bool more_b = tg + 3 < ntaps;
+        const bool more_a = arn > 0;
+        const bool more_b = tg + 3 < total_taps;
         int issued = 0;
         // phase 0
         {
@@ -275,11 +305,11 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(set_c, I0{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more_a) issued += dma_a_rows_xp(c + 1, ring_next, ar0, arn, I0{});
+        if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I0{});
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(set_c, I1{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more_a) issued += dma_a_rows_xp(c + 1, ring_next, ar0, arn, I1{});
+        if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I1{});
         phase_end();
         // phase 1
         {
@@ -293,94 +323,162 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(set_c, I2{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more_a) issued += dma_a_rows_xp(c + 1, ring_next, ar0, arn, I2{});
+        if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I2{});
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(set_c, I3{});
         __builtin_amdgcn_sched_barrier(0);
-        if (more_b) { dma_b_tap(tg + 3); issued += 2; }
+        if (more_b) {
+            const int t3 = tap + 3;          // (chunk, tap) of flattened tap tg + 3: the same weights for every tile of this workgroup
+            const int c3 = t3 < 9 ? c : (last_of_tile ? 0 : c + 1);
+            dma_b_tap(c3, t3 < 9 ? t3 : t3 - 9, (tg + 3) & (B_RING - 1));
+            issued += 2;
+        }
         phase_end();
-        (void)has_next;
         wait_vmcnt(issued);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    int ring = 0;       // ring row of the current chunk's image row 0
-#pragma unroll 1
-    for (int c = 0; c < nchunks; c += 2) {
-        // two chunks per iteration: 18 taps, so the register sets alternate with a compile-time parity
-        const int ring1 = (ring + I) & (RING_ROWS - 1), ring2 = (ring1 + I) & (RING_ROWS - 1);
-        tap_body(I0{}, c, 0, ring, ring1, 0, RING_ROWS - I);
-        tap_body(I1{}, c, 1, ring, ring1, 0, 0);
-        tap_body(I0{}, c, 2, ring, ring1, 0, 0);
-        tap_body(I1{}, c, 3, ring, ring1, RING_ROWS - I, D);
-        tap_body(I0{}, c, 4, ring, ring1, 0, 0);
-        tap_body(I1{}, c, 5, ring, ring1, 0, 0);
-        tap_body(I0{}, c, 6, ring, ring1, RING_ROWS - I + D, D);
-        tap_body(I1{}, c, 7, ring, ring1, 0, 0);
-        tap_body(I0{}, c, 8, ring, ring1, RING_ROWS - I + 2 * D, 2 * D);
-        if (c + 1 < nchunks) {
-            tap_body(I1{}, c + 1, 0, ring1, ring2, 0, RING_ROWS - I);
-            tap_body(I0{}, c + 1, 1, ring1, ring2, 0, 0);
-            tap_body(I1{}, c + 1, 2, ring1, ring2, 0, 0);
-            tap_body(I0{}, c + 1, 3, ring1, ring2, RING_ROWS - I, D);
-            tap_body(I1{}, c + 1, 4, ring1, ring2, 0, 0);
-            tap_body(I0{}, c + 1, 5, ring1, ring2, 0, 0);
-            tap_body(I1{}, c + 1, 6, ring1, ring2, RING_ROWS - I + D, D);
-            tap_body(I0{}, c + 1, 7, ring1, ring2, 0, 0);
-            tap_body(I1{}, c + 1, 8, ring1, ring2, RING_ROWS - I + 2 * D, 2 * D);
-        }
-        ring = ring2;
-    }
 
-    // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel (4 wm + i, frow) -----------
-    const int nq = n0 + wn * 64 + fc * 4;
-    const float* bp = a.bias ? a.bias + (a.bias_bstride ? (size_t)b * a.bias_bstride : 0) : nullptr;
-    float4 b4[4];
+    // ---- epilogue of the current tile straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel
+    // (4 wm + i, frow).  The whole residual tile is requested before the first use (16 loads in flight: one memory round trip, not one
+    // per pixel row -- the stores of row i may alias the loads of row i + 1 for all the compiler knows); the stores are not waited
+    // for here: the next tile's taps run while they drain (a tap's closing vmcnt wait covers them, they are older than its pieces).
+    // One instance of the store loop per output format; the activation of the common layers is a select, not a switch.
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int nq = n0 + wn * 64 + fc * 4;
+        const float* bp = a.bias ? a.bias + (a.bias_bstride ? (size_t)cur_b * a.bias_bstride : 0) : nullptr;
+        const int gx = cur_x0 + frow;
+        // 16 residual bytes per (pixel row i, channel block j), fetched as two 8-byte halves for BOTH formats (same instruction stream):
+        // S32: hi 4 x bf16 | lo 4 x bf16 (64 B apart); fp32: floats 0,1 | floats 2,3 (8 B apart)
+        uint2 rlo[4][4], rhi[4][4];
+        if (a.res && !(a.dbg & 8)) {
+            const bool rs32 = a.res_fmt == APE_FMT_S32;
+            const long second = rs32 ? 64 : 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = nq + j * 16;
-        b4[j] = (bp && n < a.Cout) ? *reinterpret_cast<const float4*>(bp + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+            for (int i = 0; i < 4; ++i) {
+                const int gy = cur_y0 + 4 * wm + i;
+                const bool pix_ok = gy < a.H && gx < a.W;
+                const size_t m = ((size_t)cur_b * a.H + (pix_ok ? gy : 0)) * a.W + (pix_ok ? gx : 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gy = y0 + 4 * wm + i, gx = x0 + frow;
-        if (gy >= a.H || gx >= a.W) continue;
-        const size_t m = ((size_t)b * a.H + gy) * a.W + gx;
-        float4 rr[4];
-        if (a.res) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = nq + j * 16;
-                if (n >= a.Cout) continue;
-                if (a.res_fmt == APE_FMT_S32) {
-                    const int cr = a.roff + n;
-                    const char* rp = a.res + m * a.ldr * 4 + (cr >> 5) * 128 + (cr & 31) * 2;
-                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(rp), l = *reinterpret_cast<const bf16x4*>(rp + 64);
-                    rr[j] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
-                } else {
-                    rr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + m * a.ldr + a.roff + n);
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nq + j * 16;
+                    const int cr = a.roff + (n < a.Cout ? n : 0);       // (a clamped, never-used address for channels past Cout)
+                    const char* rp = a.res + (rs32 ? m * a.ldr * 4 + (size_t)((cr >> 5) * 128 + (cr & 31) * 2) : (m * a.ldr + cr) * 4);
+                    rlo[i][j] = *reinterpret_cast<const uint2*>(rp);
+                    rhi[i][j] = *reinterpret_cast<const uint2*>(rp + second);
                 }
             }
         }
+        float4 b4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = nq + j * 16;
-            if (n >= a.Cout) continue;
-            float vv[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
-            if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
+            b4[j] = (bp && n < a.Cout) ? *reinterpret_cast<const float4*>(bp + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const bool relu = a.act == APE_ACT_RELU;
+        const float slope = a.act == APE_ACT_PRELU ? a.alpha : 1.f;         // APE_ACT_NONE: v <= 0 -> 1 * v
+        const bool sigmoid = a.act == APE_ACT_SIGMOID;
+        auto store_tile = [&](auto s32_c) __attribute__((always_inline)) {
+            constexpr bool OUT_S32 = decltype(s32_c)::value != 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vv[e] = act_h(vv[e], a.act, a.alpha);
-            if (a.out_fmt == APE_FMT_S32) {
-                const int cy = a.yoff + n;
-                char* yp = a.y + m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
-                bf16x4 h, l;
+            for (int i = 0; i < 4; ++i) {
+                const int gy = cur_y0 + 4 * wm + i;
+                if (gy >= a.H || gx >= a.W) continue;
+                const size_t m = ((size_t)cur_b * a.H + gy) * a.W + gx;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
-                *reinterpret_cast<bf16x4*>(yp) = h;
-                *reinterpret_cast<bf16x4*>(yp + 64) = l;
-            } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nq + j * 16;
+                    if (n >= a.Cout || (a.dbg & 4)) continue;
+                    float vv[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
+                    if (a.res && !(a.dbg & 8)) {
+                        if (a.res_fmt == APE_FMT_S32) {
+                            const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[i][j]), l = __builtin_bit_cast(bf16x4, rhi[i][j]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vv[e] += (float)h[e] + (float)l[e];
+                        } else {
+                            vv[0] += __uint_as_float(rlo[i][j].x);
+                            vv[1] += __uint_as_float(rlo[i][j].y);
+                            vv[2] += __uint_as_float(rhi[i][j].x);
+                            vv[3] += __uint_as_float(rhi[i][j].y);
+                        }
+                    }
+                    if (sigmoid) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = 1.f / (1.f + __expf(-vv[e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float neg = relu ? 0.f : slope * vv[e];
+                            vv[e] = vv[e] > 0.f ? vv[e] : neg;
+                        }
+                    }
+                    if (OUT_S32) {
+                        const int cy = a.yoff + n;
+                        char* yp = a.y + m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
+                        bf16x4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
+                        *reinterpret_cast<bf16x4*>(yp) = h;
+                        *reinterpret_cast<bf16x4*>(yp + 64) = l;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                }
             }
+        };
+        if (a.out_fmt == APE_FMT_S32) store_tile(I1{}); else store_tile(I0{});
+    };
+
+    // ---- one channel chunk = nine taps on alternating register sets (P0 = the set its tap 0 multiplies); gc = flattened chunk index.
+    int c = 0;                  // chunk inside the current tile
+    bool tile_done = false;     // the chunk just multiplied was its tile's last: the epilogue follows at the end of the iteration
+    auto chunk = [&](auto p0_c, int gc, int ring_cur, int ring_next) __attribute__((always_inline)) {
+        constexpr int P0 = decltype(p0_c)::value;
+        using PA = std::integral_constant<int, P0>;
+        using PB = std::integral_constant<int, P0 ^ 1>;
+        const bool last_of_tile = c + 1 == nchunks;
+        const bool has_next = gc + 1 < total_chunks;       // a further chunk (of this tile or of the workgroup's next tile) follows
+        const int tg = gc * 9;
+        // tap 0: the last 2 D rows of THIS chunk's image (skipped for the workgroup's very first chunk: the prologue loaded all of it)
+        tap_body(PA{}, tg + 0, c, 0, last_of_tile, ring_cur, ring_next, c, ring_cur, I - 2 * D, gc > 0 ? 2 * D : 0);
+        // from here on the DMA side works on the next chunk's image: chunk c + 1 of this tile, or chunk 0 of the workgroup's next tile
+        int dc = c + 1;
+        if (last_of_tile) {
+            dc = 0;
+            if (has_next) {
+                int tb, ty0, tx0, tn0;
+                decode(cur_orig + grid, tb, ty0, tx0, tn0);
+                set_dma_tile(tb, ty0, tx0);
+            }
+        }
+        constexpr int FREE = RING_ROWS - I;                // rows of the next image that land on ring rows no image uses now
+        constexpr int H1 = (FREE + 1) / 2;
+        tap_body(PB{}, tg + 1, c, 1, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, has_next ? H1 : 0);
+        tap_body(PA{}, tg + 2, c, 2, last_of_tile, ring_cur, ring_next, dc, ring_next, H1, has_next ? FREE - H1 : 0);
+        tap_body(PB{}, tg + 3, c, 3, last_of_tile, ring_cur, ring_next, dc, ring_next, FREE, has_next ? D : 0);
+        tap_body(PA{}, tg + 4, c, 4, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_body(PB{}, tg + 5, c, 5, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_body(PA{}, tg + 6, c, 6, last_of_tile, ring_cur, ring_next, dc, ring_next, FREE + D, has_next ? D : 0);
+        tap_body(PB{}, tg + 7, c, 7, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_body(PA{}, tg + 8, c, 8, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tile_done = last_of_tile;
+        c = last_of_tile ? 0 : c + 1;
+    };
+    int ring = 0;       // ring row of the current chunk's image row 0
+#pragma unroll 1
+    for (int gc = 0; gc < total_chunks; gc += 2) {
+        // two chunks per iteration: 18 taps, so the register sets alternate with a compile-time parity.  A tile ends only at the end of
+        // an iteration: the host walks several tiles per workgroup only for an even chunk count (Cin % 64 == 0); with an odd count
+        // every workgroup has ONE tile, which ends with the iteration's first chunk, the second being skipped.
+        const int ring1 = (ring + I) & (RING_ROWS - 1), ring2 = (ring1 + I) & (RING_ROWS - 1);
+        chunk(I0{}, gc, ring, ring1);
+        if (gc + 1 < total_chunks) chunk(I1{}, gc + 1, ring1, ring2);
+        ring = ring2;
+        if (tile_done) {
+            epilogue();
+            zero_acc();
+            cur_orig += grid;
+            if (gc + 2 < total_chunks) { int tn0; decode(cur_orig, cur_b, cur_y0, cur_x0, tn0); }
         }
     }
 #endif
@@ -399,7 +497,19 @@ int launch_halo_s32(const HaloS32Args& a, hipStream_t st)
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_x * a.tiles_y * a.n_tiles), dim3(512), LDS_BYTES, st, a);
+    // one workgroup fills a CU (160 KB of LDS, 8 waves x 256 registers): launch one per CU and let each walk its share of the tiles.
+    // The walk keeps a workgroup on ONE channel tile (its weight descriptor is built once) when the tile stride grid / 8 is a multiple
+    // of n_tiles; otherwise, and for grids smaller than the chip, every tile gets its own workgroup as before.
+    const int nwg = a.B * a.tiles_x * a.tiles_y * a.n_tiles;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
+    }
+    int grid = nwg;
+    const int unit = 8 * a.n_tiles;
+    if (!(a.dbg & 2) && nwg > ncu && ncu >= unit && (a.Cin / 32) % 2 == 0) grid = (ncu / unit) * unit;    // (kernel: a tile ends on an even chunk)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, a);
     return ape::check_launch("ape_conv3x3_halo_s32");
 }
 

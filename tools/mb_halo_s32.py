@@ -19,8 +19,22 @@ for name, b, h, w, cin, cout, dil in shapes:
         _lib.lib().ape_conv3x3_halo_s32_debug(1)
         conv(xs, out=out, out_fmt=E.FMT_S32)
         _lib.lib().ape_conv3x3_halo_s32_debug(0)
+    def oneper():
+        _lib.lib().ape_conv3x3_halo_s32_debug(2)
+        conv(xs, out=out, out_fmt=E.FMT_S32)
+        _lib.lib().ape_conv3x3_halo_s32_debug(0)
+    res32 = E.S32.from_f32(torch.randn(b, h, w, cout, device="cuda"))
+
+    def dbg(bits, **kw):
+        def f():
+            _lib.lib().ape_conv3x3_halo_s32_debug(bits)
+            conv(xs, out=out, out_fmt=E.FMT_S32, **kw)
+            _lib.lib().ape_conv3x3_halo_s32_debug(0)
+        return f
     arms = {"halo (fp32 in)": lambda: conv(x, out=out), "halo_s32 -> f32": lambda: conv(xs, out=out), "halo_s32 -> s32": lambda: conv(xs, out=out, out_fmt=E.FMT_S32),
-            "  -> s32, static priority": noprio}
+            "  -> s32, static priority": noprio, "  -> s32, one wg per tile": oneper,
+            "  -> s32 + s32 residual": lambda: conv(xs, out=out, residual=res32, out_fmt=E.FMT_S32),
+            "  ABLATION no stores": dbg(4), "  ABLATION res, no stores": dbg(4, residual=res32), "  ABLATION res not loaded": dbg(8, residual=res32)}
     for f in arms.values():
         f()
     torch.cuda.synchronize()
