@@ -76,14 +76,13 @@ struct HaloArgs {
     int head_c, head_dsm;
 };
 
+// NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
+// per element: ~1.8 k scalar instructions in a 256-element epilogue); same values bit for bit (1 * v == v, also for -0 and NaN)
 __device__ __forceinline__ float activate_h(float v, int act, float alpha)
 {
-    switch (act) {
-        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
-        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
-        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        default: return v;
-    }
+    if (act == APE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    const float neg = act == APE_ACT_RELU ? 0.f : (act == APE_ACT_PRELU ? alpha : 1.f) * v;
+    return v > 0.f ? v : neg;
 }
 
 template <int NSPLIT, int D, int BNH, bool UPS, bool HEAD>
@@ -431,6 +430,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         static_assert(BNH == 64, "the fused head needs the whole 64-channel pixel in one workgroup");
         float wreg[16], hbias[4];
         ape_seg::seg_head_load_weights(a.head_w, a.head_b, a.head_c, lane, wreg, hbias);
+        const ape::ActFast af = ape::act_fast_make(p.act, p.alpha);
         float4 cb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -444,10 +444,17 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             const int pidx = wm * (32 * TMW) + i * 16 + r16;
             const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
             float4 xv[4];
+            if (p.act == APE_ACT_SIGMOID) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                xv[j] = make_float4(activate_h(acc[i][j][0] + cb[j].x, p.act, p.alpha), activate_h(acc[i][j][1] + cb[j].y, p.act, p.alpha),
-                                    activate_h(acc[i][j][2] + cb[j].z, p.act, p.alpha), activate_h(acc[i][j][3] + cb[j].w, p.act, p.alpha));
+                for (int j = 0; j < 4; ++j)
+                    xv[j] = make_float4(activate_h(acc[i][j][0] + cb[j].x, p.act, p.alpha), activate_h(acc[i][j][1] + cb[j].y, p.act, p.alpha),
+                                        activate_h(acc[i][j][2] + cb[j].z, p.act, p.alpha), activate_h(acc[i][j][3] + cb[j].w, p.act, p.alpha));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xv[j] = make_float4(ape::act_fast(acc[i][j][0] + cb[j].x, af), ape::act_fast(acc[i][j][1] + cb[j].y, af),
+                                        ape::act_fast(acc[i][j][2] + cb[j].z, af), ape::act_fast(acc[i][j][3] + cb[j].w, af));
+            }
             int am;
             float pm;
             ape_seg::seg_head_group(xv, wreg, hbias, a.head_c, lane, a.head_dsm, am, pm);
@@ -464,6 +471,8 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     // -> barrier per tile, which with K = 576 was a large part of a tile)
     const bool vec_ok = (p.ldy % 4 == 0) && (p.yoff % 4 == 0) && (!a.res || (p.ldr % 4 == 0 && p.roff % 4 == 0));
     const int nq = n0 + wn * 64 + kq * 4;               // + 16 j
+    const ape::ActFast af2 = ape::act_fast_make(p.act, p.alpha);
+    const bool sigm = p.act == APE_ACT_SIGMOID;
     const float* bp = a.bias ? a.bias + (p.bias_bstride ? (size_t)b * p.bias_bstride : 0) : nullptr;
     float4 b4[4];
 #pragma unroll
@@ -493,8 +502,9 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             if (vec_ok && nvalid == 4) {
                 if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
                 *reinterpret_cast<float4*>(a.y + m * p.ldy + p.yoff + n) =
-                    make_float4(activate_h(vv[0], p.act, p.alpha), activate_h(vv[1], p.act, p.alpha), activate_h(vv[2], p.act, p.alpha),
-                                activate_h(vv[3], p.act, p.alpha));
+                    sigm ? make_float4(activate_h(vv[0], p.act, p.alpha), activate_h(vv[1], p.act, p.alpha), activate_h(vv[2], p.act, p.alpha),
+                                       activate_h(vv[3], p.act, p.alpha))
+                         : make_float4(ape::act_fast(vv[0], af2), ape::act_fast(vv[1], af2), ape::act_fast(vv[2], af2), ape::act_fast(vv[3], af2));
             } else {
                 for (int k = 0; k < nvalid; ++k) {
                     float t = vv[k];
@@ -586,6 +596,12 @@ extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const
 #undef HALO_DISPATCH
 }
 
+extern "C" int ape_up3_seghead_ws_supported(const ape_conv_params* params, int nsplit);
+extern "C" int ape_up3_seghead_debug_get(void);
+extern "C" int ape_up3_seghead_ws_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params, int nsplit,
+                                       const float* head_w, const float* head_b, int C, uint8_t* label, float* score, int double_softmax,
+                                       void* stream);
+
 /* Same convolution (Cout must be 64, no residual) with the segmentation head fused into its epilogue: see include/ape_hip.h */
 extern "C" int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params,
                                              int nsplit, const float* head_w, const float* head_b, int C, uint8_t* label, float* score,
@@ -599,6 +615,10 @@ extern "C" int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packe
     if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID || (p.ups != 0 && p.ups != 1)) return APE_EINVAL;
     if (p.ups && ((p.H & 1) || (p.W & 1))) return APE_EINVAL;
     if (p.B == 0) return APE_OK;
+    // opt-in (ape_up3_seghead_debug bit 1): the wave-specialised persistent kernel (up3_head_ws.hip), bit-identical labels and scores,
+    // measured at the same speed as the kernel below
+    if ((ape_up3_seghead_debug_get() & 2) && ape_up3_seghead_ws_supported(params, nsplit) && (!bias || ((size_t)bias % 16 == 0 && p.bias_bstride % 4 == 0)))
+        return ape_up3_seghead_ws_bf16(x, w_packed, bias, params, nsplit, head_w, head_b, C, label, score, double_softmax, stream);
     const long K = 9L * p.Cin, Kp = (K + 7) / 8 * 8;
     if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * Kp >= (1L << 31)) return APE_EINVAL;
     HaloArgs a;

@@ -48,14 +48,13 @@ struct HaloS32Args {
                             // persistent walk (results unchanged by either); timing-only ablations: 4 = no epilogue stores, 8 = no residual loads
 };
 
+// NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
+// per element: ~1.8 k scalar instructions in a 256-element epilogue); same values bit for bit (1 * v == v, also for -0 and NaN)
 __device__ __forceinline__ float act_h(float v, int act, float alpha)
 {
-    switch (act) {
-        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
-        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
-        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        default: return v;
-    }
+    if (act == APE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    const float neg = act == APE_ACT_RELU ? 0.f : (act == APE_ACT_PRELU ? alpha : 1.f) * v;
+    return v > 0.f ? v : neg;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -375,8 +374,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             const int n = nq + j * 16;
             b4[j] = (bp && n < a.Cout) ? *reinterpret_cast<const float4*>(bp + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const bool relu = a.act == APE_ACT_RELU;
-        const float slope = a.act == APE_ACT_PRELU ? a.alpha : 1.f;         // APE_ACT_NONE: v <= 0 -> 1 * v
+        const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);        // (common.h: no scalar compare-and-branch cascade per element)
         const bool sigmoid = a.act == APE_ACT_SIGMOID;
         auto store_tile = [&](auto s32_c) __attribute__((always_inline)) {
             constexpr bool OUT_S32 = decltype(s32_c)::value != 0;
@@ -407,10 +405,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
                         for (int e = 0; e < 4; ++e) vv[e] = 1.f / (1.f + __expf(-vv[e]));
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float neg = relu ? 0.f : slope * vv[e];
-                            vv[e] = vv[e] > 0.f ? vv[e] : neg;
-                        }
+                        for (int e = 0; e < 4; ++e) vv[e] = ape::act_fast(vv[e], af);
                     }
                     if (OUT_S32) {
                         const int cy = a.yoff + n;

@@ -38,14 +38,13 @@ struct GemmArgs {
     long plane_stride;
 };
 
+// NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
+// per element: ~1.8 k scalar instructions in a 256-element epilogue); same values bit for bit (1 * v == v, also for -0 and NaN)
 __device__ __forceinline__ float activate(float v, int act, float alpha)
 {
-    switch (act) {
-        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
-        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
-        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        default: return v;
-    }
+    if (act == APE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    const float neg = act == APE_ACT_RELU ? 0.f : (act == APE_ACT_PRELU ? alpha : 1.f) * v;
+    return v > 0.f ? v : neg;
 }
 
 __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, bf16x8& hi, bf16x8& lo)
@@ -279,6 +278,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     // as long as the whole k-loop of a K = 256 layer).
     {
         const int nq = n0 + wn * WTN + fc * 4;          // + 16 j
+        const ape::ActFast af = ape::act_fast_make(p.act, p.alpha);
+        const bool sigm = p.act == APE_ACT_SIGMOID;
         float4 b4[TN];
         if (a.bias && !p.bias_bstride) {
 #pragma unroll
@@ -310,8 +311,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                     if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
                     else if (a.bias) { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
                     if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
-                    const float4 o4 = make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha), activate(vv[2], p.act, p.alpha),
-                                                  activate(vv[3], p.act, p.alpha));
+                    const float4 o4 = sigm ? make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha), activate(vv[2], p.act, p.alpha),
+                                                         activate(vv[3], p.act, p.alpha))
+                                           : make_float4(ape::act_fast(vv[0], af), ape::act_fast(vv[1], af), ape::act_fast(vv[2], af), ape::act_fast(vv[3], af));
                     if (a.out_fmt == APE_FMT_S32) ape::s32_store4(a.y, (long)m, p.ldy / 4, (p.yoff + n) / 4, o4);
                     else *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o4;
                 } else {

@@ -51,14 +51,13 @@ struct GemmS32Args {
                             // 32: no static priority for waves 4-7
 };
 
+// NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
+// per element); same values bit for bit (1 * v == v, also for -0 and NaN)
 __device__ __forceinline__ float act_fn(float v, int act, float alpha)
 {
-    switch (act) {
-        case APE_ACT_RELU: return v > 0.f ? v : 0.f;
-        case APE_ACT_PRELU: return v > 0.f ? v : alpha * v;
-        case APE_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
-        default: return v;
-    }
+    if (act == APE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    const float neg = act == APE_ACT_RELU ? 0.f : (act == APE_ACT_PRELU ? alpha : 1.f) * v;
+    return v > 0.f ? v : neg;
 }
 
 
@@ -306,6 +305,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
 
     // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel 16 i + frow ---------
     const int nq = n0 + wn * (TN * 16) + fc * 4;
+    const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);
+    const bool sigm = a.act == APE_ACT_SIGMOID;
     float4 b4[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
             else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
             if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vv[e] = act_fn(vv[e], a.act, a.alpha);
+            for (int e = 0; e < 4; ++e) vv[e] = sigm ? act_fn(vv[e], a.act, a.alpha) : ape::act_fast(vv[e], af);
             if (a.out_fmt == APE_FMT_S32) {
                 const int cy = a.yoff + n;
                 char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
