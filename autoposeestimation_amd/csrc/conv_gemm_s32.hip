@@ -313,47 +313,67 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
         const int n = nq + j * 16;
         b4[j] = (a.bias && !a.bias_bstride && n < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // The residual tile is requested FOUR pixel rows ahead of its use, as two 8-byte halves per (row, block) for both formats (S32: hi 4 x
+    // bf16 | lo 4 x bf16, 64 B apart; fp32: floats 0,1 | 2,3): 4 x TN loads in flight per round trip instead of TN -- the stores of
+    // row i may alias the loads of row i + 1 for all the compiler knows, so the row-at-a-time form paid eight serialised round trips
+    // per tile (the PSP bottleneck, whose residual is the 1.26 GB prior sum, spent as long in its epilogue as in its k-loop).
+    const bool rs32 = a.res_fmt == APE_FMT_S32;
+    const long rsecond = rs32 ? 64 : 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + frow;
-        if (m >= a.M) continue;
-        const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
-        float4 rr[TN];
+    for (int i0 = 0; i0 < 8; i0 += 4) {
+        uint2 rlo[4][TN], rhi[4][TN];
         if (a.res) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = nq + j * 16;
-                if (n >= a.Cout) continue;
-                if (a.res_fmt == APE_FMT_S32) {
-                    const int cr = a.roff + n;
-                    const char* rp = a.res + (size_t)m * a.ldr * 4 + (cr >> 5) * 128 + (cr & 31) * 2;
-                    const bf16x4 h = *reinterpret_cast<const bf16x4*>(rp), l = *reinterpret_cast<const bf16x4*>(rp + 64);
-                    rr[j] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
-                } else {
-                    rr[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + (size_t)m * a.ldr + a.roff + n);
+            for (int ii = 0; ii < 4; ++ii) {
+                const int m = m0 + wm * 128 + (i0 + ii) * 16 + frow;
+                const size_t mc = m < a.M ? m : a.M - 1;                       // (a clamped, never-used address for rows past M)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = nq + j * 16;
+                    const int cr = a.roff + (n < a.Cout ? n : 0);
+                    const char* rp = a.res + (rs32 ? mc * a.ldr * 4 + (size_t)((cr >> 5) * 128 + (cr & 31) * 2) : (mc * a.ldr + cr) * 4);
+                    rlo[ii][j] = *reinterpret_cast<const uint2*>(rp);
+                    rhi[ii][j] = *reinterpret_cast<const uint2*>(rp + rsecond);
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = nq + j * 16;
-            if (n >= a.Cout) continue;
-            float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
-            else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
-            if (a.res) { vv[0] += rr[j].x; vv[1] += rr[j].y; vv[2] += rr[j].z; vv[3] += rr[j].w; }
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = i0 + ii;
+            const int m = m0 + wm * 128 + i * 16 + frow;
+            if (m >= a.M) continue;
+            const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vv[e] = sigm ? act_fn(vv[e], a.act, a.alpha) : ape::act_fast(vv[e], af);
-            if (a.out_fmt == APE_FMT_S32) {
-                const int cy = a.yoff + n;
-                char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
-                bf16x4 h, l;
+            for (int j = 0; j < TN; ++j) {
+                const int n = nq + j * 16;
+                if (n >= a.Cout) continue;
+                float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
+                else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
+                if (a.res) {
+                    if (rs32) {
+                        const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[ii][j]), l = __builtin_bit_cast(bf16x4, rhi[ii][j]);
+                        // (hi + lo first, then the add: the order of the row-at-a-time form)
+                        vv[0] += (float)h[0] + (float)l[0]; vv[1] += (float)h[1] + (float)l[1];
+                        vv[2] += (float)h[2] + (float)l[2]; vv[3] += (float)h[3] + (float)l[3];
+                    } else {
+                        vv[0] += __uint_as_float(rlo[ii][j].x); vv[1] += __uint_as_float(rlo[ii][j].y);
+                        vv[2] += __uint_as_float(rhi[ii][j].x); vv[3] += __uint_as_float(rhi[ii][j].y);
+                    }
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
-                *reinterpret_cast<bf16x4*>(yp) = h;
-                *reinterpret_cast<bf16x4*>(yp + 64) = l;
-            } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                for (int e = 0; e < 4; ++e) vv[e] = sigm ? act_fn(vv[e], a.act, a.alpha) : ape::act_fast(vv[e], af);
+                if (a.out_fmt == APE_FMT_S32) {
+                    const int cy = a.yoff + n;
+                    char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
+                    *reinterpret_cast<bf16x4*>(yp) = h;
+                    *reinterpret_cast<bf16x4*>(yp + 64) = l;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
             }
         }
     }
