@@ -172,7 +172,9 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
     // (the blend weights and the in-image bit travel from ups_fetch to ups_lerp in registers: a second read of the table entry at
     // the end of the tap returned wrong weights under load -- large grids only, never found why -- the first read does not)
     auto ups_fetch = [&](int j, int ci0, float4 (&r)[4], float (&wgt)[3]) {
-        const int e = tid + NTH * j;
+        int t_op = tid;
+        asm volatile("" : "+v"(t_op));      // opaque: the eleven items' table addresses are formed here, not hoisted in front of the chunk loop and spilled
+        const int e = t_op + NTH * j;
         const int px = e < HP * 8 ? e >> 3 : HP - 1;
         const uint4 ent = ups_tbl[px];
         const unsigned base = ent.x + (unsigned)(ci0 + (e & 7) * 4);
@@ -243,9 +245,11 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         }
     };
     auto store_a = [&](int buf) {
+        int t_op = tid;
+        asm volatile("" : "+v"(t_op));      // (as in ups_fetch: keeps the per-item LDS offsets out of long-lived registers)
 #pragma unroll
         for (int j = 0; j < A_ITEMS; ++j) {
-            const int e = tid + NTH * j;
+            const int e = t_op + NTH * j;
             if (e >= HP * 8) continue;
             const int px = e >> 3, c4 = e & 7;
             const float4 v = (a_okmask >> j) & 1u ? areg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -428,20 +432,24 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
         // 16-pixel row block goes straight into the 64 -> C head + softmax(+softmax) + arg-max: no LDS pass, no barrier, and the
         // 64-channel activation never reaches HBM.
         static_assert(BNH == 64, "the fused head needs the whole 64-channel pixel in one workgroup");
+        // opaque copies of the lane coordinates: the epilogue's address parts are formed here instead of being hoisted in front of the
+        // chunk loop and spilled around it
+        int r16_e = r16, kq_e = kq;
+        asm volatile("" : "+v"(r16_e), "+v"(kq_e));
         float wreg[16], hbias[4];
         ape_seg::seg_head_load_weights(a.head_w, a.head_b, a.head_c, lane, wreg, hbias);
         const ape::ActFast af = ape::act_fast_make(p.act, p.alpha);
         float4 cb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = j * 16 + kq * 4;
+            const int n = j * 16 + kq_e * 4;
             const float* bp = a.bias ? a.bias + (p.bias_bstride ? (size_t)b * p.bias_bstride : 0) : nullptr;
             cb[j] = make_float4(bp && n < p.Cout ? bp[n] : 0.f, bp && n + 1 < p.Cout ? bp[n + 1] : 0.f, bp && n + 2 < p.Cout ? bp[n + 2] : 0.f,
                                 bp && n + 3 < p.Cout ? bp[n + 3] : 0.f);
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int pidx = wm * (32 * TMW) + i * 16 + r16;
+            const int pidx = wm * (32 * TMW) + i * 16 + r16_e;
             const int gy = y0 + (pidx >> 4), gx = x0 + (pidx & 15);
             float4 xv[4];
             if (p.act == APE_ACT_SIGMOID) {
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(halo_threads(BNH), 2) void conv3x3_halo_kernel(cons
             int am;
             float pm;
             ape_seg::seg_head_group(xv, wreg, hbias, a.head_c, lane, a.head_dsm, am, pm);
-            if (kq == 0 && gy < p.Ho && gx < p.Wo) {
+            if (kq_e == 0 && gy < p.Ho && gx < p.Wo) {
                 const size_t m = ((size_t)b * p.Ho + gy) * p.Wo + gx;
                 a.label[m] = (uint8_t)am;
                 a.score[m] = pm;

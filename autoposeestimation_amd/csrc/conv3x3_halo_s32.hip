@@ -23,6 +23,13 @@
 #include <type_traits>
 #include "common.h"
 
+// timing-only ablation switches (results wrong when set): compiled out of the ISA-audit build (tools/isa_audit.py, -DAPE_NO_ABLATIONS)
+#ifdef APE_NO_ABLATIONS
+#define ABL(bit) 0
+#else
+#define ABL(bit) (a.dbg & (bit))
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -74,6 +81,15 @@ __device__ __forceinline__ void ds_read_half(u32x4 (&A)[2][2], u32x4 (&Bf)[4][2]
     APE_DS_READ(A[1][0], a1h, 0); APE_DS_READ(A[1][1], a1l, 0);
     APE_DS_READ(Bf[JOFF][0], bh, JOFF * 2048);           APE_DS_READ(Bf[JOFF][1], bl, JOFF * 2048);
     APE_DS_READ(Bf[JOFF + 1][0], bh, JOFF * 2048 + 2048); APE_DS_READ(Bf[JOFF + 1][1], bl, JOFF * 2048 + 2048);
+}
+
+// keeps asm-read destinations allocated up to this point (a free function: asm operands cannot name variables captured by a generic
+// lambda; device pass only: the host pass cannot check a "v" constraint)
+__device__ __forceinline__ void keep_regs(const u32x4& a, const u32x4& b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"(a), "v"(b));
+#endif
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a literal)
@@ -256,6 +272,15 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
+    // the asm reads' destinations stay allocated until the wait behind them (conv_gemm_s32.hip keep_a / keep_b: where hipcc finds such
+    // outputs dead -- the look-ahead reads of a workgroup's last tap -- it re-uses their registers while the LDS data is on its way)
+    auto keep_half = [&](auto half_c, auto bset_c) {
+        constexpr int half = decltype(half_c)::value, bset = decltype(bset_c)::value;
+        keep_regs(Ah[half][0][0], Ah[half][0][1]);
+        keep_regs(Ah[half][1][0], Ah[half][1][1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep_regs(Bf[bset][j][0], Bf[bset][j][1]);
+    };
 
     // one wave of every SIMD pair at priority 1 for the whole kernel pays in the GEMM kernel (conv_gemm_s32.hip, -1.5 .. -3 %) but not
     // here (+-0 .. +1 % on all six layer shapes, tools/mb_halo_s32.py): off unless the debug bit asks for it
@@ -270,13 +295,15 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_half(I0{}, I0{}, 0, 0, 0);
+    u32x4 dummy[2][2];
     {   // second half of tap 0's weights (its pixel rows 2, 3 are read during the tap's first phase)
-        u32x4 dummy[2][2];
         const unsigned a0 = a_lane[0][0];
         ds_read_half<2>(dummy, Bf[0], a0, a0, a0, a0, b_lane[0], b_lane[1]);
-        asm volatile("" :: "v"(dummy[0][0]), "v"(dummy[0][1]), "v"(dummy[1][0]), "v"(dummy[1][1]));
     }
     phase_end();
+    keep_half(I0{}, I0{});
+    keep_regs(dummy[0][0], dummy[0][1]);
+    keep_regs(dummy[1][0], dummy[1][1]);
 
     // ---- one tap = two phases of 24 MFMAs (pixel rows 0,1 | 2,3 against the four weight blocks of B set P).  While a phase runs, the
     // fragments of the NEXT phase are read: phase 0 fetches this tap's rows 2,3 and weight blocks 0,1 of tap t+1 (into the other B
@@ -310,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         __builtin_amdgcn_sched_barrier(0);
         if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I1{});
         phase_end();
+        keep_half(I1{}, std::integral_constant<int, P ^ 1>{});
         // phase 1
         {
             const int ky = ntap / 3, kx = ntap - ky * 3;
@@ -333,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             issued += 2;
         }
         phase_end();
+        keep_half(I0{}, std::integral_constant<int, P ^ 1>{});
         wait_vmcnt(issued);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -344,13 +373,17 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     // for here: the next tile's taps run while they drain (a tap's closing vmcnt wait covers them, they are older than its pieces).
     // One instance of the store loop per output format; the activation of the common layers is a select, not a switch.
     auto epilogue = [&]() __attribute__((always_inline)) {
-        const int nq = n0 + wn * 64 + fc * 4;
+        // opaque copies of the lane coordinates: the epilogue's 64-bit address parts must be formed HERE -- hoisted in front of the tile loop
+        // (they are loop-invariant) they are spilled around the 250-register tap bodies and reloaded from scratch here
+        int frow_e = frow, fc_e = fc;
+        asm volatile("" : "+v"(frow_e), "+v"(fc_e));
+        const int nq = n0 + wn * 64 + fc_e * 4;
         const float* bp = a.bias ? a.bias + (a.bias_bstride ? (size_t)cur_b * a.bias_bstride : 0) : nullptr;
-        const int gx = cur_x0 + frow;
+        const int gx = cur_x0 + frow_e;
         // 16 residual bytes per (pixel row i, channel block j), fetched as two 8-byte halves for BOTH formats (same instruction stream):
         // S32: hi 4 x bf16 | lo 4 x bf16 (64 B apart); fp32: floats 0,1 | floats 2,3 (8 B apart)
         uint2 rlo[4][4], rhi[4][4];
-        if (a.res && !(a.dbg & 8)) {
+        if (a.res && !(ABL(8))) {
             const bool rs32 = a.res_fmt == APE_FMT_S32;
             const long second = rs32 ? 64 : 8;
 #pragma unroll
@@ -386,9 +419,9 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int n = nq + j * 16;
-                    if (n >= a.Cout || (a.dbg & 4)) continue;
+                    if (n >= a.Cout || (ABL(4))) continue;
                     float vv[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
-                    if (a.res && !(a.dbg & 8)) {
+                    if (a.res && !(ABL(8))) {
                         if (a.res_fmt == APE_FMT_S32) {
                             const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[i][j]), l = __builtin_bit_cast(bf16x4, rhi[i][j]);
 #pragma unroll

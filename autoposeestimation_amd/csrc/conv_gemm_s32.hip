@@ -25,6 +25,14 @@
 #include <type_traits>
 #include "common.h"
 
+// timing-only ablation switches (results wrong when set): compiled out of the ISA-audit build (tools/isa_audit.py, -DAPE_NO_ABLATIONS), whose
+// wait-counter walk should see the product's control flow only
+#ifdef APE_NO_ABLATIONS
+#define ABL(bit) 0
+#else
+#define ABL(bit) (a.dbg & (bit))
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -94,6 +102,15 @@ __device__ __forceinline__ void ds_read_frags(u32x4 (&f)[TNH][2], unsigned hi, u
     }
 }
 #undef APE_DS_READ
+
+// keeps asm-read destinations allocated up to this point (a free function: asm operands cannot name variables captured by a generic
+// lambda; device pass only: the host pass cannot check a "v" constraint)
+__device__ __forceinline__ void keep_regs(const u32x4& a, const u32x4& b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"(a), "v"(b));
+#endif
+}
 
 constexpr int BM = 256;
 constexpr int A_STAGE = BM * 128;        // bytes of the A image of one k-tile
@@ -183,13 +200,13 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     u32x4 A[2][4][2], B[2][TNH][2];
     auto read_a = [&](auto which_c, auto half_c, auto set_c) {        // which: 0 = the current k-tile's ring slot, 1 = the next one's
         constexpr int which = decltype(which_c)::value, half = decltype(half_c)::value, set = decltype(set_c)::value;
-        if (a.dbg & 8) return;
+        if (ABL(8)) return;
         ds_read_frags4<half * 4 * 2048>(A[set], a_addr[which][0], a_addr[which][1]);
     };
     auto read_b = [&](auto stage_c, auto half_c, auto set_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, set = decltype(set_c)::value;
         constexpr int j0 = half ? TN0 : 0, nj = half ? TN - TN0 : TN0;
-        if (a.dbg & 8) return;
+        if (ABL(8)) return;
         ds_read_frags<j0 * 2048, nj, TNH>(B[set], b_addr[stage][0], b_addr[stage][1]);
     };
     f32x4 acc[8][TN];
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
         constexpr int j0 = bhalf ? TN0 : 0, nj = bhalf ? TN - TN0 : TN0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (!(a.dbg & 4)) {
+            if (!ABL(4)) {
 #pragma unroll
                 for (int j = 0; j < nj; ++j) {
                     f32x4& c = acc[ahalf * 4 + i][j0 + j];
@@ -223,6 +240,21 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
             hook(i);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    // The destinations of the asm reads must stay ALLOCATED until the wait that follows them: hipcc regards an asm's outputs as written at
+    // the statement, so where it finds them dead (the look-ahead reads of a workgroup's last k-tile feed no MFMA) it gives them all one
+    // register quad and re-uses that quad for its own values while the LDS data is still on its way (tools/isa_audit.py found a
+    // v_cndmask + v_cmp pair on such a register in the odd-k-tile tail: the returning data could have changed a branch).  An empty asm that
+    // reads the registers behind the phase's wait keeps them live across it (cdna_hip_programming.md 5.7 item 1, form (iii)).
+    auto keep_a = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) keep_regs(A[set][i][0], A[set][i][1]);
+    };
+    auto keep_b = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
+#pragma unroll
+        for (int j = 0; j < TNH; ++j) keep_regs(B[set][j][0], B[set][j][1]);
     };
     auto no_hook = [](int) {};
     using I0 = std::integral_constant<int, 0>;
@@ -254,6 +286,8 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     read_a(I0{}, I0{}, I0{});
     read_b(I0{}, I0{}, I0{});
     phase_end();
+    keep_a(I0{});
+    keep_b(I0{});
     int slot_free = 0;             // byte offset of the A ring slot that holds the current tile (free after its barrier)
 
     // one k-tile; X = kt & 1 = its B stage = the B register set that holds its B0
@@ -266,15 +300,17 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
         __builtin_amdgcn_sched_barrier(0);
         mfma(I0{}, I0{}, I0{}, S{}, no_hook);
         phase_end();
+        keep_b(T{});
         // phase 1: (A0, B1) while A1 of this tile is read
         read_a(I0{}, I1{}, I1{});
         __builtin_amdgcn_sched_barrier(0);
         mfma(I0{}, I0{}, I1{}, T{}, no_hook);
         phase_end();
+        keep_a(I1{});
         // every read of tile kt is back; tile kt+1 must have landed (only A(kt+2)'s four pieces may still be in flight)
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(a.dbg & 2)) __builtin_amdgcn_s_barrier();
-        const bool more_b = kt + 2 < nk && !(a.dbg & 1), more_a = kt + 3 < nk && !(a.dbg & 1);
+        if (!ABL(2)) __builtin_amdgcn_s_barrier();
+        const bool more_b = kt + 2 < nk && !ABL(1), more_a = kt + 3 < nk && !ABL(1);
         const int slot = slot_free;
         slot_free = slot_free + A_STAGE == NA * A_STAGE ? 0 : slot_free + A_STAGE;
         __builtin_amdgcn_sched_barrier(0);
@@ -283,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
         __builtin_amdgcn_sched_barrier(0);
         mfma(I1{}, I1{}, I1{}, T{}, [&](int i) { if (more_b) dma_b_piece(kt + 2, X, i); });
         phase_end();
+        keep_a(I0{});
         // phase 3: (A1, B0) while B0 of the next tile is read into the set B1 just left; A(kt+3) goes out likewise
         read_b(T{}, I0{}, T{});
         __builtin_amdgcn_sched_barrier(0);
@@ -294,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
             a_addr[1][0] = a_lane[0] + (unsigned)nxt; a_addr[1][1] = a_lane[1] + (unsigned)nxt;
         }
         phase_end();
+        keep_b(T{});
     };
     int kt = 0;
 #pragma unroll 1

@@ -26,6 +26,13 @@
 #include "common.h"
 #include "seg_head.h"
 
+// timing-only ablation switches (results wrong when set): compiled out of the ISA-audit build (tools/isa_audit.py, -DAPE_NO_ABLATIONS)
+#ifdef APE_NO_ABLATIONS
+#define ABL(bit) 0
+#else
+#define ABL(bit) (a.dbg & (bit))
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void up3_head_ws_kernel(const Up3Args a)
         store_w(C1{}, 1);
         load_w(C0{}, 0, 2);                               // written in tap 0
         load_w(C1{}, 0, 3);                               // written in tap 1
-        if (!(a.dbg & 4)) {
+        if (!(ABL(4))) {
             static_for(std::make_integer_sequence<int, 6>{}, [&](auto jc) __attribute__((always_inline)) {      // batches 0..2 of (tile 0, chunk 1)
                 constexpr int j = decltype(jc)::value;
                 fetch(j, 32, 0, raw[j / 2][j & 1], rwg[j / 2][j & 1]);
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void up3_head_ws_kernel(const Up3Args a)
 #pragma unroll 1
         for (int k = 0; k < my_tiles; ++k) {
             const bool has_next = k + 1 < my_tiles;
-            const bool halo_on = !(a.dbg & 4);
+            const bool halo_on = !(ABL(4));
             static_for(std::make_integer_sequence<int, 18>{}, [&](auto Tc) __attribute__((always_inline)) {
                 constexpr int T = decltype(Tc)::value;
                 constexpr int c = T / 9, tap = T % 9;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void up3_head_ws_kernel(const Up3Args a)
             // after the last tile the read returns stale bytes nobody uses), pinned in front of the MFMAs
             read_frags(std::integral_constant<int, (T + 1) % 18>{});
             __builtin_amdgcn_sched_barrier(0);
-            if (!(a.dbg & 8))
+            if (!(ABL(8)))
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void up3_head_ws_kernel(const Up3Args a)
         }
         int am[4];
         float pm[4];
-        if (!(a.dbg & 16)) {
+        if (!(ABL(16))) {
             ape_seg::seg_head_groups<4>(xv, wreg, hbias, a.head_c, lane, a.head_dsm, am, pm);     // the four rows' chains interleaved
         } else {
 #pragma unroll

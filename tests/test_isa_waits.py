@@ -1,0 +1,87 @@
+"""Static ISA audit of the kernels whose hazards the compiler cannot see (no GPU needed: hipcc cross-compiles gfx950 with -save-temps,
+tools/isa_audit.py walks the instruction stream).  What is asserted for every named kernel:
+
+  * no inline-asm / compiler `ds_read` result is read or overwritten before an `s_waitcnt lgkmcnt` has retired it, on ANY path of the
+    control-flow graph (path-exact walk).  This found a real one: where hipcc saw the look-ahead fragment reads of a workgroup's last
+    k-tile dead, it gave them all one register quad and re-used the quad for a branch condition while the LDS data was still on its way
+    (conv_gemm_s32.hip, odd-k-tile tail) -- the reads' destinations are now kept allocated up to their wait (`keep_regs`);
+  * between an LDS-DMA (`buffer_load ... lds`) and the next `s_barrier` there is an `s_waitcnt` with a vmcnt field;
+  * no VGPR spill and no scratch (a scratch reload inside a DMA-pipelined loop waits vmcnt(0) and drains the pipeline): found 4..14 spilled
+    registers (hoisted loop-invariant epilogue / halo-item addresses) in halo_s32 and in the up_3 kernel, now formed where they are used;
+  * the kernel stays inside its register budget (<= 256 VGPRs at two waves per SIMD).
+Whether a hand-counted `vmcnt(N)` has the right N depends on run-time trip counts and is what the bit-exact GPU tests cover."""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+# file -> [(substring of the mangled kernel name, human name, LDS-DMA kernel?)]
+KERNELS = {
+    "conv3x3_halo_s32.hip": [("halo_s32_kernelILi1E", "halo_s32_kernel<1>", True), ("halo_s32_kernelILi2E", "halo_s32_kernel<2>", True),
+                             ("halo_s32_kernelILi4E", "halo_s32_kernel<4>", True)],
+    "conv_gemm_s32.hip": [("gemm_s32_kernelILi128E", "gemm_s32_kernel<128>", True), ("gemm_s32_kernelILi192E", "gemm_s32_kernel<192>", True),
+                          ("gemm_s32_kernelILi256E", "gemm_s32_kernel<256>", True)],
+    "conv3x3_halo.hip": [("conv3x3_halo_kernelILi3ELi1ELi64ELb1ELb1E", "conv3x3_halo_kernel<3,1,64,true,true>", False),
+                         ("conv3x3_halo_kernelILi3ELi1ELi64ELb0ELb0E", "conv3x3_halo_kernel<3,1,64,false,false>", False)],
+}
+
+
+@pytest.fixture(scope="module")
+def audit_mod():
+    import isa_audit
+    if not os.path.exists(isa_audit.HIPCC):
+        pytest.skip("hipcc not present")
+    return isa_audit
+
+
+@pytest.mark.parametrize("hip_file", sorted(KERNELS))
+def test_wait_counters_and_spills(audit_mod, hip_file, tmp_path_factory):
+    out_dir = os.path.join(REPO, "autoposeestimation_amd", "csrc", "build", "isa_audit")
+    asm = audit_mod.compile_to_asm(os.path.join(audit_mod.CSRC, hip_file), out_dir)
+    symbols = audit_mod.kernel_symbols(asm)
+    for key, name, has_dma in KERNELS[hip_file]:
+        sym = [s for s in symbols if key in s]
+        assert len(sym) == 1, (name, sym)
+        r = audit_mod.audit(asm, sym[0])
+        assert r["n_mfma"] >= 100 and r["n_dsread"] >= 60, (name, r["n_mfma"], r["n_dsread"])       # the walk saw the real kernel
+        assert (r["n_dma"] > 0) == has_dma, (name, r["n_dma"])
+        assert not r["findings"], "%s:\n  %s" % (name, "\n  ".join(r["findings"]))
+        meta = r["meta"]
+        assert meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0, (name, meta)
+        assert meta["vgpr_count"] <= 256, (name, meta)
+
+
+def test_the_audit_catches_a_missing_wait(audit_mod, tmp_path):
+    """the checker itself: a hand-made instruction stream with a ds_read result used one instruction early, a wait that is one too weak
+    on one of two paths, and a barrier right behind an LDS-DMA"""
+    asm = tmp_path / "toy.s"
+    asm.write_text("""
+toy:
+	ds_read_b128 v[4:7], v1
+	ds_read_b128 v[8:11], v1 offset:16
+	s_waitcnt lgkmcnt(1)
+	v_mfma_f32_16x16x32_bf16 v[20:23], v[4:7], v[4:7], v[20:23]
+	v_add_u32_e32 v8, 1, v2
+	s_waitcnt lgkmcnt(0)
+	ds_read_b128 v[12:15], v1
+	s_cbranch_scc1 .LBB0_2
+	ds_read_b128 v[16:19], v1
+.LBB0_2:
+	s_waitcnt lgkmcnt(1)
+	v_mov_b32_e32 v30, v12
+	buffer_load_dwordx4 v3, s[8:11], s0 offen lds
+	s_barrier
+	s_waitcnt vmcnt(0) lgkmcnt(0)
+	s_endpgm
+.Lfunc_end0:
+""")
+    r = audit_mod.audit(str(asm), "toy")
+    kinds = sorted(f.split(" at line")[0] for f in r["findings"])
+    lines = sorted(int(f.split(" at line ")[1].split(" ")[0]) for f in r["findings"])
+    # v8 overwritten while its ds_read is pending (line 7); lgkmcnt(1) retires the read of v12 only on the path that issued a younger read:
+    # still pending on the branch-taken path (line 14); barrier behind the DMA (line 16)
+    assert kinds == ["barrier behind an un-waited LDS-DMA", "ds_read result used before its wait", "ds_read result used before its wait"], r["findings"]
+    assert lines == [7, 14, 16], r["findings"]

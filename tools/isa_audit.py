@@ -1,0 +1,286 @@
+"""Static audit of the wait counters in a gfx950 kernel's ISA (`hipcc -save-temps` .s): the standing check behind the kernels whose hazards the
+compiler cannot see (inline-asm `ds_read_b128` whose results hipcc believes are ready at once, LDS-DMA `buffer_load ... lds` kept in flight
+across barriers behind hand-counted `s_waitcnt vmcnt(N)`).  Runs on the CPU (hipcc cross-compiles), used by tests/test_isa_waits.py.
+
+Counter model (MI355X_MICROARCH.md "s_waitcnt"): vector-memory operations -- loads, stores, atomics, LDS-DMA -- retire in issue order on
+vmcnt; LDS operations retire in order on lgkmcnt; scalar-memory loads share lgkmcnt and may return out of order (with one pending only
+lgkmcnt(0) proves anything).  `s_waitcnt vmcnt(N)` / `lgkmcnt(N)` returns when at most N operations of that kind are outstanding.
+What is checked, and how: see audit().  Spills come from the kernel's metadata (`.vgpr_spill_count`, `.private_segment_fixed_size`,
+`.sgpr_spill_count`).  The kernels are compiled with -DAPE_NO_ABLATIONS: their timing-only debug switches ("no barrier", "no MFMAs" ...)
+are wrong-result paths that the product never takes.
+"""
+import os
+import re
+import subprocess
+import sys
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "autoposeestimation_amd", "csrc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",          # = csrc/Makefile ...
+         "-DAPE_NO_ABLATIONS"]     # ... without the kernels' timing-only ablation switches (wrong-result debug paths, e.g. "no barrier")
+
+
+def compile_to_asm(hip_file, out_dir):
+    """-> path of the gfx950 .s of `hip_file` (cached under out_dir while it is newer than the source and its headers)"""
+    os.makedirs(out_dir, exist_ok=True)
+    stem = os.path.splitext(os.path.basename(hip_file))[0]
+    asm = os.path.join(out_dir, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    deps = [hip_file] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(REPO, "include", "ape_hip.h")]
+    if os.path.exists(asm) and all(os.path.getmtime(asm) >= os.path.getmtime(d) for d in deps):
+        return asm
+    subprocess.check_call([HIPCC] + FLAGS + ["-save-temps", "-c", hip_file, "-I" + CSRC, "-o", os.path.join(out_dir, stem + ".o")], cwd=out_dir,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return asm
+
+
+def kernel_symbols(asm_path):
+    """{demangled-ish key: mangled symbol} of the kernels defined in the file (from their `.amdhsa_kernel` directives)"""
+    syms = re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", open(asm_path).read(), re.M)
+    return syms
+
+
+def kernel_metadata(asm_path, symbol):
+    text = open(asm_path).read()
+    text = text[text.rfind("amdhsa.kernels:"):]
+    blocks = re.split(r"\n  - (?=\.)", text)            # one YAML list item per kernel
+    blk = next((b for b in blocks if re.search(r"\.name:\s+" + re.escape(symbol) + r"\s", b)), "")
+    out = {}
+    for key in (".vgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size", ".sgpr_count", ".group_segment_fixed_size"):
+        mm = re.search(re.escape(key) + r":\s+(\d+)", blk)
+        out[key[1:]] = int(mm.group(1)) if mm else None
+    return out
+
+
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    regs = set()
+    for m in _VREG.finditer(text):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+class Insn:
+    __slots__ = ("line", "op", "text", "regs", "dest", "kind", "target", "vm_wait", "lgkm_wait")
+
+    def __init__(self, line, text):
+        self.line, self.text = line, text
+        self.op, _, rest = text.partition(" ")
+        self.regs = _vregs(rest)
+        self.dest, self.kind, self.target, self.vm_wait, self.lgkm_wait = set(), None, None, None, None
+        op = self.op
+        first = rest.split(",")[0].strip() if rest else ""
+        if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")):
+            if re.search(r"\blds\b", rest):
+                self.kind = "dma"                      # LDS-DMA: no VGPR destination, counts on vmcnt
+            else:
+                self.kind, self.dest = "vload", _vregs(first)
+        elif op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_atomic", "buffer_atomic", "flat_atomic")):
+            self.kind = "vstore"
+        elif op.startswith("ds_"):
+            if op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append")) or "rtn" in op:
+                self.kind, self.dest = "dsread", _vregs(first)
+            else:
+                self.kind = "dswrite"
+        elif op.startswith(("s_load", "s_buffer_load", "s_memtime", "s_memrealtime", "s_dcache")):
+            self.kind = "smem"
+        elif op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", rest)
+            self.vm_wait = int(m.group(1)) if m else None
+            m = re.search(r"lgkmcnt\((\d+)\)", rest)
+            self.lgkm_wait = int(m.group(1)) if m else None
+            if m is None and self.vm_wait is None and re.fullmatch(r"\s*(0x[0-9a-fA-F]+|\d+)\s*", rest or ""):
+                imm = int(rest.strip(), 0)             # raw immediate (gfx9 layout): vmcnt = [3:0] | [15:14] << 4, lgkmcnt = [11:8]
+                self.vm_wait = (imm & 15) | (((imm >> 14) & 3) << 4)
+                self.lgkm_wait = (imm >> 8) & 15
+                self.vm_wait = None if self.vm_wait == 63 else self.vm_wait
+                self.lgkm_wait = None if self.lgkm_wait == 15 else self.lgkm_wait
+            self.kind = "wait"
+        elif op == "s_barrier":
+            self.kind = "barrier"
+        elif op in ("s_branch",) or op.startswith("s_cbranch"):
+            self.kind = "branch"
+            self.target = rest.strip().split()[-1] if rest else None
+        elif op in ("s_endpgm", "s_setpc_b64", "s_trap"):
+            self.kind = "end"
+
+
+def parse_kernel(asm_path, symbol):
+    lines = open(asm_path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(symbol + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end") or lines[i].strip().startswith(".section"))
+    blocks, labels, cur = [], {}, []
+
+    def close():
+        nonlocal cur
+        if cur:
+            blocks.append(cur)
+        cur = []
+
+    for ln in range(start + 1, end):
+        t = lines[ln].split(";")[0].strip()
+        if not t or t.startswith("."):
+            m = re.match(r"^(\.L\w+):", t)
+            if m:
+                close()
+                labels[m.group(1)] = len(blocks)
+            continue
+        m = re.match(r"^(\.?\w+):$", t)
+        if m:
+            close()
+            labels[m.group(1)] = len(blocks)
+            continue
+        ins = Insn(ln + 1, t)
+        cur.append(ins)
+        if ins.kind in ("branch", "end"):
+            close()
+    close()
+    succ = []
+    for bi, blk in enumerate(blocks):
+        last = blk[-1]
+        s = []
+        if last.kind == "branch":
+            if last.target in labels and labels[last.target] < len(blocks):
+                s.append(labels[last.target])
+            if last.op != "s_branch" and bi + 1 < len(blocks):
+                s.append(bi + 1)
+        elif last.kind != "end" and bi + 1 < len(blocks):
+            s.append(bi + 1)
+        succ.append(s)
+    return blocks, succ
+
+
+def _fixed_point(blocks, succ, init, transfer, join):
+    """forward dataflow to a fixed point: state per block entry; transfer(state, insn) -> state; join(a, b) -> merged (None = unreached)"""
+    ins_state = [None] * len(blocks)
+    ins_state[0] = init
+    work = [0]
+    while work:
+        bi = work.pop()
+        st = ins_state[bi]
+        for ins in blocks[bi]:
+            st = transfer(st, ins)
+        for sj in succ[bi]:
+            merged = st if ins_state[sj] is None else join(ins_state[sj], st)
+            if merged != ins_state[sj]:
+                ins_state[sj] = merged
+                work.append(sj)
+    return ins_state
+
+
+def audit(asm_path, symbol, max_findings=20):
+    """-> dict(findings=[...], vmcnt_literals=[...], n_insns, n_mfma, n_dsread, n_dma, meta={...})
+
+    Three forward dataflow passes over the kernel's control-flow graph (see the module docstring for the counter model):
+      1. LDS side, path-exact: a state is the SET of possible lgkmcnt queues (one per path history).  FINDING "ds_read result used before
+         its wait": an instruction touches a VGPR that a still-queued ds_read has yet to write.  This is the pass that covers the
+         inline-asm fragment reads, whose completion the compiler does not track.
+      2. vector-memory side, register loads: per pending load the MINIMUM number of younger vector-memory operations over all paths
+         (`s_waitcnt vmcnt(N)` proves a load back iff at least N operations were issued after it on every path).  FINDING "load result
+         used before its wait".
+      3. LDS-DMA discipline (structural, text order): between a `buffer_load ... lds` and the next `s_barrier` there is an `s_waitcnt` with a
+         vmcnt field (FINDING "barrier behind an un-waited LDS-DMA" otherwise: that barrier could not make the piece visible to the other
+         waves); `vmcnt_literals` lists the counts the kernel waits with (halo_s32's closing wait is a switch over vmcnt(0..8) on the
+         number of pieces its tap issued: all nine must be there).  Whether a COUNT is the right one depends on run-time trip counts
+         (pieces per tap, whether a further k-tile follows) and is what the bit-exact GPU tests cover, not this walk.
+    Pass 2 merges paths pessimistically (a load that is followed by fewer operations on ONE path is treated as if on all), so its findings
+    are candidates to look at, reported under "candidates", not asserted."""
+    blocks, succ = parse_kernel(asm_path, symbol)
+    dest_of = {ins.line: frozenset(ins.dest) for blk in blocks for ins in blk}
+    findings, candidates, seen = [], [], set()
+
+    def note(kind, ins, detail):
+        if (kind, ins.line) not in seen:
+            seen.add((kind, ins.line))
+            dst = candidates if kind == "load result used before its wait" else findings
+            if len(dst) < max_findings:
+                dst.append("%s at line %d `%s`: %s" % (kind, ins.line, ins.text[:80], detail))
+
+    # ---- pass 1: lgkmcnt, path-exact sets of queues; queue entry = (line, kind) -------------------------------------------------
+    def t1(states, ins):
+        out = set()
+        for lg in states:
+            if ins.kind == "wait":
+                if ins.lgkm_wait is not None:
+                    if ins.lgkm_wait == 0:
+                        lg = ()
+                    elif not any(k == "smem" for _, k in lg):
+                        lg = lg[len(lg) - ins.lgkm_wait:] if ins.lgkm_wait < len(lg) else lg
+                out.add(lg)
+                continue
+            if ins.regs:
+                busy = [l for l, k in lg if k == "dsread" and l != ins.line and dest_of[l] & ins.regs]
+                if busy:
+                    note("ds_read result used before its wait", ins, "VGPRs of the ds_read(s) at line(s) %s" % busy[:4])
+            if ins.kind in ("dsread", "dswrite", "smem"):
+                lg = lg + ((ins.line, ins.kind),)
+                if len(lg) > 64:
+                    lg = lg[-64:]
+            out.add(lg)
+        if len(out) > 64:       # far beyond anything these kernels produce; keep the longest queues (the most pessimistic)
+            out = set(sorted(out, key=len)[-64:])
+        return frozenset(out)
+
+    _fixed_point(blocks, succ, frozenset({()}), t1, lambda a, b: a | b)
+
+    # ---- pass 2: vmcnt, pending register loads with the minimum number of younger operations ---------------------------------------
+    def t2(st, ins):
+        st = dict(st)
+        if ins.kind == "wait":
+            if ins.vm_wait is not None:
+                st = {l: y for l, y in st.items() if y < ins.vm_wait}
+            return tuple(sorted(st.items()))
+        if ins.regs:
+            busy = [l for l in st if l != ins.line and dest_of[l] & ins.regs]
+            if busy:
+                note("load result used before its wait", ins, "VGPRs of the load(s) at line(s) %s" % busy[:4])
+        if ins.kind in ("vload", "vstore", "dma"):
+            st = {l: y + 1 for l, y in st.items()}
+            if ins.kind == "vload":
+                st[ins.line] = 0
+        return tuple(sorted(st.items()))
+
+    def j2(a, b):
+        da, db = dict(a), dict(b)
+        return tuple(sorted({l: min(da.get(l, 1 << 30), db.get(l, 1 << 30)) for l in set(da) | set(db)}.items()))
+
+    _fixed_point(blocks, succ, (), t2, j2)
+
+    # ---- pass 3: LDS-DMA discipline, in TEXT order (the closing wait of a halo_s32 tap is a switch over vmcnt(0..8): the structurizer lowers it to
+    # predicated "Flow" blocks through which a path-insensitive walk finds routes that skip every case) -----------------------------------------
+    flat = [ins for blk in blocks for ins in blk]
+    dma_since_wait = 0
+    for ins in flat:
+        if ins.kind == "wait" and ins.vm_wait is not None:
+            dma_since_wait = 0
+        elif ins.kind == "dma":
+            dma_since_wait += 1
+        elif ins.kind == "barrier" and dma_since_wait:
+            note("barrier behind an un-waited LDS-DMA", ins, "%d LDS-DMA instruction(s) and no s_waitcnt vmcnt between them and this barrier" % dma_since_wait)
+    vm_literals = sorted({ins.vm_wait for ins in flat if ins.kind == "wait" and ins.vm_wait is not None})
+    kinds = [ins.kind for blk in blocks for ins in blk]
+    return {"findings": findings, "candidates": candidates, "vmcnt_literals": vm_literals, "n_insns": len(kinds), "n_dsread": kinds.count("dsread"),
+            "n_dma": kinds.count("dma"), "n_mfma": sum(1 for blk in blocks for ins in blk if ins.op.startswith("v_mfma")),
+            "meta": kernel_metadata(asm_path, symbol)}
+
+
+if __name__ == "__main__":
+    src = sys.argv[1]
+    pats = sys.argv[2:]
+    asm = src if src.endswith(".s") else compile_to_asm(os.path.join(CSRC, src) if not os.path.exists(src) else src, "/tmp/ape_isa_audit")
+    for sym in kernel_symbols(asm):
+        if pats and not any(p in sym for p in pats):
+            continue
+        r = audit(asm, sym)
+        print(sym)
+        print("   %d instructions, %d MFMA, %d ds_read, %d LDS-DMA; vmcnt literals %s; %s" %
+              (r["n_insns"], r["n_mfma"], r["n_dsread"], r["n_dma"], r["vmcnt_literals"], r["meta"]))
+        for f in r["findings"]:
+            print("   FINDING:", f)
+        for f in r["candidates"][:5]:
+            print("   candidate (pass 2, pessimistic merge):", f)
