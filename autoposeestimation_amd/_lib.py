@@ -101,6 +101,18 @@ SIGNATURES = {
     "ape_icp_run_f64": [_I, _P, _P, _P, _P, _I, _D, _P, _I, _P, _P, _D, _D, _D, _I, _I, _I, _P, _P, _P, _P, _P, _c.c_size_t, _P],
     "ape_mahalanobis_f64": [_P, _I, _P, _P, _P],
     "ape_select_points_f64": [_P, _P, _I, _P, _P, _P, _P, _c.c_size_t, _P],
+    # batched forms (blockIdx.y = cloud; per-cloud arguments as host arrays of pointers / sizes)
+    "ape_pc_batch_workspace_bytes": [_I, _c.c_long],
+    "ape_surface_points_batch_f64": [_I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "ape_voxel_down_sample_batch_f64": [_I, _P, _P, _D, _P, _P, _P, _c.c_size_t, _P],
+    "ape_grid_build_batch_f64": [_I, _P, _P, _D, _P, _P, _P, _P, _P, _c.c_size_t, _P],
+    "ape_grid_query_batch_f64": [_I, _I, _P, _P, _P, _P, _P, _D, _P, _P, _D, _I, _P, _P, _P, _P],
+    "ape_select_points_batch_f64": [_I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "ape_moments_batch_f64": [_I, _P, _P, _P, _P, _c.c_size_t, _P],
+    "ape_mahalanobis_batch_f64": [_I, _P, _P, _P, _P, _P],
+    "ape_transform_points_batch_f64": [_I, _P, _P, _P, _P, _P],
+    "ape_concat_points_batch_f64": [_I, _P, _P, _P, _P, _P, _P],
+    "ape_icp_run_batch_f64": [_I, _I, _P, _P, _P, _P, _P, _D, _P, _P, _P, _P, _D, _D, _D, _I, _I, _I, _P, _P, _P, _P, _P, _c.c_size_t, _P],
 }
 
 
@@ -113,7 +125,7 @@ class ConvParams(_c.Structure):
 
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 _RESTYPES = {"ape_last_error": _c.c_char_p, "ape_adaptive_avgpool_multi_workspace_bytes": _c.c_size_t, "ape_seg_components_workspace_bytes": _c.c_size_t,
-             "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t,
+             "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t, "ape_pc_batch_workspace_bytes": _c.c_size_t,
              "ape_conv2d_wgrad_workspace_bytes": _c.c_size_t}
 
 _lib = None

@@ -25,17 +25,21 @@ inline int grid_for(long work, int cap = 4096) { long g = (work + kT - 1) / kT; 
 struct Mat4 { double m[16]; };
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void surface_flags_kernel(const uint8_t* __restrict__ label, const uint16_t* __restrict__ depth, uint8_t* __restrict__ flag, int n)
+__device__ __forceinline__ void surface_flags_kernel_body(const uint8_t* __restrict__ label, const uint16_t* __restrict__ depth, uint8_t* __restrict__ flag, int n, const int bx, const int gx)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
         flag[i] = (label[i] != 0 && depth[i] != 0) ? 1 : 0;
 }
 
-__global__ void surface_points_kernel(const int* __restrict__ pix, const int* __restrict__ n_sel, const uint16_t* __restrict__ depth,
-                                      int W, double fx, double fy, double ppx, double ppy, Mat4 T, double* __restrict__ out)
+__global__ void surface_flags_kernel(const uint8_t* __restrict__ label, const uint16_t* __restrict__ depth, uint8_t* __restrict__ flag, int n)
+{
+    surface_flags_kernel_body(label, depth, flag, n, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void surface_points_kernel_body(const int* __restrict__ pix, const int* __restrict__ n_sel, const uint16_t* __restrict__ depth, int W, double fx, double fy, double ppx, double ppy, Mat4 T, double* __restrict__ out, const int bx, const int gx)
 {
     const int n = *n_sel;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x) {
         const int p = pix[i];
         const int py = p / W, px = p - py * W;
         const double p2 = (double)depth[p];
@@ -46,9 +50,15 @@ __global__ void surface_points_kernel(const int* __restrict__ pix, const int* __
     }
 }
 
-__global__ void transform_kernel(double* __restrict__ pts, int n, Mat4 T, double* __restrict__ normals)
+__global__ void surface_points_kernel(const int* __restrict__ pix, const int* __restrict__ n_sel, const uint16_t* __restrict__ depth,
+                                      int W, double fx, double fy, double ppx, double ppy, Mat4 T, double* __restrict__ out)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    surface_points_kernel_body(pix, n_sel, depth, W, fx, fy, ppx, ppy, T, out, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void transform_kernel_body(double* __restrict__ pts, int n, Mat4 T, double* __restrict__ normals, const int bx, const int gx)
+{
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x) {
         const double x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
         for (int r = 0; r < 3; ++r) pts[i * 3 + r] = ((T.m[r * 4] * x + T.m[r * 4 + 1] * y) + T.m[r * 4 + 2] * z) + T.m[r * 4 + 3];
         if (normals) {
@@ -58,13 +68,18 @@ __global__ void transform_kernel(double* __restrict__ pts, int n, Mat4 T, double
     }
 }
 
+__global__ void transform_kernel(double* __restrict__ pts, int n, Mat4 T, double* __restrict__ normals)
+{
+    transform_kernel_body(pts, n, T, normals, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fixed-order min/max bound: stage 1 per block into part[g][6], stage 2 single block
-__global__ void bounds_stage1(const double* __restrict__ pts, int n, double* __restrict__ part)
+__device__ __forceinline__ void bounds_stage1_body(const double* __restrict__ pts, int n, double* __restrict__ part, const int bx, const int gx)
 {
     __shared__ double s[6][kT];
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
         for (int d = 0; d < 3; ++d) { const double v = pts[(size_t)i * 3 + d]; lo[d] = fmin(lo[d], v); hi[d] = fmax(hi[d], v); }
     for (int d = 0; d < 3; ++d) { s[d][threadIdx.x] = lo[d]; s[3 + d][threadIdx.x] = hi[d]; }
     __syncthreads();
@@ -76,16 +91,26 @@ __global__ void bounds_stage1(const double* __restrict__ pts, int n, double* __r
             }
         __syncthreads();
     }
-    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+    if (threadIdx.x < 6) part[bx * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ void bounds_stage2(const double* __restrict__ part, int g, double* __restrict__ out6)
+__global__ void bounds_stage1(const double* __restrict__ pts, int n, double* __restrict__ part)
+{
+    bounds_stage1_body(pts, n, part, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void bounds_stage2_body(const double* __restrict__ part, int g, double* __restrict__ out6, const int bx, const int gx)
 {
     if (threadIdx.x < 6) {
         double v = part[threadIdx.x];
         for (int b = 1; b < g; ++b) v = threadIdx.x < 3 ? fmin(v, part[b * 6 + threadIdx.x]) : fmax(v, part[b * 6 + threadIdx.x]);
         out6[threadIdx.x] = v;
     }
+}
+
+__global__ void bounds_stage2(const double* __restrict__ part, int g, double* __restrict__ out6)
+{
+    bounds_stage2_body(part, g, out6, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ u64 pack_key(long cx, long cy, long cz) { return ((u64)cx << 42) | ((u64)cy << 21) | (u64)cz; }
@@ -99,12 +124,11 @@ __device__ __forceinline__ void cell_of(const double* p, const double* o, double
     }
 }
 
-__global__ void keys_kernel(const double* __restrict__ pts, int n, const double* __restrict__ bounds6, double h, double shift,
-                            u64* __restrict__ keys, unsigned* __restrict__ idx, double* __restrict__ origin_out)
+__device__ __forceinline__ void keys_kernel_body(const double* __restrict__ pts, int n, const double* __restrict__ bounds6, double h, double shift, u64* __restrict__ keys, unsigned* __restrict__ idx, double* __restrict__ origin_out, const int bx, const int gx)
 {
     double o[3] = {bounds6[0] - shift, bounds6[1] - shift, bounds6[2] - shift};
-    if (origin_out && blockIdx.x == 0 && threadIdx.x < 3) origin_out[threadIdx.x] = o[threadIdx.x];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (origin_out && bx == 0 && threadIdx.x < 3) origin_out[threadIdx.x] = o[threadIdx.x];
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x) {
         long c[3];
         // open3d: floor((p - voxel_min_bound) / voxel_size) -- a division, kept as one for identical cell borders
         for (int d = 0; d < 3; ++d) {
@@ -116,18 +140,27 @@ __global__ void keys_kernel(const double* __restrict__ pts, int n, const double*
     }
 }
 
-__global__ void heads_kernel(const u64* __restrict__ keys, int n, int* __restrict__ head)
+__global__ void keys_kernel(const double* __restrict__ pts, int n, const double* __restrict__ bounds6, double h, double shift,
+                            u64* __restrict__ keys, unsigned* __restrict__ idx, double* __restrict__ origin_out)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    keys_kernel_body(pts, n, bounds6, h, shift, keys, idx, origin_out, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void heads_kernel_body(const u64* __restrict__ keys, int n, int* __restrict__ head, const int bx, const int gx)
+{
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
         head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
-// seg[i] = exclusive-scan(head)[i] + head[i] - 1 = segment id; one thread per segment start averages its run in order
-__global__ void voxel_mean_kernel(const double* __restrict__ pts, const u64* __restrict__ keys, const unsigned* __restrict__ order,
-                                  const int* __restrict__ head, const int* __restrict__ scan, int n, double* __restrict__ out,
-                                  int* __restrict__ n_out)
+__global__ void heads_kernel(const u64* __restrict__ keys, int n, int* __restrict__ head)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    heads_kernel_body(keys, n, head, blockIdx.x, gridDim.x);
+}
+
+// seg[i] = exclusive-scan(head)[i] + head[i] - 1 = segment id; one thread per segment start averages its run in order
+__device__ __forceinline__ void voxel_mean_kernel_body(const double* __restrict__ pts, const u64* __restrict__ keys, const unsigned* __restrict__ order, const int* __restrict__ head, const int* __restrict__ scan, int n, double* __restrict__ out, int* __restrict__ n_out, const int bx, const int gx)
+{
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x) {
         if (!head[i]) continue;
         double s[3] = {0, 0, 0};
         int c = 0;
@@ -136,13 +169,25 @@ __global__ void voxel_mean_kernel(const double* __restrict__ pts, const u64* __r
         const int seg = scan[i];
         for (int d = 0; d < 3; ++d) out[(size_t)seg * 3 + d] = s[d] / (double)c;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = scan[n - 1] + head[n - 1];
+    if (bx == 0 && threadIdx.x == 0) *n_out = scan[n - 1] + head[n - 1];
+}
+
+__global__ void voxel_mean_kernel(const double* __restrict__ pts, const u64* __restrict__ keys, const unsigned* __restrict__ order,
+                                  const int* __restrict__ head, const int* __restrict__ scan, int n, double* __restrict__ out,
+                                  int* __restrict__ n_out)
+{
+    voxel_mean_kernel_body(pts, keys, order, head, scan, n, out, n_out, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void gather_sorted_kernel_body(const double* __restrict__ pts, const unsigned* __restrict__ order, int n, double* __restrict__ out, const int bx, const int gx)
+{
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
+        for (int d = 0; d < 3; ++d) out[(size_t)i * 3 + d] = pts[(size_t)order[i] * 3 + d];
 }
 
 __global__ void gather_sorted_kernel(const double* __restrict__ pts, const unsigned* __restrict__ order, int n, double* __restrict__ out)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        for (int d = 0; d < 3; ++d) out[(size_t)i * 3 + d] = pts[(size_t)order[i] * 3 + d];
+    gather_sorted_kernel_body(pts, order, n, out, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -182,22 +227,26 @@ __device__ __forceinline__ void for_my_cell(const Grid& g, const double* q, int 
     }
 }
 
-__global__ __launch_bounds__(kT) void radius_count_group_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ count)
+__device__ __forceinline__ void radius_count_group_kernel_body(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ count, const int bx, const int gx)
 {
     const int lane = threadIdx.x % kG;
-    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    const int i = (bx * kT + threadIdx.x) / kG;
     int c = 0;
     if (i < nq) for_my_cell(g, q + (size_t)i * 3, lane, [&](int, double d2) { c += d2 < r2 ? 1 : 0; });
     for (int m = kG / 2; m >= 1; m >>= 1) c += __shfl_xor(c, m, kG);
     if (i < nq && lane == 0) count[i] = c;
 }
 
-__global__ __launch_bounds__(kT) void nn1_group_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx,
-                                                       double* __restrict__ dist2, const double* __restrict__ skip)
+__global__ __launch_bounds__(kT) void radius_count_group_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ count)
+{
+    radius_count_group_kernel_body(g, q, nq, r2, count, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void nn1_group_kernel_body(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx, double* __restrict__ dist2, const double* __restrict__ skip, const int bx, const int gx)
 {
     if (skip && skip[0] != 0.0) return;
     const int lane = threadIdx.x % kG;
-    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    const int i = (bx * kT + threadIdx.x) / kG;
     double best = r2;
     unsigned bi = 0xffffffffu;
     if (i < nq)
@@ -214,6 +263,12 @@ __global__ __launch_bounds__(kT) void nn1_group_kernel(Grid g, const double* __r
         idx[i] = bi == 0xffffffffu ? -1 : (int)bi;
         dist2[i] = bi == 0xffffffffu ? 0.0 : best;
     }
+}
+
+__global__ __launch_bounds__(kT) void nn1_group_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int* __restrict__ idx,
+                                                       double* __restrict__ dist2, const double* __restrict__ skip)
+{
+    nn1_group_kernel_body(g, q, nq, r2, idx, dist2, skip, blockIdx.x, gridDim.x);
 }
 
 // `skip` (optional, in the kernels of the ICP loop): a device word that, once non-zero, turns the launch into a no-op -- the loop runs
@@ -270,14 +325,14 @@ __device__ void normal_from_selection(const Grid& g, const int* bj, int cnt, dou
 // part on the selection in that order.  More than kNrmCand candidates: the rounds re-walk each lane's cell instead of the list.
 constexpr int kNrmCand = 224;
 
-__global__ __launch_bounds__(kT) void normals_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int max_nn, double* __restrict__ normals)
+__device__ __forceinline__ void normals_kernel_body(Grid g, const double* __restrict__ q, int nq, double r2, int max_nn, double* __restrict__ normals, const int bx, const int gx)
 {
     __shared__ double cand_d[kT / kG][kNrmCand];
     __shared__ int cand_j[kT / kG][kNrmCand];
     __shared__ int sel[kT / kG][kMaxNN];
     __shared__ int ncand[kT / kG];
     const int lane = threadIdx.x % kG, grp = threadIdx.x / kG;
-    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    const int i = (bx * kT + threadIdx.x) / kG;
     if (lane == 0) ncand[grp] = 0;
     __syncthreads();
     double qq[3] = {0, 0, 0};
@@ -317,6 +372,11 @@ __global__ __launch_bounds__(kT) void normals_kernel(Grid g, const double* __res
         normal_from_selection(g, sel[grp], cnt, nrm);
         for (int d = 0; d < 3; ++d) normals[(size_t)i * 3 + d] = nrm[d];
     }
+}
+
+__global__ __launch_bounds__(kT) void normals_kernel(Grid g, const double* __restrict__ q, int nq, double r2, int max_nn, double* __restrict__ normals)
+{
+    normals_kernel_body(g, q, nq, r2, max_nn, normals, blockIdx.x, gridDim.x);
 }
 
 // brute-force k-NN (self included, like KDTree SearchKNN on the cloud itself): mean of the k smallest distances
@@ -374,12 +434,12 @@ __device__ __forceinline__ void knn_round_reduce(double& bd, int& bp)
     }
 }
 
-__global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double* __restrict__ mean)
+__device__ __forceinline__ void knn_mean_grid_kernel_body(Grid g, int k, double* __restrict__ mean, const int bx, const int gx)
 {
     __shared__ double cand[kT / kG][kKnnCand];
     __shared__ int ncand[kT / kG];
     const int lane = threadIdx.x % kG, grp = threadIdx.x / kG;
-    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    const int i = (bx * kT + threadIdx.x) / kG;
     if (i >= g.n) return;                                    // whole groups leave together; the LDS traffic below is per group (one wave
                                                              // holds two groups: same-wave program order, no block barrier needed)
     const double q[3] = {g.sorted[(size_t)i * 3], g.sorted[(size_t)i * 3 + 1], g.sorted[(size_t)i * 3 + 2]};
@@ -454,15 +514,20 @@ __global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double
     if (lane == 0) mean[g.order[i]] = sum / (double)k;
 }
 
+__global__ __launch_bounds__(kT) void knn_mean_grid_kernel(Grid g, int k, double* __restrict__ mean)
+{
+    knn_mean_grid_kernel_body(g, k, mean, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // generic fixed-order reduction of NV doubles per element: stage 1 -> part[blocks][NV], stage 2 -> out[NV]
 template <int NV, class F>
-__device__ void reduce_stage1(int n, F value, double* part)
+__device__ void reduce_stage1(int n, F value, double* part, const int bx, const int gx)
 {
     __shared__ double s[kT];
     double acc[NV];
     for (int v = 0; v < NV; ++v) acc[v] = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x) {
         double e[NV];
         if (value(i, e)) for (int v = 0; v < NV; ++v) acc[v] += e[v];
     }
@@ -471,21 +536,24 @@ __device__ void reduce_stage1(int n, F value, double* part)
         s[threadIdx.x] = acc[v];
         __syncthreads();
         for (int off = kT / 2; off > 0; off >>= 1) { if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off]; __syncthreads(); }
-        if (threadIdx.x == 0) part[blockIdx.x * NV + v] = s[0];
+        if (threadIdx.x == 0) part[bx * NV + v] = s[0];
     }
 }
 
-__global__ void reduce_stage2(const double* __restrict__ part, int g, int nv, double* __restrict__ out, const double* __restrict__ skip = nullptr)
+__device__ __forceinline__ void reduce_stage2_body(const double* __restrict__ part, int g, int nv, double* __restrict__ out, const double* __restrict__ skip, const int bx, const int gx)
 {
     if (skip && skip[0] != 0.0) return;
     const int v = threadIdx.x;
     if (v < nv) { double s = 0; for (int b = 0; b < g; ++b) s += part[b * nv + v]; out[v] = s; }
 }
 
+__global__ void reduce_stage2(const double* __restrict__ part, int g, int nv, double* __restrict__ out, const double* __restrict__ skip = nullptr)
+{
+    reduce_stage2_body(part, g, nv, out, skip, blockIdx.x, gridDim.x);
+}
+
 // out: [0] count, [1] sum d^2, [2..4] sum s, [5..7] sum t, [8..16] sum s_a t_b (row a, col b)
-__global__ __launch_bounds__(kT) void p2p_sums_kernel(const double* __restrict__ src, const double* __restrict__ tgt, const int* __restrict__ corr,
-                                                      const double* __restrict__ d2, int n, double* __restrict__ part,
-                                                      const double* __restrict__ skip = nullptr)
+__device__ __forceinline__ void p2p_sums_kernel_body(const double* __restrict__ src, const double* __restrict__ tgt, const int* __restrict__ corr, const double* __restrict__ d2, int n, double* __restrict__ part, const double* __restrict__ skip, const int bx, const int gx)
 {
     if (skip && skip[0] != 0.0) return;
     reduce_stage1<17>(n, [&](int i, double* e) {
@@ -496,14 +564,18 @@ __global__ __launch_bounds__(kT) void p2p_sums_kernel(const double* __restrict__
         e[0] = 1.0; e[1] = d2[i];
         for (int a = 0; a < 3; ++a) { e[2 + a] = s[a]; e[5 + a] = t[a]; for (int b = 0; b < 3; ++b) e[8 + a * 3 + b] = s[a] * t[b]; }
         return true;
-    }, part);
+    }, part, bx, gx);
+}
+
+__global__ __launch_bounds__(kT) void p2p_sums_kernel(const double* __restrict__ src, const double* __restrict__ tgt, const int* __restrict__ corr,
+                                                      const double* __restrict__ d2, int n, double* __restrict__ part,
+                                                      const double* __restrict__ skip = nullptr)
+{
+    p2p_sums_kernel_body(src, tgt, corr, d2, n, part, skip, blockIdx.x, gridDim.x);
 }
 
 // out: [0] count, [1] sum d^2, [2..22] upper triangle of J^T J (row major), [23..28] J^T r
-__global__ __launch_bounds__(kT) void p2plane_sums_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
-                                                          const double* __restrict__ tn, const int* __restrict__ corr,
-                                                          const double* __restrict__ d2, int n, double* __restrict__ part,
-                                                          const double* __restrict__ skip = nullptr)
+__device__ __forceinline__ void p2plane_sums_kernel_body(const double* __restrict__ src, const double* __restrict__ tgt, const double* __restrict__ tn, const int* __restrict__ corr, const double* __restrict__ d2, int n, double* __restrict__ part, const double* __restrict__ skip, const int bx, const int gx)
 {
     if (skip && skip[0] != 0.0) return;
     reduce_stage1<29>(n, [&](int i, double* e) {
@@ -519,25 +591,38 @@ __global__ __launch_bounds__(kT) void p2plane_sums_kernel(const double* __restri
         for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) e[k++] = J[a] * J[b];
         for (int a = 0; a < 6; ++a) e[23 + a] = J[a] * r;
         return true;
-    }, part);
+    }, part, bx, gx);
+}
+
+__global__ __launch_bounds__(kT) void p2plane_sums_kernel(const double* __restrict__ src, const double* __restrict__ tgt,
+                                                          const double* __restrict__ tn, const int* __restrict__ corr,
+                                                          const double* __restrict__ d2, int n, double* __restrict__ part,
+                                                          const double* __restrict__ skip = nullptr)
+{
+    p2plane_sums_kernel_body(src, tgt, tn, corr, d2, n, part, skip, blockIdx.x, gridDim.x);
 }
 
 // out: [0..2] sum p, [3..8] sum p_a p_b upper triangle
-__global__ __launch_bounds__(kT) void moments_kernel(const double* __restrict__ pts, int n, double* __restrict__ part)
+__device__ __forceinline__ void moments_kernel_body(const double* __restrict__ pts, int n, double* __restrict__ part, const int bx, const int gx)
 {
     reduce_stage1<9>(n, [&](int i, double* e) {
         const double* p = pts + (size_t)i * 3;
         e[0] = p[0]; e[1] = p[1]; e[2] = p[2];
         e[3] = p[0] * p[0]; e[4] = p[0] * p[1]; e[5] = p[0] * p[2]; e[6] = p[1] * p[1]; e[7] = p[1] * p[2]; e[8] = p[2] * p[2];
         return true;
-    }, part);
+    }, part, bx, gx);
+}
+
+__global__ __launch_bounds__(kT) void moments_kernel(const double* __restrict__ pts, int n, double* __restrict__ part)
+{
+    moments_kernel_body(pts, n, part, blockIdx.x, gridDim.x);
 }
 
 struct Vec12 { double v[12]; };
 // sqrt((p - mu)^T Cinv (p - mu));  mc = (mu[3], Cinv[9])
-__global__ void mahalanobis_kernel(const double* __restrict__ pts, int n, Vec12 mc, double* __restrict__ out)
+__device__ __forceinline__ void mahalanobis_kernel_body(const double* __restrict__ pts, int n, Vec12 mc, double* __restrict__ out, const int bx, const int gx)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x) {
         double e[3];
         for (int d = 0; d < 3; ++d) e[d] = pts[(size_t)i * 3 + d] - mc.v[d];
         double s = 0;
@@ -546,11 +631,21 @@ __global__ void mahalanobis_kernel(const double* __restrict__ pts, int n, Vec12 
     }
 }
 
-__global__ void select_rows_kernel(const double* __restrict__ pts, const int* __restrict__ sel, const int* __restrict__ n_sel, double* __restrict__ out)
+__global__ void mahalanobis_kernel(const double* __restrict__ pts, int n, Vec12 mc, double* __restrict__ out)
+{
+    mahalanobis_kernel_body(pts, n, mc, out, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void select_rows_kernel_body(const double* __restrict__ pts, const int* __restrict__ sel, const int* __restrict__ n_sel, double* __restrict__ out, const int bx, const int gx)
 {
     const int n = *n_sel;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
         for (int d = 0; d < 3; ++d) out[(size_t)i * 3 + d] = pts[(size_t)sel[i] * 3 + d];
+}
+
+__global__ void select_rows_kernel(const double* __restrict__ pts, const int* __restrict__ sel, const int* __restrict__ n_sel, double* __restrict__ out)
+{
+    select_rows_kernel_body(pts, sel, n_sel, out, blockIdx.x, gridDim.x);
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -892,8 +987,7 @@ __device__ void icp_step(int kind, const double* s, double* __restrict__ st, int
 
 // last stage of the sums reduction (one thread per reduced value, fixed order over the workgroup partials) with the ICP step on its
 // tail: thread 0 runs icp_step on the totals it finds in LDS -- one launch instead of two per iteration
-__global__ __launch_bounds__(64) void icp_reduce_step_kernel(const double* __restrict__ part, int g, int nv, double* __restrict__ sums, int kind,
-                                                             double* __restrict__ st, int ns, double rel_fitness, double rel_rmse, int max_iteration)
+__device__ __forceinline__ void icp_reduce_step_kernel_body(const double* __restrict__ part, int g, int nv, double* __restrict__ sums, int kind, double* __restrict__ st, int ns, double rel_fitness, double rel_rmse, int max_iteration, const int bx, const int gx)
 {
     if (st[0] != 0.0) return;
     __shared__ double tot[32];
@@ -903,14 +997,19 @@ __global__ __launch_bounds__(64) void icp_reduce_step_kernel(const double* __res
     if (v == 0) icp_step(kind, tot, st, ns, rel_fitness, rel_rmse, max_iteration);
 }
 
+__global__ __launch_bounds__(64) void icp_reduce_step_kernel(const double* __restrict__ part, int g, int nv, double* __restrict__ sums, int kind,
+                                                             double* __restrict__ st, int ns, double rel_fitness, double rel_rmse, int max_iteration)
+{
+    icp_reduce_step_kernel_body(part, g, nv, sums, kind, st, ns, rel_fitness, rel_rmse, max_iteration, blockIdx.x, gridDim.x);
+}
+
 // correspondence search of the ICP loop with the pending update applied on the way: the query is moved by state[21..36] (the update the
 // previous step computed), written back, and searched -- kG lanes per query as in nn1_group_kernel (every lane moves its copy)
-__global__ __launch_bounds__(kT) void icp_move_nn1_kernel(Grid g, double* __restrict__ src, int nq, double r2, int* __restrict__ idx,
-                                                          double* __restrict__ dist2, const double* __restrict__ st, int apply)
+__device__ __forceinline__ void icp_move_nn1_kernel_body(Grid g, double* __restrict__ src, int nq, double r2, int* __restrict__ idx, double* __restrict__ dist2, const double* __restrict__ st, int apply, const int bx, const int gx)
 {
     if (st[0] != 0.0) return;
     const int lane = threadIdx.x % kG;
-    const int i = (blockIdx.x * kT + threadIdx.x) / kG;
+    const int i = (bx * kT + threadIdx.x) / kG;
     double q[3] = {0, 0, 0};
     if (i < nq) {
         const double x = src[(size_t)i * 3], y = src[(size_t)i * 3 + 1], z = src[(size_t)i * 3 + 2];
@@ -937,6 +1036,12 @@ __global__ __launch_bounds__(kT) void icp_move_nn1_kernel(Grid g, double* __rest
         idx[i] = bi == 0xffffffffu ? -1 : (int)bi;
         dist2[i] = bi == 0xffffffffu ? 0.0 : best;
     }
+}
+
+__global__ __launch_bounds__(kT) void icp_move_nn1_kernel(Grid g, double* __restrict__ src, int nq, double r2, int* __restrict__ idx,
+                                                          double* __restrict__ dist2, const double* __restrict__ st, int apply)
+{
+    icp_move_nn1_kernel_body(g, src, nq, r2, idx, dist2, st, apply, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -970,4 +1075,725 @@ extern "C" int ape_icp_run_f64(int kind, GRID_ARGS, double* src, int ns, const d
     if (first_call) block(0);
     for (int it = 0; it < n_iter; ++it) block(1);
     return ape::check_launch("ape_icp_run_f64");
+}
+
+
+// =====================================================================================================================================
+// BATCHED forms (`*_batch_f64`): the label path's clouds are tiny (10^3..10^4 points) and every step of a chain depends on the one before,
+// so a chain by itself is a string of 5-20 us kernels behind dependent launches -- 38.6 k launches and 13.6 k small copies per 200-view
+// step in round 2, three host threads fighting over the GIL to keep the GPU fed.  The (object, direction) chains are independent of each
+// other (create_pointcloud.py:276-312: one sequential fusion per rotation directory), so here ONE launch advances up to kMaxBatch chains:
+// blockIdx.y selects the chain's argument record (passed by value in the kernel arguments), blockIdx.x walks that chain's own grid -- the
+// SAME `*_body` device code with the SAME per-chain grid size as the one-cloud entry points above (the fixed-order two-stage reductions
+// keep their partial layout), hence bit-identical results.  hipCUB's sort becomes ONE segmented radix sort over all chains (same stable
+// LSD radix per segment); its select / scan calls become a single-workgroup ordered compaction / scan per chain.
+namespace {
+
+constexpr int kMaxBatch = 16;
+template <class T> struct Batch { T t[kMaxBatch]; };
+constexpr int kCT = 1024;           // threads of the single-workgroup compaction / scan kernels
+
+// ordered compaction by one workgroup: out_idx[k] = i for the k-th i in [0, n) with pred(i); returns the count in *n_out.
+// Chunks of kCT * 4 consecutive elements; per chunk: every thread's 4-element count -> wave prefix by shuffles -> wave totals through LDS.
+template <class P>
+__device__ __forceinline__ void compact_block(int n, P pred, int* __restrict__ out_idx, int* __restrict__ n_out)
+{
+    __shared__ int wtot[kCT / 64];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += kCT * 4) {
+        const int i0 = c0 + tid * 4;
+        bool f[4];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { f[u] = i0 + u < n && pred(i0 + u); cnt += f[u] ? 1 : 0; }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kCT / 64; ++w) { const int t = wtot[w]; if (w < wv) wbase += t; total += t; }
+        int pos = base_s + wbase + incl - cnt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (f[u]) out_idx[pos++] = i0 + u;
+        __syncthreads();
+        if (tid == 0) base_s += total;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = base_s;
+}
+
+// exclusive scan of head[0..n) by one workgroup -> scan[]
+__device__ __forceinline__ void scan_block(const int* __restrict__ head, int n, int* __restrict__ scan)
+{
+    __shared__ int wtot[kCT / 64];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += kCT * 4) {
+        const int i0 = c0 + tid * 4;
+        int v[4], cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = i0 + u < n ? head[i0 + u] : 0; cnt += v[u]; }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kCT / 64; ++w) { const int t = wtot[w]; if (w < wv) wbase += t; total += t; }
+        int run = base_s + wbase + incl - cnt;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (i0 + u < n) { scan[i0 + u] = run; run += v[u]; }
+        __syncthreads();
+        if (tid == 0) base_s += total;
+        __syncthreads();
+    }
+}
+
+// ---- argument records (one per chain) -----------------------------------------------------------------------------------------------
+struct BSurf { const uint8_t* label; const uint16_t* depth; int* pix; int* n_out; double* out; Mat4 T; int n, W, gx; double fx, fy, ppx, ppy; };
+struct BPts { const double* pts; double* part; double* out6; int n, gx; };                        // bounds
+struct BKeys { const double* pts; const double* bounds6; u64* keys; unsigned* idx; double* origin; int n, gx; double h, shift; };
+struct BVox { const double* pts; const u64* keys; const unsigned* order; int* head; int* scan; double* out; int* n_out; int n, gx; };
+struct BGather { const double* pts; const unsigned* order; double* out; int n, gx; };
+struct BGridQ { Grid g; const double* q; int nq, gx; double r2; int* count; double* normals; int max_nn; double* mean; int k; };
+struct BSel { const double* pts; const int* count; const double* mean; int* sel; int* n_out; double* out; int n, gx, thr_count; double thr_mean; int mode; };
+struct BMom { const double* pts; double* part; double* out; int n, gx; };
+struct BMaha { const double* pts; double* out; int n, gx; Vec12 mc; };
+struct BXform { double* pts; double* normals; Mat4 T; int n, gx; };
+struct BCopy { const double* a; const double* b; double* out; int na, nb, gx; };
+struct BIcp { Grid g; double* src; const double* tgt; const double* tn; int* corr; double* d2; double* part; double* sums; double* st; int ns, gx_nn, gx_sum; };
+
+__global__ __launch_bounds__(kCT) void surface_compact_batch(const Batch<BSurf> b)
+{
+    const BSurf& a = b.t[blockIdx.y];
+    if (a.n <= 0) return;
+    compact_block(a.n, [&](int i) { return a.label[i] != 0 && a.depth[i] != 0; }, a.pix, a.n_out);
+}
+__global__ void surface_points_batch(const Batch<BSurf> b)
+{
+    const BSurf& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    surface_points_kernel_body(a.pix, a.n_out, a.depth, a.W, a.fx, a.fy, a.ppx, a.ppy, a.T, a.out, blockIdx.x, a.gx);
+}
+__global__ void bounds1_batch(const Batch<BPts> b)
+{
+    const BPts& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    bounds_stage1_body(a.pts, a.n, a.part, blockIdx.x, a.gx);
+}
+__global__ void bounds2_batch(const Batch<BPts> b)
+{
+    const BPts& a = b.t[blockIdx.y];
+    if (a.gx <= 0) return;
+    bounds_stage2_body(a.part, a.gx, a.out6, 0, 1);
+}
+__global__ void keys_batch(const Batch<BKeys> b)
+{
+    const BKeys& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    keys_kernel_body(a.pts, a.n, a.bounds6, a.h, a.shift, a.keys, a.idx, a.origin, blockIdx.x, a.gx);
+}
+__global__ void heads_batch(const Batch<BVox> b)
+{
+    const BVox& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    heads_kernel_body(a.keys, a.n, a.head, blockIdx.x, a.gx);
+}
+__global__ __launch_bounds__(kCT) void scan_batch(const Batch<BVox> b)
+{
+    const BVox& a = b.t[blockIdx.y];
+    if (a.n <= 0) return;
+    scan_block(a.head, a.n, a.scan);
+}
+__global__ void voxel_mean_batch(const Batch<BVox> b)
+{
+    const BVox& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    voxel_mean_kernel_body(a.pts, a.keys, a.order, a.head, a.scan, a.n, a.out, a.n_out, blockIdx.x, a.gx);
+}
+__global__ void gather_batch(const Batch<BGather> b)
+{
+    const BGather& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    gather_sorted_kernel_body(a.pts, a.order, a.n, a.out, blockIdx.x, a.gx);
+}
+__global__ __launch_bounds__(kT) void radius_count_batch(const Batch<BGridQ> b)
+{
+    const BGridQ& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    radius_count_group_kernel_body(a.g, a.q, a.nq, a.r2, a.count, blockIdx.x, a.gx);
+}
+__global__ __launch_bounds__(kT) void normals_batch(const Batch<BGridQ> b)
+{
+    const BGridQ& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    normals_kernel_body(a.g, a.q, a.nq, a.r2, a.max_nn, a.normals, blockIdx.x, a.gx);
+}
+__global__ __launch_bounds__(kT) void knn_mean_batch(const Batch<BGridQ> b)
+{
+    const BGridQ& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    knn_mean_grid_kernel_body(a.g, a.k, a.mean, blockIdx.x, a.gx);
+}
+// keep rule evaluated on the device: mode 0: count[i] > thr_count (RemoveRadiusOutliers); mode 1: mean[i] > 0 && mean[i] < thr_mean
+// (RemoveStatisticalOutliers; the threshold comes from the host's float64 statistics of the means, as in the one-cloud path)
+__global__ __launch_bounds__(kCT) void select_compact_batch(const Batch<BSel> b)
+{
+    const BSel& a = b.t[blockIdx.y];
+    if (a.n <= 0) return;
+    if (a.mode == 0) compact_block(a.n, [&](int i) { return a.count[i] > a.thr_count; }, a.sel, a.n_out);
+    else compact_block(a.n, [&](int i) { const double m = a.mean[i]; return m > 0.0 && m < a.thr_mean; }, a.sel, a.n_out);
+}
+__global__ void select_rows_batch(const Batch<BSel> b)
+{
+    const BSel& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    select_rows_kernel_body(a.pts, a.sel, a.n_out, a.out, blockIdx.x, a.gx);
+}
+__global__ __launch_bounds__(kT) void moments1_batch(const Batch<BMom> b)
+{
+    const BMom& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    moments_kernel_body(a.pts, a.n, a.part, blockIdx.x, a.gx);
+}
+__global__ void moments2_batch(const Batch<BMom> b)
+{
+    const BMom& a = b.t[blockIdx.y];
+    if (a.gx <= 0) return;
+    reduce_stage2_body(a.part, a.gx, 9, a.out, nullptr, 0, 1);
+}
+__global__ void mahalanobis_batch(const Batch<BMaha> b)
+{
+    const BMaha& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    mahalanobis_kernel_body(a.pts, a.n, a.mc, a.out, blockIdx.x, a.gx);
+}
+__global__ void transform_batch(const Batch<BXform> b)
+{
+    const BXform& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    transform_kernel_body(a.pts, a.n, a.T, a.normals, blockIdx.x, a.gx);
+}
+// out = [a rows | b rows] (torch.cat of two clouds) or a plain copy (nb = 0)
+__global__ void concat_batch(const Batch<BCopy> b)
+{
+    const BCopy& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx) return;
+    const long tot = 3L * (a.na + a.nb), na3 = 3L * a.na;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long)a.gx * blockDim.x) a.out[i] = i < na3 ? a.a[i] : a.b[i - na3];
+}
+__global__ __launch_bounds__(kT) void icp_move_nn1_batch(const Batch<BIcp> b, double r2, int apply)
+{
+    const BIcp& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx_nn) return;
+    icp_move_nn1_kernel_body(a.g, a.src, a.ns, r2, a.corr, a.d2, a.st, apply, blockIdx.x, a.gx_nn);
+}
+__global__ __launch_bounds__(kT) void icp_sums_batch(const Batch<BIcp> b, int kind)
+{
+    const BIcp& a = b.t[blockIdx.y];
+    if ((int)blockIdx.x >= a.gx_sum) return;
+    if (kind == 0) p2p_sums_kernel_body(a.src, a.tgt, a.corr, a.d2, a.ns, a.part, a.st, blockIdx.x, a.gx_sum);
+    else p2plane_sums_kernel_body(a.src, a.tgt, a.tn, a.corr, a.d2, a.ns, a.part, a.st, blockIdx.x, a.gx_sum);
+}
+__global__ __launch_bounds__(64) void icp_reduce_step_batch(const Batch<BIcp> b, int kind, double rel_fitness, double rel_rmse, int max_iteration)
+{
+    const BIcp& a = b.t[blockIdx.y];
+    if (a.gx_sum <= 0) return;
+    icp_reduce_step_kernel_body(a.part, a.gx_sum, kind == 0 ? 17 : 29, a.sums, kind, a.st, a.ns, rel_fitness, rel_rmse, max_iteration, 0, 1);
+}
+
+// ---- one workgroup sorts one cloud's (cell key, original index) pairs: stable sort by key = sort by (key, index) -------------------------
+// hipCUB's radix sort walks all 64 key bits in 8 passes of several launches (its segmented form: 405 us per call for eight 5 k-point
+// segments -- half the label path's GPU time); the keys are cell coordinates of a compact cloud, so here (cx, cy, cz) is re-coded as the
+// lexicographic rank (cx * ny + cy) * nz + cz < 2^46 (ny, nz: 1 + the cloud's largest cell coordinate; same order as the packed 3 x 21-bit
+// key), packed with the 17-bit index into ONE 64-bit word and sorted by a bitonic network in LDS (runs of 16 k words = 128 KB, one
+// workgroup per run; ascending-everywhere "flip + disperse" form, so positions past n act as +infinity without being stored); a cloud of
+// several runs (a raw 640x480 surface: 20..60 k points) is then merged by rank (seg_merge_batch).  Clouds beyond 128 k points or 2^46
+// cells take the same network over the global key / index arrays with the (key, index) compare.
+struct BSort { const u64* k_in; const unsigned* i_in; u64* k_out; unsigned* i_out; u64* k_scratch; unsigned* i_scratch; int* flag; int n, gx; };
+constexpr int kSortLdsMax = 16384, kSortRuns = 8, kSortIdxBits = 17;       // runs of 16 k words (128 KB of LDS), 8 x 16 k = 2^17 indices
+
+// positions >= n are +infinity and never touched; all block sizes are powers of two, so the pair -> (i, l) maps are shifts, and i grows
+// with p, so a thread stops at its first pair past the data
+template <class CE>
+__device__ __forceinline__ void bitonic_flip(int n, int lk, int half_pairs, CE cmpex)
+{
+    const int k = 1 << lk, hk = k >> 1;
+    for (int p = threadIdx.x; p < half_pairs; p += blockDim.x) {              // i <-> its mirror inside the block of k
+        const int base = (p >> (lk - 1)) << lk, off = p & (hk - 1);
+        const int i = base | off, l = base | (k - 1 - off);
+        if (i >= n) break;
+        if (l < n) cmpex(i, l);
+    }
+}
+template <class CE>
+__device__ __forceinline__ void bitonic_disperse(int n, int lj, int half_pairs, CE cmpex)
+{
+    const int j = 1 << lj;
+    for (int p = threadIdx.x; p < half_pairs; p += blockDim.x) {              // i <-> i + j
+        const int i = ((p >> lj) << (lj + 1)) | (p & (j - 1)), l = i | j;
+        if (i >= n) break;
+        if (l < n) cmpex(i, l);
+    }
+}
+template <class CE>
+__device__ __forceinline__ void bitonic_network(int n, CE cmpex)
+{
+    int lpad = 0;
+    while ((1 << lpad) < n) ++lpad;
+    const int half_pairs = (1 << lpad) >> 1;
+    for (int lk = 1; lk <= lpad; ++lk) {
+        bitonic_flip(n, lk, half_pairs, cmpex);
+        __syncthreads();
+        for (int lj = lk - 2; lj >= 0; --lj) {
+            bitonic_disperse(n, lj, half_pairs, cmpex);
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void cswap(u64& x, u64& y) { const u64 lo = x < y ? x : y, hi = x < y ? y : x; x = lo; y = hi; }
+// the network's steps of stride 4, 2, 1 on eight neighbours held in registers
+__device__ __forceinline__ void disperse8(u64 (&v)[8])
+{
+    cswap(v[0], v[4]); cswap(v[1], v[5]); cswap(v[2], v[6]); cswap(v[3], v[7]);
+    cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+}
+__device__ __forceinline__ void sort8(u64 (&v)[8])
+{
+    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);                       // k = 2
+    cswap(v[0], v[3]); cswap(v[1], v[2]); cswap(v[4], v[7]); cswap(v[5], v[6]);                       // k = 4: flip
+    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+    cswap(v[0], v[7]); cswap(v[1], v[6]); cswap(v[2], v[5]); cswap(v[3], v[4]);                       // k = 8: flip
+    cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+}
+// LDS words s[0, n8), n8 a multiple of 8 with +infinity in [n, n8): strides >= 8 through LDS, strides 4, 2, 1 in registers (one barrier
+// for three steps, 16-byte LDS accesses)
+template <bool First>
+__device__ __forceinline__ void regs8_pass(u64* s, int n8)
+{
+    for (int g = threadIdx.x * 8; g < n8; g += blockDim.x * 8) {
+        u64 v[8];
+        #pragma unroll
+        for (int e = 0; e < 8; e += 2) { const ulonglong2 t = *reinterpret_cast<const ulonglong2*>(s + g + e); v[e] = t.x; v[e + 1] = t.y; }
+        if (First) sort8(v); else disperse8(v);
+        #pragma unroll
+        for (int e = 0; e < 8; e += 2) *reinterpret_cast<ulonglong2*>(s + g + e) = ulonglong2{v[e], v[e + 1]};
+    }
+}
+__device__ __forceinline__ void bitonic_lds(u64* s, int n8)
+{
+    int lpad = 3;
+    while ((1 << lpad) < n8) ++lpad;
+    const int half_pairs = (1 << lpad) >> 1;
+    auto cmpex = [&](int i, int l) { const u64 x = s[i], y = s[l]; if (x > y) { s[i] = y; s[l] = x; } };
+    regs8_pass<true>(s, n8);
+    __syncthreads();
+    for (int lk = 4; lk <= lpad; ++lk) {
+        bitonic_flip(n8, lk, half_pairs, cmpex);
+        __syncthreads();
+        for (int lj = lk - 2; lj >= 3; --lj) {
+            bitonic_disperse(n8, lj, half_pairs, cmpex);
+            __syncthreads();
+        }
+        regs8_pass<false>(s, n8);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 sort_lds[];
+    const BSort& a = b.t[blockIdx.y];
+    const int n = a.n, run = blockIdx.x;
+    const int nruns = (n + kSortLdsMax - 1) / kSortLdsMax;
+    if (n <= 0 || (run > 0 && run >= nruns)) return;
+    // cells per axis = 1 + the largest cell coordinate among THIS cloud's keys (every run's workgroup walks the whole cloud: same value)
+    __shared__ unsigned cmax[3];
+    if (threadIdx.x < 3) cmax[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        unsigned mx = 0, my = 0, mz = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const u64 key = a.k_in[i];
+            const unsigned cx = (unsigned)(key >> 42), cy = (unsigned)((key >> 21) & 2097151ULL), cz = (unsigned)(key & 2097151ULL);
+            mx = cx > mx ? cx : mx; my = cy > my ? cy : my; mz = cz > mz ? cz : mz;
+        }
+        atomicMax(&cmax[0], mx); atomicMax(&cmax[1], my); atomicMax(&cmax[2], mz);
+    }
+    __syncthreads();
+    const u64 dim[3] = {(u64)cmax[0] + 1, (u64)cmax[1] + 1, (u64)cmax[2] + 1};
+    const bool compact = nruns <= kSortRuns && (double)dim[0] * (double)dim[1] * (double)dim[2] <= 70368744177664.0;      // 2^46
+    if (run == 0 && threadIdx.x == 0) *a.flag = compact ? 1 : 0;
+    if (compact) {
+        const int r0 = run * kSortLdsMax, len = n - r0 < kSortLdsMax ? n - r0 : kSortLdsMax;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            const u64 key = a.k_in[r0 + i];
+            const u64 cx = key >> 42, cy = (key >> 21) & 2097151ULL, cz = key & 2097151ULL;
+            sort_lds[i] = ((((cx * dim[1]) + cy) * dim[2] + cz) << kSortIdxBits) | (u64)(r0 + i);       // i_in[i] == i (keys_kernel)
+        }
+        const int n8 = (len + 7) & ~7;
+        if ((int)threadIdx.x < n8 - len) sort_lds[len + threadIdx.x] = ~0ULL;
+        __syncthreads();
+        bitonic_lds(sort_lds, n8);
+        if (nruns == 1) {
+            for (int i = threadIdx.x; i < len; i += blockDim.x) {
+                const unsigned src = (unsigned)(sort_lds[i] & ((1ULL << kSortIdxBits) - 1));
+                a.i_out[i] = src;
+                a.k_out[i] = a.k_in[src];
+            }
+        } else {
+            for (int i = threadIdx.x; i < len; i += blockDim.x) a.k_scratch[r0 + i] = sort_lds[i];     // a sorted run; seg_merge_batch places it
+        }
+        return;
+    }
+    if (run != 0) return;
+    // general form: the same network over global scratch copies, (key, index) compare; workgroup-scope fences order the exchanges
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { a.k_scratch[i] = a.k_in[i]; a.i_scratch[i] = a.i_in[i]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    bitonic_network(n, [&](int i, int l) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const u64 kx = a.k_scratch[i], ky = a.k_scratch[l];
+        const unsigned ix = a.i_scratch[i], iy = a.i_scratch[l];
+        if (kx > ky || (kx == ky && ix > iy)) { a.k_scratch[i] = ky; a.k_scratch[l] = kx; a.i_scratch[i] = iy; a.i_scratch[l] = ix; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    });
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { a.k_out[i] = a.k_scratch[i]; a.i_out[i] = a.i_scratch[i]; }
+}
+
+// clouds of 2..kSortRuns sorted runs: a word's place = its place in its run + the number of smaller words in every other run (the words
+// are distinct: the index is part of them)
+__global__ void seg_merge_batch(const Batch<BSort> b)
+{
+    const BSort& a = b.t[blockIdx.y];
+    const int n = a.n;
+    const int nruns = (n + kSortLdsMax - 1) / kSortLdsMax;
+    if (nruns < 2 || (int)blockIdx.x >= a.gx || !*a.flag) return;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += a.gx * blockDim.x) {
+        const u64 w = a.k_scratch[g];
+        const int r = g / kSortLdsMax;
+        int pos = g - r * kSortLdsMax;
+        for (int r2 = 0; r2 < nruns; ++r2) {
+            if (r2 == r) continue;
+            const u64* run = a.k_scratch + (size_t)r2 * kSortLdsMax;
+            int lo = 0, hi = n - r2 * kSortLdsMax < kSortLdsMax ? n - r2 * kSortLdsMax : kSortLdsMax;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (run[mid] < w) lo = mid + 1; else hi = mid; }
+            pos += lo;
+        }
+        const unsigned src = (unsigned)(w & ((1ULL << kSortIdxBits) - 1));
+        a.i_out[pos] = src;
+        a.k_out[pos] = a.k_in[src];
+    }
+}
+
+template <class A, class K, class... X>
+void launch_batch(K kern, const Batch<A>& b, int nb, int max_gx, int threads, hipStream_t st, X... extra)
+{
+    hipLaunchKernelGGL(kern, dim3(max_gx < 1 ? 1 : max_gx, nb), dim3(threads), 0, st, b, extra...);
+}
+
+// bounds -> keys -> one single-workgroup sort per cloud (ONE launch).  k0 / i0: concatenated [sum n] scratch, chain c at off[c]; the sorted
+// keys / order go straight to k_out[c] / i_out[c] (per-cloud buffers); ks / is: scratch of the sort's general form.
+int keys_and_sort(int nb, const double* const* pts, const int* n, const int* off, double h, double shift, double* const* origin, u64* k0, unsigned* i0,
+                  u64* const* k_out, unsigned* const* i_out, u64* ks, unsigned* is, double* part, hipStream_t st)
+{
+    Batch<BPts> bp{};
+    Batch<BKeys> bk{};
+    Batch<BSort> bs{};
+    int mg1 = 1, mg2 = 1, nmax = 1;
+    for (int c = 0; c < nb; ++c) {
+        const int g = n[c] > 0 ? grid_for(n[c], 1024) : 0;
+        bp.t[c] = BPts{pts[c], part + (size_t)c * (1024 * 6 + 8), part + (size_t)c * (1024 * 6 + 8) + 1024 * 6, n[c], g};
+        bk.t[c] = BKeys{pts[c], bp.t[c].out6, k0 + off[c], i0 + off[c], origin ? origin[c] : nullptr, n[c], n[c] > 0 ? grid_for(n[c]) : 0, h, shift};
+        bs.t[c] = BSort{k0 + off[c], i0 + off[c], k_out[c], i_out[c], ks + off[c], is + off[c], reinterpret_cast<int*>(bp.t[c].out6 + 7), n[c], bk.t[c].gx};
+        mg1 = g > mg1 ? g : mg1;
+        mg2 = bk.t[c].gx > mg2 ? bk.t[c].gx : mg2;
+        nmax = n[c] > nmax ? n[c] : nmax;
+    }
+    launch_batch(bounds1_batch, bp, nb, mg1, kT, st);
+    launch_batch(bounds2_batch, bp, nb, 1, 64, st);
+    launch_batch(keys_batch, bk, nb, mg2, kT, st);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_batch), hipFuncAttributeMaxDynamicSharedMemorySize, kSortLdsMax * 8) != hipSuccess) return APE_ELAUNCH;
+        attr_set = true;
+    }
+    const size_t lds = (size_t)(((nmax < kSortLdsMax ? nmax : kSortLdsMax) + 7) & ~7) * 8;
+    const int runs = (nmax + kSortLdsMax - 1) / kSortLdsMax;
+    hipLaunchKernelGGL(seg_sort_batch, dim3(runs < 1 ? 1 : (runs > kSortRuns ? kSortRuns : runs), nb), dim3(kCT), lds, st, bs);
+    if (runs > 1) launch_batch(seg_merge_batch, bs, nb, mg2, kT, st);
+    return APE_OK;
+}
+
+}  // namespace
+
+/* workspace for the batched entry points over `nb` clouds with `n_total` points in all (surface: n_total = nb * H * W pixels) */
+extern "C" size_t ape_pc_batch_workspace_bytes(int nb, long n_total)
+{
+    if (nb < 1) nb = 1;
+    if (n_total < 1) n_total = 1;
+    const int nt = (int)(n_total > 0x7fffffffL ? 0x7fffffff : n_total);
+    return 3 * align_up((size_t)nt * 8) + 5 * align_up((size_t)nt * 4) + align_up((size_t)nb * (1024 * 6 + 8) * 8) + align_up((size_t)nb * 512 * 29 * 8) + 8192;
+}
+
+#define APE_BATCH_CHECK(nb) if ((nb) < 1 || (nb) > kMaxBatch) return APE_EINVAL
+
+/* ape_surface_points_f64 for nb views at once: label[c] / depth[c] [H][W], T16_host [nb][16], points[c] capacity H*W rows,
+ * n_out [nb] on the device; pix_ws: nb * H * W ints */
+extern "C" int ape_surface_points_batch_f64(int nb, const uint8_t* const* label, const uint16_t* const* depth, int H, int W, const double* intr4_host,
+                                            const double* T16_host, double* const* points, int* n_out, int* pix_ws, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!label || !depth || !intr4_host || !T16_host || !points || !n_out || !pix_ws || H < 1 || W < 1) return APE_EINVAL;
+    const int n = H * W;
+    Batch<BSurf> b{};
+    for (int c = 0; c < nb; ++c)
+        b.t[c] = BSurf{label[c], depth[c], pix_ws + (size_t)c * n, n_out + c, points[c], load_mat(T16_host + c * 16), n, W, grid_for(n),
+                       intr4_host[c * 4], intr4_host[c * 4 + 1], intr4_host[c * 4 + 2], intr4_host[c * 4 + 3]};
+    hipStream_t st = (hipStream_t)stream;
+    launch_batch(surface_compact_batch, b, nb, 1, kCT, st);
+    launch_batch(surface_points_batch, b, nb, grid_for(n), kT, st);
+    return ape::check_launch("ape_surface_points_batch_f64");
+}
+
+/* ape_voxel_down_sample_f64 for nb clouds: out[c] capacity n[c] rows, n_out [nb] on the device; n / out pointers are host arrays */
+extern "C" int ape_voxel_down_sample_batch_f64(int nb, const double* const* pts, const int* n, double voxel, double* const* out, int* n_out, void* ws,
+                                               size_t ws_bytes, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!pts || !n || !out || !n_out || !ws || !(voxel > 0)) return APE_EINVAL;
+    int off[kMaxBatch + 1];
+    off[0] = 0;
+    for (int c = 0; c < nb; ++c) { if (n[c] < 0) return APE_EINVAL; off[c + 1] = off[c] + n[c]; }
+    const int nt = off[nb];
+    if (nt == 0) return APE_OK;
+    if (ws_bytes < ape_pc_batch_workspace_bytes(nb, nt)) return APE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv{(char*)ws, (char*)ws + ws_bytes};
+    u64* k0 = cv.take<u64>(nt); u64* k1 = cv.take<u64>(nt); u64* ks = cv.take<u64>(nt);
+    unsigned* i0 = cv.take<unsigned>(nt); unsigned* i1 = cv.take<unsigned>(nt); unsigned* is = cv.take<unsigned>(nt);
+    int* head = cv.take<int>(nt); int* scan = cv.take<int>(nt);
+    double* part = cv.take<double>((size_t)nb * (1024 * 6 + 8));
+    if (!part) return APE_EWORKSPACE;
+    u64* ko[kMaxBatch]; unsigned* io[kMaxBatch];
+    for (int c = 0; c < nb; ++c) { ko[c] = k1 + off[c]; io[c] = i1 + off[c]; }
+    int rc = keys_and_sort(nb, pts, n, off, voxel, voxel * 0.5, nullptr, k0, i0, ko, io, ks, is, part, st);
+    if (rc != APE_OK) return rc;
+    Batch<BVox> bv{};
+    int mg = 1;
+    for (int c = 0; c < nb; ++c) {
+        bv.t[c] = BVox{pts[c], k1 + off[c], i1 + off[c], head + off[c], scan + off[c], out[c], n_out + c, n[c], n[c] > 0 ? grid_for(n[c]) : 0};
+        mg = bv.t[c].gx > mg ? bv.t[c].gx : mg;
+    }
+    launch_batch(heads_batch, bv, nb, mg, kT, st);
+    launch_batch(scan_batch, bv, nb, 1, kCT, st);
+    launch_batch(voxel_mean_batch, bv, nb, mg, kT, st);
+    return ape::check_launch("ape_voxel_down_sample_batch_f64");
+}
+
+/* ape_grid_build_f64 for nb clouds; sorted / keys / order / origin: per-cloud device buffers (host arrays of pointers) */
+extern "C" int ape_grid_build_batch_f64(int nb, const double* const* pts, const int* n, double cell, double* const* sorted,
+                                        unsigned long long* const* keys, unsigned* const* order, double* const* origin3, void* ws, size_t ws_bytes,
+                                        void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!pts || !n || !sorted || !keys || !order || !origin3 || !ws || !(cell > 0)) return APE_EINVAL;
+    int off[kMaxBatch + 1];
+    off[0] = 0;
+    for (int c = 0; c < nb; ++c) { if (n[c] < 0) return APE_EINVAL; off[c + 1] = off[c] + n[c]; }
+    const int nt = off[nb];
+    if (nt == 0) return APE_OK;
+    if (ws_bytes < ape_pc_batch_workspace_bytes(nb, nt)) return APE_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv{(char*)ws, (char*)ws + ws_bytes};
+    u64* k0 = cv.take<u64>(nt); cv.take<u64>(nt); u64* ks = cv.take<u64>(nt);
+    unsigned* i0 = cv.take<unsigned>(nt); cv.take<unsigned>(nt); unsigned* is = cv.take<unsigned>(nt);
+    cv.take<int>(nt); cv.take<int>(nt);
+    double* part = cv.take<double>((size_t)nb * (1024 * 6 + 8));
+    if (!part) return APE_EWORKSPACE;
+    int rc = keys_and_sort(nb, pts, n, off, cell, cell, origin3, k0, i0, (u64* const*)keys, order, ks, is, part, st);
+    if (rc != APE_OK) return rc;
+    Batch<BGather> bg{};
+    int mg = 1;
+    for (int c = 0; c < nb; ++c) {
+        bg.t[c] = BGather{pts[c], order[c], sorted[c], n[c], n[c] > 0 ? grid_for(n[c]) : 0};
+        mg = bg.t[c].gx > mg ? bg.t[c].gx : mg;
+    }
+    launch_batch(gather_batch, bg, nb, mg, kT, st);
+    return ape::check_launch("ape_grid_build_batch_f64");
+}
+
+/* per-cloud grid description for the batched searches: the arguments of GRID_ARGS as arrays */
+#define BGRID_ARGS const double* const* sorted, const unsigned long long* const* keys, const unsigned* const* order, const double* const* origin3, const int* gn, double cell
+#define BGRID(c) Grid{sorted[c], (const u64*)keys[c], order[c], origin3[c], gn[c], cell}
+
+/* op 0: radius count (count[c][nq]); op 1: hybrid normals (normals[c][nq][3], max_nn); op 2: k-NN mean distance of the grid's own points
+ * (mean[c][gn], k) -- the queries q[c] (nq[c] rows) are ignored for op 2 */
+extern "C" int ape_grid_query_batch_f64(int op, int nb, BGRID_ARGS, const double* const* q, const int* nq, double radius, int max_nn_or_k,
+                                        int* const* count, double* const* normals, double* const* mean, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (op < 0 || op > 2 || !sorted || !keys || !order || !origin3 || !gn || !(cell > 0)) return APE_EINVAL;
+    if (op == 0 && (!q || !nq || !count || radius > cell)) return APE_EINVAL;
+    if (op == 1 && (!q || !nq || !normals || radius > cell || max_nn_or_k < 1 || max_nn_or_k > kMaxNN)) return APE_EINVAL;
+    if (op == 2 && (!mean || max_nn_or_k < 1 || max_nn_or_k > kMaxNN)) return APE_EINVAL;
+    Batch<BGridQ> b{};
+    int mg = 1;
+    for (int c = 0; c < nb; ++c) {
+        const int nqc = op == 2 ? gn[c] : nq[c];
+        if (gn[c] < 0 || nqc < 0 || (op == 2 && gn[c] > 0 && max_nn_or_k > gn[c])) return APE_EINVAL;
+        const int gx = (gn[c] > 0 && nqc > 0) ? ape::ceil_div((long)nqc * kG, (long)kT) : 0;
+        b.t[c] = BGridQ{BGRID(c), op == 2 ? nullptr : q[c], nqc, gx, radius * radius, op == 0 ? count[c] : nullptr, op == 1 ? normals[c] : nullptr, max_nn_or_k,
+                        op == 2 ? mean[c] : nullptr, max_nn_or_k};
+        mg = gx > mg ? gx : mg;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (op == 0) launch_batch(radius_count_batch, b, nb, mg, kT, st);
+    else if (op == 1) launch_batch(normals_batch, b, nb, mg, kT, st);
+    else launch_batch(knn_mean_batch, b, nb, mg, kT, st);
+    return ape::check_launch("ape_grid_query_batch_f64");
+}
+
+/* ordered row selection with the keep rule evaluated on the device.  mode 0: count[c][i] > thr_count (RemoveRadiusOutliers);
+ * mode 1: mean[c][i] > 0 && mean[c][i] < thr_mean_host[c] (RemoveStatisticalOutliers).  out[c] capacity n[c] rows, sel_ws: sum n ints,
+ * n_out [nb] on the device */
+extern "C" int ape_select_points_batch_f64(int mode, int nb, const double* const* pts, const int* n, const int* const* count, int thr_count,
+                                           const double* const* mean, const double* thr_mean_host, double* const* out, int* n_out, int* sel_ws,
+                                           void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if ((mode != 0 && mode != 1) || !pts || !n || !out || !n_out || !sel_ws) return APE_EINVAL;
+    if ((mode == 0 && !count) || (mode == 1 && (!mean || !thr_mean_host))) return APE_EINVAL;
+    Batch<BSel> b{};
+    int mg = 1, off = 0;
+    for (int c = 0; c < nb; ++c) {
+        if (n[c] < 0) return APE_EINVAL;
+        b.t[c] = BSel{pts[c], mode == 0 ? count[c] : nullptr, mode == 1 ? mean[c] : nullptr, sel_ws + off, n_out + c, out[c], n[c], n[c] > 0 ? grid_for(n[c]) : 0,
+                      thr_count, mode == 1 ? thr_mean_host[c] : 0.0, mode};
+        off += n[c];
+        mg = b.t[c].gx > mg ? b.t[c].gx : mg;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    launch_batch(select_compact_batch, b, nb, 1, kCT, st);
+    launch_batch(select_rows_batch, b, nb, mg, kT, st);
+    return ape::check_launch("ape_select_points_batch_f64");
+}
+
+/* ape_icp_sums_f64(kind 2) for nb clouds: out9 [nb][9] on the device; ws: nb * 512 * 9 doubles */
+extern "C" int ape_moments_batch_f64(int nb, const double* const* pts, const int* n, double* out9, void* ws, size_t ws_bytes, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!pts || !n || !out9 || !ws || ws_bytes < (size_t)nb * 512 * 9 * 8) return APE_EINVAL;
+    Batch<BMom> b{};
+    int mg = 1;
+    for (int c = 0; c < nb; ++c) {
+        if (n[c] < 0) return APE_EINVAL;
+        b.t[c] = BMom{pts[c], (double*)ws + (size_t)c * 512 * 9, out9 + c * 9, n[c], n[c] > 0 ? grid_for(n[c], 512) : 0};
+        mg = b.t[c].gx > mg ? b.t[c].gx : mg;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    launch_batch(moments1_batch, b, nb, mg, kT, st);
+    launch_batch(moments2_batch, b, nb, 1, 64, st);
+    return ape::check_launch("ape_moments_batch_f64");
+}
+
+/* ape_mahalanobis_f64 for nb clouds: mc12_host [nb][12] */
+extern "C" int ape_mahalanobis_batch_f64(int nb, const double* const* pts, const int* n, const double* mc12_host, double* const* out, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!pts || !n || !mc12_host || !out) return APE_EINVAL;
+    // Vec12 by value is 96 B per chain: two launches of up to eight chains keep the kernel arguments under 4 KB
+    hipStream_t st = (hipStream_t)stream;
+    for (int c0 = 0; c0 < nb; c0 += 8) {
+        Batch<BMaha> b{};
+        int mg = 1, m = nb - c0 < 8 ? nb - c0 : 8;
+        for (int c = 0; c < m; ++c) {
+            if (n[c0 + c] < 0) return APE_EINVAL;
+            b.t[c] = BMaha{pts[c0 + c], out[c0 + c], n[c0 + c], n[c0 + c] > 0 ? grid_for(n[c0 + c]) : 0, {}};
+            for (int i = 0; i < 12; ++i) b.t[c].mc.v[i] = mc12_host[(c0 + c) * 12 + i];
+            mg = b.t[c].gx > mg ? b.t[c].gx : mg;
+        }
+        launch_batch(mahalanobis_batch, b, m, mg, kT, st);
+    }
+    return ape::check_launch("ape_mahalanobis_batch_f64");
+}
+
+/* ape_transform_points_f64 for nb clouds in place: T16_host [nb][16]; normals[c] may be null */
+extern "C" int ape_transform_points_batch_f64(int nb, double* const* pts, double* const* normals, const int* n, const double* T16_host, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!pts || !n || !T16_host) return APE_EINVAL;
+    Batch<BXform> b{};
+    int mg = 1;
+    for (int c = 0; c < nb; ++c) {
+        if (n[c] < 0) return APE_EINVAL;
+        b.t[c] = BXform{pts[c], normals ? normals[c] : nullptr, load_mat(T16_host + c * 16), n[c], n[c] > 0 ? grid_for(n[c]) : 0};
+        mg = b.t[c].gx > mg ? b.t[c].gx : mg;
+    }
+    launch_batch(transform_batch, b, nb, mg, kT, (hipStream_t)stream);
+    return ape::check_launch("ape_transform_points_batch_f64");
+}
+
+/* out[c] = [a[c] (na[c] rows) | b[c] (nb_rows[c] rows)]; b may be null (plain copies) */
+extern "C" int ape_concat_points_batch_f64(int nb, const double* const* a, const int* na, const double* const* b, const int* nb_rows, double* const* out,
+                                           void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (!a || !na || !out) return APE_EINVAL;
+    Batch<BCopy> bt{};
+    int mg = 1;
+    for (int c = 0; c < nb; ++c) {
+        const int n2 = b && nb_rows ? nb_rows[c] : 0;
+        if (na[c] < 0 || n2 < 0) return APE_EINVAL;
+        const int tot = na[c] + n2;
+        bt.t[c] = BCopy{a[c], b ? b[c] : nullptr, out[c], na[c], n2, tot > 0 ? grid_for(3L * tot) : 0};
+        mg = bt.t[c].gx > mg ? bt.t[c].gx : mg;
+    }
+    launch_batch(concat_batch, bt, nb, mg, kT, (hipStream_t)stream);
+    return ape::check_launch("ape_concat_points_batch_f64");
+}
+
+/* ape_icp_run_f64 for nb registrations of the same kind advancing together: per chain the target's grid, the moved source src[c] (ns[c]
+ * rows, updated in place), target points / normals, scratch corr[c] / dist2[c] / sums[c] (29) and state[c] (40 doubles on the device, set
+ * up as for ape_icp_run_f64); chains with ns[c] == 0 or gn[c] == 0 are skipped.  ws: nb * 512 * 29 doubles. */
+extern "C" int ape_icp_run_batch_f64(int kind, int nb, BGRID_ARGS, double* const* src, const int* ns, const double* const* tgt,
+                                     const double* const* tgt_normals, double max_dist, double rel_fitness, double rel_rmse, int max_iteration, int n_iter,
+                                     int first_call, int* const* corr, double* const* dist2, double* const* sums, double* const* state, void* ws,
+                                     size_t ws_bytes, void* stream)
+{
+    APE_BATCH_CHECK(nb);
+    if (kind < 0 || kind > 1 || !sorted || !keys || !order || !origin3 || !gn || !src || !ns || !tgt || !corr || !dist2 || !sums || !state || !ws) return APE_EINVAL;
+    if (kind == 1 && !tgt_normals) return APE_EINVAL;
+    if (max_dist > cell || n_iter < 0 || max_iteration < 0 || ws_bytes < (size_t)nb * 512 * 29 * 8) return APE_EINVAL;
+    Batch<BIcp> b{};
+    int mg_nn = 1, mg_sum = 1;
+    for (int c = 0; c < nb; ++c) {
+        const bool on = ns[c] > 0 && gn[c] > 0;
+        if (ns[c] < 0 || gn[c] < 0 || (on && kind == 1 && !tgt_normals[c])) return APE_EINVAL;
+        b.t[c] = BIcp{BGRID(c), src[c], tgt[c], kind == 1 ? tgt_normals[c] : nullptr, corr[c], dist2[c], (double*)ws + (size_t)c * 512 * 29, sums[c], state[c],
+                      ns[c], on ? ape::ceil_div((long)ns[c] * kG, (long)kT) : 0, on ? grid_for(ns[c], 512) : 0};
+        mg_nn = b.t[c].gx_nn > mg_nn ? b.t[c].gx_nn : mg_nn;
+        mg_sum = b.t[c].gx_sum > mg_sum ? b.t[c].gx_sum : mg_sum;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    auto block = [&](int apply) {
+        launch_batch(icp_move_nn1_batch, b, nb, mg_nn, kT, st, max_dist * max_dist, apply);
+        launch_batch(icp_sums_batch, b, nb, mg_sum, kT, st, kind);
+        launch_batch(icp_reduce_step_batch, b, nb, 1, 64, st, kind, rel_fitness, rel_rmse, max_iteration);
+    };
+    if (first_call) block(0);
+    for (int it = 0; it < n_iter; ++it) block(1);
+    return ape::check_launch("ape_icp_run_batch_f64");
 }

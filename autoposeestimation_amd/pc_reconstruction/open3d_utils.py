@@ -196,7 +196,35 @@ def fuse_chains(chains, intr, voxel_size=2, threshold=10, min_friends=20, min_di
     from autoposeestimation_amd import sharding
     make_set, fuse = _chain_workers(intr, voxel_size, threshold, min_friends, min_dist, nb_neighbors, voxel_size_out, icp_point2point,
                                     icp_point2plane)
-    return sharding.sharded_chains([list(v) for v in chains], make_set, fuse, dist, load=_load_view)
+    if not USE_BATCHED:
+        return sharding.sharded_chains([list(v) for v in chains], make_set, fuse, dist, load=_load_view)
+    # lock-step batched form (pc_reconstruction/batched.py): one host thread, one launch per step for all of this rank's views / chains
+    from autoposeestimation_amd.pc_reconstruction import batched as B
 
+    def make_sets(views):
+        views = [v() if callable(v) else v for v in views]
+        return [c._p for c in B.get_surface_batch(views, intr, min_friends, min_dist, nb_neighbors, voxel_size)]
+
+    def fuse_many(parts):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        clouds = []
+        for sets in parts:
+            row = []
+            for p in sets:
+                c = _pc.PointCloud(device=dev)
+                c.points = p.to(dev)
+                row.append(c)
+            clouds.append(row)
+        return B.fuse_surfaces_batch(clouds, voxel_size=voxel_size, threshold=threshold, voxel_size_out=voxel_size_out,
+                                     icp_point2point=icp_point2point, icp_point2plane=icp_point2plane)
+
+    return sharding.sharded_chains([list(v) for v in chains], make_set, fuse, dist, load=_load_view, make_sets=make_sets, fuse_many=fuse_many)
+
+
+import os  # noqa: E402
 
 import torch  # noqa: E402
+
+# fuse_chains advances all of a rank's views / chains in lock step, one launch per step (batched.py); APE_LABEL_BATCHED=0 keeps the round-2 form
+# (a host thread and a HIP stream per unit, sharding.run_side_by_side) -- both give the same clouds bit for bit
+USE_BATCHED = os.environ.get("APE_LABEL_BATCHED", "1") != "0"

@@ -247,12 +247,15 @@ def sharded_chain(items, make_set, fuse, owner, dist=None, load=None):
     return guarded(dist, lambda: fuse(sets) if rank == owner else None, "the fusion of a sharded chain")
 
 
-def sharded_chains(chains, make_set, fuse, dist=None, load=None):
+def sharded_chains(chains, make_set, fuse, dist=None, load=None, make_sets=None, fuse_many=None):
     """Several chains at once: `chains` = list of item lists.  The per-item work of ALL chains is spread over the ranks as one flat
     list (balanced even when chains differ in length), ONE padded all-gather distributes the sets, and then every rank fuses the
     chains it owns (`chain_owner`) -- the sequential, order-dependent parts of different chains run side by side on different GPUs,
     which a loop of `sharded_chain` calls cannot do (each of its all-gathers would wait for the previous chain's owner).
-    Returns {chain index: fuse(sets of that chain)} for the chains this rank owns."""
+    Returns {chain index: fuse(sets of that chain)} for the chains this rank owns.
+
+    `make_sets(list of loaded items) -> list of sets` and `fuse_many(list of set lists) -> list of results`: optional BATCHED forms of the
+    two stages (pc_reconstruction/batched.py: one launch advances many clouds); when given they replace the thread-per-unit form."""
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     flat = [(ci, item) for ci, items in enumerate(chains) for item in items]
@@ -260,6 +263,8 @@ def sharded_chains(chains, make_set, fuse, dist=None, load=None):
 
     def produce():
         loaded = list(prefetched([f[1] for f in flat[lo:hi]], load))
+        if make_sets is not None:
+            return list(zip(range(lo, hi), make_sets(loaded)))
         return list(zip(range(lo, hi), run_side_by_side([lambda x=x: make_set(x) for x in loaded])))
 
     local = guarded(dist, produce, "the per-view stage of the sharded chains")
@@ -269,6 +274,7 @@ def sharded_chains(chains, make_set, fuse, dist=None, load=None):
         if chain_owner(ci, world) == rank:
             mine.append((ci, sets[pos:pos + len(items)]))
         pos += len(items)
-    fused = guarded(dist, lambda: run_side_by_side([lambda part=part: fuse(part) for _, part in mine]),       # this rank's chains, side by side
+    fused = guarded(dist, lambda: fuse_many([part for _, part in mine]) if fuse_many is not None else
+                    run_side_by_side([lambda part=part: fuse(part) for _, part in mine]),       # this rank's chains, in lock step / side by side
                     "the fusion stage of the sharded chains")
     return {ci: res for (ci, _), res in zip(mine, fused)}

@@ -324,6 +324,45 @@ int ape_mahalanobis_f64(const double* pts, int n, const double* mean_cinv12_host
 int ape_select_points_f64(const double* pts, const uint8_t* keep, int n, double* out, int* sel_idx, int* n_out, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* ---- BATCHED forms of the point-cloud kernels above (pose-label path, SURVEY.md 8e: the (object, direction) chains of
+ * pc_reconstruction/create_pointcloud.py:276-312 are independent of each other).  ONE launch advances up to 16 clouds: blockIdx.y selects
+ * the cloud's argument record, blockIdx.x walks that cloud's own grid -- the same device code with the same per-cloud grid sizes as the
+ * one-cloud entry points, hence bit-identical results per cloud.  Per-cloud arguments are HOST arrays (of device pointers / sizes) of
+ * length nb <= 16; clouds with n = 0 are skipped.  hipCUB's radix sort becomes a single-workgroup LDS sort per cloud (the cell keys re-coded
+ * as a 32-bit lexicographic rank, packed with the index: stable, the same permutation), its select / scan calls a single-workgroup ordered
+ * compaction / scan per cloud. */
+size_t ape_pc_batch_workspace_bytes(int nb, long n_total);
+/* label[c] / depth[c] [H][W]; intr4_host [nb][4] = fx, fy, ppx, ppy; T16_host [nb][16]; points[c] capacity H*W rows;
+ * n_out [nb] on the device; pix_ws: nb * H * W ints of scratch */
+int ape_surface_points_batch_f64(int nb, const uint8_t* const* label, const uint16_t* const* depth, int H, int W, const double* intr4_host,
+                                 const double* T16_host, double* const* points, int* n_out, int* pix_ws, void* stream);
+int ape_voxel_down_sample_batch_f64(int nb, const double* const* pts, const int* n, double voxel, double* const* out, int* n_out, void* ws,
+                                    size_t ws_bytes, void* stream);
+int ape_grid_build_batch_f64(int nb, const double* const* pts, const int* n, double cell, double* const* sorted, unsigned long long* const* keys,
+                             unsigned* const* order, double* const* origin3, void* ws, size_t ws_bytes, void* stream);
+/* op 0: ape_grid_radius_count_f64 (count[c][nq[c]]); op 1: ape_grid_normals_f64 (normals[c][nq[c]][3], max_nn); op 2:
+ * ape_grid_knn_mean_dist_f64 (mean[c][gn[c]], k; q / nq unused) */
+int ape_grid_query_batch_f64(int op, int nb, const double* const* sorted, const unsigned long long* const* keys, const unsigned* const* order,
+                             const double* const* origin3, const int* gn, double cell, const double* const* q, const int* nq, double radius,
+                             int max_nn_or_k, int* const* count, double* const* normals, double* const* mean, void* stream);
+/* ape_select_points_f64 with the keep rule evaluated on the device: mode 0 count[c][i] > thr_count (RemoveRadiusOutliers), mode 1
+ * mean[c][i] > 0 && mean[c][i] < thr_mean_host[c] (RemoveStatisticalOutliers); sel_ws: sum n ints; n_out [nb] on the device */
+int ape_select_points_batch_f64(int mode, int nb, const double* const* pts, const int* n, const int* const* count, int thr_count,
+                                const double* const* mean, const double* thr_mean_host, double* const* out, int* n_out, int* sel_ws, void* stream);
+/* ape_icp_sums_f64(kind 2): out9 [nb][9] on the device; ws: nb * 512 * 9 doubles */
+int ape_moments_batch_f64(int nb, const double* const* pts, const int* n, double* out9, void* ws, size_t ws_bytes, void* stream);
+int ape_mahalanobis_batch_f64(int nb, const double* const* pts, const int* n, const double* mc12_host, double* const* out, void* stream);
+int ape_transform_points_batch_f64(int nb, double* const* pts, double* const* normals, const int* n, const double* T16_host, void* stream);
+/* out[c] = [a[c] | b[c]] (b may be NULL: copies) */
+int ape_concat_points_batch_f64(int nb, const double* const* a, const int* na, const double* const* b, const int* nb_rows, double* const* out,
+                                void* stream);
+/* ape_icp_run_f64 for nb registrations of one kind advancing together (state[c]: 40 doubles on the device each); ws: nb * 512 * 29 doubles */
+int ape_icp_run_batch_f64(int kind, int nb, const double* const* sorted, const unsigned long long* const* keys, const unsigned* const* order,
+                          const double* const* origin3, const int* gn, double cell, double* const* src, const int* ns, const double* const* tgt,
+                          const double* const* tgt_normals, double max_dist, double rel_fitness, double rel_rmse, int max_iteration, int n_iter,
+                          int first_call, int* const* corr, double* const* dist2, double* const* sums, double* const* state, void* ws,
+                          size_t ws_bytes, void* stream);
+
 /* ape_conv3x3_halo_bf16 for a 64-channel layer (the segmentor's up_3, pspnet.py:51) with ape_seg_head_f32 fused into its
  * epilogue: the [B][H][W][64] activation is never written, label[B][H][W] u8 / score[B][H][W] f32 are (bit-identical to the
  * unfused pair).  params->Cout must be 64, no residual; params->ups as in ape_conv3x3_halo_bf16. */

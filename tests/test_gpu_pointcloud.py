@@ -267,3 +267,79 @@ def test_get_surface_and_sequential_fusion():
         # T . err ~ identity up to the weakly constrained rotation of a near-spherical object and the reference's loose
         # convergence criteria (relative_fitness = relative_rmse = 1e-2, open3d_utils.py:76-78)
         assert np.abs((T @ err)[:3, :3] - np.eye(3)).max() < 0.05
+
+
+def test_batched_primitives_equal_the_one_cloud_methods_bitwise():
+    """pc_reconstruction/batched.py (one launch advances many clouds, blockIdx.y = cloud) against the PointCloud methods, cloud by cloud and
+    bit for bit: uneven sizes, an EMPTY cloud in the batch, more clouds than one launch takes (16), every primitive of the label path"""
+    import torch
+    from autoposeestimation_amd.pc_reconstruction import batched as B
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    rng = np.random.default_rng(7)
+    sizes = [1500, 0, 3100, 777, 2048] + [400 + 37 * i for i in range(14)]          # 19 clouds
+    clouds = []
+    for i, n in enumerate(sizes):
+        v = rng.standard_normal((n, 3))
+        v /= np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-9)
+        clouds.append(PC.PointCloud(v * (40.0 + i) + rng.standard_normal((n, 3)) * 0.7 + np.array([300.0, 10.0 * i, 100.0])))
+    eq = lambda a, b: a.shape == b.shape and torch.equal(a, b)  # noqa: E731
+    down = B.voxel_down_sample(clouds, 3.0)
+    want_down = [c.voxel_down_sample(3.0) for c in clouds]
+    assert all(eq(a._p, b._p) for a, b in zip(down, want_down))
+    rad = B.remove_radius_outlier(want_down, 3, 7.0)
+    want_rad = [c.remove_radius_outlier(3, 7.0)[0] for c in want_down]
+    assert all(eq(a._p, b._p) for a, b in zip(rad, want_rad)) and any(len(a) < len(b) for a, b in zip(rad, want_down))
+    maha = B.mahalanobis(want_rad)
+    for m, c in zip(maha, want_rad):
+        assert np.array_equal(m, c.compute_mahalanobis_distance())
+    ratios = [float(np.abs(np.std(np.abs(m)))) if len(m) else 0.0 for m in maha]
+    stat = B.remove_statistical_outlier(want_rad, 8, ratios, 9.0)
+    want_stat = [c.remove_statistical_outlier(8, r, cell_hint=9.0)[0] for c, r in zip(want_rad, ratios)]
+    assert all(eq(a._p, b._p) for a, b in zip(stat, want_stat))
+    nb = B.estimate_normals([c.clone() for c in want_stat], 8.0, 30)
+    want_n = [c.clone().estimate_normals(radius=8.0, max_nn=30) for c in want_stat]
+    assert all((a._n is None and len(a) == 0) or eq(a._n, b._n) for a, b in zip(nb, want_n))
+    Ts = [_rot(0.01 * i, -0.02, 0.015, (0.3 * i, -0.2, 0.1)) for i in range(len(clouds))]
+    moved = B.transform(B.concat(want_stat), Ts)
+    want_m = [c.clone().transform(T) for c, T in zip(want_stat, Ts)]
+    assert all(eq(a._p, b._p) for a, b in zip(moved, want_m))
+    cat = B.concat(moved, want_stat)
+    assert all(eq(a._p, torch.cat([m._p, s._p], 0)) for a, m, s in zip(cat, want_m, want_stat))
+    # both estimators, pairs that need different numbers of iterations, an empty source in the batch
+    crit = PC.ICPConvergenceCriteria(relative_fitness=1e-2, relative_rmse=1e-2, max_iteration=100)
+    for kind, est in ((0, PC.TransformationEstimationPointToPoint()), (1, PC.TransformationEstimationPointToPlane())):
+        got = B.registration_icp(want_m, want_n, 6.0, [None] * len(clouds), kind, crit)
+        for g, s, t in zip(got, want_m, want_n):
+            w = PC.registration_icp(s, t, 6.0, None, est, crit).transformation if len(s) and len(t) else np.eye(4)
+            assert np.array_equal(g, w)
+
+
+@pytest.mark.gpu
+def test_batched_sort_general_form_equals_hipcub_order():
+    """the batched path's sort has three forms: cell ranks packed into LDS words (one run: <= 16 k points), several such runs merged by
+    rank (<= 128 k points), and the general (key, index) network over global memory (more points, or >= 2^46 cells).  A 20 k- and a
+    40 k-point cloud, a 140 k-point one, a cloud spread over 1e17 cells of the voxel size, a cloud of EXACTLY 16384 points, 16385 points
+    and one with many duplicate cells: voxel sample and search grid equal the one-cloud (hipCUB sort) results."""
+    import torch
+    from autoposeestimation_amd.pc_reconstruction import batched as B
+    from autoposeestimation_amd.pc_reconstruction import pointcloud as PC
+    rng = np.random.default_rng(11)
+    clouds = [PC.PointCloud(rng.uniform(-60, 60, (20000, 3))),
+              PC.PointCloud(rng.uniform(-40, 40, (40000, 3))),
+              PC.PointCloud(rng.uniform(-90, 90, (140000, 3))),
+              PC.PointCloud(rng.uniform(0, 33, (16385, 3))),
+              PC.PointCloud(rng.uniform(-5e5, 5e5, (3000, 3))),                       # 5e5 cells per axis at voxel 2 -> 1e17 cells
+              PC.PointCloud(rng.uniform(0, 80, (16384, 3))),
+              PC.PointCloud(np.repeat(rng.uniform(0, 30, (50, 3)), 40, axis=0) + rng.uniform(0, 0.5, (2000, 3))),
+              PC.PointCloud(rng.uniform(0, 10, (1, 3)))]
+    for voxel in (2.0, 7.5):
+        got = B.voxel_down_sample(clouds, voxel)
+        for g, c in zip(got, clouds):
+            w = c.voxel_down_sample(voxel)
+            assert g._p.shape == w._p.shape and torch.equal(g._p, w._p)
+    grids = B.build_grids(clouds, 4.0)
+    for g, c in zip(grids, clouds):
+        c._gcache = None
+        w = c._grid(4.0)
+        for k in ("sorted", "keys", "order", "origin"):
+            assert torch.equal(g[k], w[k]), k
