@@ -31,6 +31,8 @@ SIGNATURES = {
     "ape_conv3x3_halo_s32_debug": [_I],
     "ape_conv_gemm_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
     "ape_conv_gemm_bf16_fmt": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
+    "ape_conv_gemm_splitk_workspace_bytes": [_P],
+    "ape_conv_gemm_bf16_splitk": [_P, _P, _P, _P, _P, _P, _I, _P, _c.c_size_t, _P],
     "ape_adaptive_avgpool_multi_nhwc_fmt": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_upconv3x3_gather_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "ape_conv3x3_halo_s32_supported": [_P],
@@ -83,6 +85,9 @@ SIGNATURES = {
     "ape_mean_rows_bwd_f32": [_P, _P, _I, _I, _I, _P],
     "ape_adds_grad_f32": [_P] * 9 + [_I, _I, _I, _I, _F, _P, _P, _P, _P],
     "ape_adam_step_f32": [_P, _P, _P, _P, _c.c_long, _F, _F, _F, _F, _I, _F, _P],
+    "ape_adam_step_multi_f32": [_I, _P, _F, _F, _F, _F, _F, _P],
+    "ape_pack_train_weights": [_I, _P, _c.c_long, _P],
+    "ape_conv2d_wgrad_param_f32": [_P, _P, _P, _P, _I, _P, _c.c_size_t, _P],
     "ape_label_trust_counts": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ape_choose_points": [_P, _P, _P, _I, _I, _I, _I, _c.c_uint, _P, _c.c_long, _P, _P, _P],
     "ape_backproject_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
@@ -116,6 +121,18 @@ SIGNATURES = {
 }
 
 
+class AdamJob(_c.Structure):
+    """Mirror of `ape_adam_job` (include/ape_hip.h)."""
+    _fields_ = [("param", _c.c_void_p), ("grad", _c.c_void_p), ("exp_avg", _c.c_void_p), ("exp_avg_sq", _c.c_void_p), ("n", _c.c_long),
+                ("bc1", _c.c_float), ("bc2_sqrt", _c.c_float)]
+
+
+class PackJob(_c.Structure):
+    """Mirror of `ape_pack_job` (include/ape_hip.h)."""
+    _fields_ = [("src", _c.c_void_p), ("dst_f32", _c.c_void_p), ("dst_bf16", _c.c_void_p), ("cout", _c.c_int32), ("cin", _c.c_int32),
+                ("taps", _c.c_int32), ("transpose", _c.c_int32)]
+
+
 class ConvParams(_c.Structure):
     """Mirror of `ape_conv_params` (include/ape_hip.h)."""
     _fields_ = [(n, _c.c_int32) for n in ("B", "H", "W", "Cin", "ldx", "xoff", "Ho", "Wo", "Cout", "ldy", "yoff",
@@ -126,7 +143,7 @@ class ConvParams(_c.Structure):
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 _RESTYPES = {"ape_last_error": _c.c_char_p, "ape_adaptive_avgpool_multi_workspace_bytes": _c.c_size_t, "ape_seg_components_workspace_bytes": _c.c_size_t,
              "ape_packed_weights_bf16_elems": _c.c_long, "ape_pc_workspace_bytes": _c.c_size_t, "ape_pc_batch_workspace_bytes": _c.c_size_t,
-             "ape_conv2d_wgrad_workspace_bytes": _c.c_size_t}
+             "ape_conv2d_wgrad_workspace_bytes": _c.c_size_t, "ape_conv_gemm_splitk_workspace_bytes": _c.c_size_t}
 
 _lib = None
 

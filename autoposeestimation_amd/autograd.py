@@ -7,6 +7,7 @@ weights stay in the reference's parameter layout ([Cout,Cin,KH,KW] / [Cout,Cin,1
 see the reference's tensors.  No CPU fallback: host tensors raise in _lib.dptr.
 """
 import ctypes
+import math
 
 import torch
 
@@ -39,19 +40,107 @@ def colsum(x2d_rows, c, ld, off, like):
     return out
 
 
-def conv_wgrad(x, dy, cout, kh, kw, stride, pad, dil):
-    """x[B,H,W,Cx] (Cx % 4 == 0), dy[B,Ho,Wo,Cout] -> dw[Cout,KH,KW,Cx]"""
+def conv_wgrad(x, dy, cout, kh, kw, stride, pad, dil, param_shape=None):
+    """x[B,H,W,Cx] (Cx % 4 == 0), dy[B,Ho,Wo,Cout] -> dw[Cout,KH,KW,Cx], or -- with `param_shape` ([Cout,Cin,...], the reference's
+    parameter) -- directly the parameter's gradient in ITS layout (the reduction pass writes it, no permute copy)"""
     b, h, w, cx = x.shape
     _, ho, wo, ldy = dy.shape
     p = _lib.ConvParams(B=b, H=h, W=w, Cin=cx, ldx=cx, xoff=0, Ho=ho, Wo=wo, Cout=cout, ldy=ldy, yoff=0, KH=kh, KW=kw,
                         stride=stride, pad=pad, dil=dil, act=0, alpha=0.0, bias_bstride=0, ldr=0, roff=0, ups=0)
     nbytes = _lib.lib().ape_conv2d_wgrad_workspace_bytes(ctypes.byref(p))
     ws = _ws(nbytes, x.device)
+    if param_shape is not None:
+        dw = torch.empty(param_shape, dtype=torch.float32, device=x.device)
+        rc = _lib.lib().ape_conv2d_wgrad_param_f32(_lib.dptr(x, torch.float32), _lib.dptr(dy, torch.float32), _lib.dptr(dw), ctypes.byref(p),
+                                                   int(param_shape[1]), _lib.dptr(ws), ws.numel(), _st())
+        _lib.check(rc, "ape_conv2d_wgrad_param_f32")
+        return dw
     dw = torch.empty(cout, kh, kw, cx, dtype=torch.float32, device=x.device)
     rc = _lib.lib().ape_conv2d_wgrad_nhwc_f32(_lib.dptr(x, torch.float32), _lib.dptr(dy, torch.float32), _lib.dptr(dw), ctypes.byref(p),
                                               _lib.dptr(ws), ws.numel(), _st())
     _lib.check(rc, "ape_conv2d_wgrad_nhwc_f32")
     return dw
+
+
+class WeightBank:
+    """The conv kernels' operands of ONE parameter, kept while the parameter does not change ("keep packed weights
+    until optimizer.step()"): the forward form ([Cout,KH,KW,Cin4] f32 + split-bf16 planes) and the input-gradient form (flipped taps,
+    channels transposed).  Both are written by ONE launch of ape_pack_train_weights from the parameter's own storage; `Adam.step()`
+    re-packs the banks of all its parameters in one further launch right after the update.  A bank is stale when the parameter's
+    torch version counter moved (load_state_dict, a torch optimizer, any in-place op) -- it is then rebuilt on the next use."""
+
+    def __init__(self, weight, precision):
+        w = weight.detach()
+        if not w.is_cuda:
+            raise ValueError("the training path needs its parameters in device memory (no CPU fallback)")
+        own = w.dtype == torch.float32 and w.is_contiguous()
+        if not own:                    # a strided slice of a parameter (the per-object head rows / column blocks): packed from a copy, per call
+            w = w.float().contiguous()
+        self.src = w
+        self.version = weight._version if own else None
+        self.precision = precision
+        nsplit = {"f32": 0, "bf16x3": 3, "bf16": 1}[precision]
+        shape = tuple(w.shape) + (1,) * (4 - w.dim())
+        self.cout, self.cin, self.kh, self.kw = shape
+        taps = self.kh * self.kw
+        dev = w.device
+        self.ops = []
+        jobs = (_lib.PackJob * 2)()
+        self.max_elems = 0
+        for tr, (n, c) in enumerate(((self.cout, self.cin), (self.cin, self.cout))):
+            c4 = (c + 3) // 4 * 4
+            kp = (taps * c4 + 7) // 8 * 8
+            wf = torch.empty(n, self.kh, self.kw, c4, dtype=torch.float32, device=dev)
+            wp = torch.empty(2 * n * kp, dtype=torch.bfloat16, device=dev) if nsplit else None
+            self.ops.append((wf, wp, c))
+            jobs[tr] = _lib.PackJob(src=w.data_ptr(), dst_f32=wf.data_ptr(), dst_bf16=wp.data_ptr() if nsplit else None, cout=self.cout,
+                                    cin=self.cin, taps=taps, transpose=tr)
+            self.max_elems = max(self.max_elems, n * kp)
+        self.jobs = jobs
+        self.convs = {}
+        self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.refresh()
+
+    def refresh(self):
+        _lib.check(_lib.lib().ape_pack_train_weights(2, _lib.dptr(self.table), self.max_elems, _st()), "ape_pack_train_weights")
+
+    def conv(self, transposed, stride, pad, dil, act):
+        key = (transposed, stride, pad, dil, act)
+        c = self.convs.get(key)
+        if c is None:
+            wf, wp, c_real = self.ops[1 if transposed else 0]
+            c = self.convs[key] = E.Conv.from_packed(wf, wp, c_real, stride, pad, dil, act, precision=self.precision)
+        return c
+
+
+def weight_bank(weight, precision):
+    bank = getattr(weight, "_ape_bank", None)
+    if (bank is None or bank.version is None or bank.version != weight._version or bank.precision != precision
+            or bank.src.data_ptr() != weight.data_ptr()):
+        bank = WeightBank(weight, precision)
+        try:
+            weight._ape_bank = bank
+        except AttributeError:
+            pass
+    return bank
+
+
+def refresh_banks(params):
+    """re-pack the operands of every parameter in `params` that has a bank: one launch (their job tables concatenated once and kept)"""
+    banks = [b for b in (getattr(p, "_ape_bank", None) for p in params) if b is not None and b.version is not None]
+    if not banks:
+        return
+    key = tuple(id(b) for b in banks)
+    cache = refresh_banks.cache
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) >= 8:
+            cache.clear()
+        hit = cache[key] = (torch.cat([b.table for b in banks]), max(b.max_elems for b in banks), banks)
+    _lib.check(_lib.lib().ape_pack_train_weights(2 * len(banks), _lib.dptr(hit[0]), hit[1], _st()), "ape_pack_train_weights")
+
+
+refresh_banks.cache = {}
 
 
 def _w4(weight):
@@ -69,12 +158,14 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, pad, dil, act, precision):
-        conv = E.Conv(weight.detach(), None, stride, pad, dil, act, device=x.device, precision=precision)
+        bank = weight_bank(weight, precision)
+        conv = bank.conv(False, stride, pad, dil, act)
         if x.shape[3] != conv.cin:
             raise ValueError("input has %d channels, the packed weight expects %d" % (x.shape[3], conv.cin))
         bflat = None if bias is None else _c(bias.detach().reshape(-1).float())
-        y = conv(_c(x), residual=None if residual is None else _c(residual), bias=bflat)
+        y = conv(_c(x), residual=None if residual is None else _c(residual), bias=bflat, splitk=True)
         ctx.cfg = (stride, pad, dil, act, precision, tuple(weight.shape), None if bias is None else tuple(bias.shape))
+        ctx.bank = bank
         ctx.save_for_backward(x, weight, y if act != E.ACT_NONE else None)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         return y
@@ -83,23 +174,21 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         stride, pad, dil, act, precision, wshape, bshape = ctx.cfg
         x, weight, y = ctx.saved_tensors
+        bank = ctx.bank
         dy = _c(dy)
         dpre = act_bwd(dy, y, act) if act != E.ACT_NONE else dy
         b, ho, wo, cout = dpre.shape
-        w4 = _w4(weight.detach())
-        _, cin, kh, kw = w4.shape
+        cin, kh, kw = bank.cin, bank.kh, bank.kw
         dx = dw = db = dres = None
         if ctx.needs_input_grad[1]:
-            dwp = conv_wgrad(_c(x), dpre, cout, kh, kw, stride, pad, dil)                        # [Cout,KH,KW,Cx]
-            dw = dwp[..., :cin].permute(0, 3, 1, 2).reshape(wshape)
+            dw = conv_wgrad(_c(x), dpre, cout, kh, kw, stride, pad, dil, param_shape=wshape)       # the parameter's layout
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(b * ho * wo, cout, cout, 0, dpre).reshape(bshape)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dpre
         if ctx.needs_input_grad[0]:
-            # input gradient = forward conv of (zero-stuffed) dpre with the flipped, transposed weights
+            # input gradient = forward conv of (zero-stuffed) dpre with the flipped, transposed weights (the bank's second operand)
             _, h, w_, cx = x.shape
-            wt = w4.flip(2, 3).permute(1, 0, 2, 3)                                               # [Cin,Cout,KH,KW]
             lh, lw = h - dil * (kh - 1) + 2 * pad, w_ - dil * (kw - 1) + 2 * pad
             if stride == 1 and cout % 4 == 0:
                 src = dpre
@@ -107,9 +196,9 @@ class ConvFn(torch.autograd.Function):
                 c4 = (cout + 3) // 4 * 4
                 src = torch.zeros(b, lh, lw, c4, dtype=torch.float32, device=dy.device)
                 src[:, ::stride, ::stride][:, :ho, :wo, :cout] = dpre
-            back = E.Conv(wt, None, 1, dil * (kh - 1) - pad, dil, E.ACT_NONE, device=dy.device, precision=precision)
+            back = bank.conv(True, 1, dil * (kh - 1) - pad, dil, E.ACT_NONE)
             dx = torch.zeros(b, h, w_, cx, dtype=torch.float32, device=dy.device) if cx != cin else None
-            dx = back(src, out=dx)
+            dx = back(src, out=dx, splitk=True)
         return dx, dw, db, dres, None, None, None, None, None
 
 
@@ -325,15 +414,27 @@ class Adam:
 
     @torch.no_grad()
     def step(self):
-        for p in self.params:
-            if p.grad is None:
-                continue
-            st = self.state.setdefault(p, {"step": 0, "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)})
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            return
+        jobs = (_lib.AdamJob * len(live))()
+        keep = []
+        b1, b2 = ctypes.c_float(self.betas[0]).value, ctypes.c_float(self.betas[1]).value      # the float32 values the kernel multiplies with
+        for i, p in enumerate(live):
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)}
             st["step"] += 1
-            g = _c(p.grad.float())
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = _c(g.float())
+                keep.append(g)
             if not p.data.is_contiguous():
                 raise RuntimeError("Adam needs contiguous parameters")
-            rc = _lib.lib().ape_adam_step_f32(_lib.dptr(p.data, torch.float32), _lib.dptr(g), _lib.dptr(st["exp_avg"]),
-                                              _lib.dptr(st["exp_avg_sq"]), p.numel(), float(self.lr), float(self.betas[0]),
-                                              float(self.betas[1]), float(self.eps), st["step"], float(self.weight_decay), _st())
-            _lib.check(rc, "ape_adam_step_f32")
+            jobs[i] = _lib.AdamJob(param=_lib.dptr(p.data, torch.float32), grad=_lib.dptr(g), exp_avg=_lib.dptr(st["exp_avg"]),
+                                   exp_avg_sq=_lib.dptr(st["exp_avg_sq"]), n=p.numel(), bc1=1.0 - b1 ** st["step"],
+                                   bc2_sqrt=math.sqrt(1.0 - b2 ** st["step"]))
+        rc = _lib.lib().ape_adam_step_multi_f32(len(live), jobs, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                float(self.weight_decay), _st())
+        _lib.check(rc, "ape_adam_step_multi_f32")
+        refresh_banks(live)          # the conv operands of the updated parameters, one launch

@@ -98,6 +98,22 @@ __global__ void split_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// the same fixed-order sum, written in the PARAMETER layout [Cout][cin][taps] (ws: [split][Cout][taps][cx])
+__global__ void split_reduce_param_kernel(const float* __restrict__ ws, float* __restrict__ out, int cout, int cin, int taps, int cx, int splits)
+{
+    const long n = (long)cout * cin * taps, nws = (long)cout * taps * cx;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const long r = i / taps;
+        const int ci = (int)(r % cin);
+        const long co = r / cin;
+        const long j = (co * taps + t) * cx + ci;
+        float s = ws[j];
+        for (int k = 1; k < splits; ++k) s += ws[(long)k * nws + j];
+        out[i] = s;
+    }
+}
+
 static int wgrad_splits(const ape_conv_params& p, int ncols, long npix)
 {
     const long tiles = (long)ape::ceil_div(ncols, WG_N) * ape::ceil_div(p.Cout, WG_M);
@@ -326,6 +342,56 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// the same update for up to kAdamJobs parameter buffers in ONE launch (blockIdx.y = buffer)
+constexpr int kAdamJobs = 64;
+struct AdamBatch { ape_adam_job j[kAdamJobs]; };
+__global__ void adam_multi_kernel(const AdamBatch b, float lr, float b1, float b2, float eps, float wd)
+{
+    const ape_adam_job& a = b.j[blockIdx.y];
+    float* __restrict__ p = a.param;
+    const float* __restrict__ g = a.grad;
+    float* __restrict__ m = a.exp_avg;
+    float* __restrict__ v = a.exp_avg_sq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (wd != 0.f) gi += wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / a.bc2_sqrt + eps;
+        p[i] -= (lr / a.bc1) * (mi / denom);
+    }
+}
+
+// parameter layout [Cout][Cin][taps] -> the conv kernels' operand layouts, many parameters per launch (blockIdx.y = job):
+// f32 [N][taps][C4] and the split-bf16 planes hi [N][Kp] | lo [N][Kp] (K = taps * C4, Kp = K rounded up to 8, zero padded).
+// transpose = 0: N = Cout, C = Cin (the forward operand); 1: N = Cin, C = Cout with the taps reversed = the flipped, transposed
+// weights whose forward conv is the input gradient.
+__global__ void pack_train_weights_kernel(const ape_pack_job* __restrict__ jobs)
+{
+    const ape_pack_job a = jobs[blockIdx.y];
+    const int N = a.transpose ? a.cin : a.cout, C = a.transpose ? a.cout : a.cin;
+    const int C4 = (C + 3) / 4 * 4, K = a.taps * C4, Kp = (K + 7) / 8 * 8;
+    const long total = (long)N * Kp;
+    __bf16* hi = (__bf16*)a.dst_bf16;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long n = i / Kp;
+        float v = 0.f;
+        if (k < K) {
+            const int t = k / C4, c = k - t * C4;
+            if (c < C) v = a.transpose ? a.src[((long)c * a.cin + n) * a.taps + (a.taps - 1 - t)] : a.src[(n * a.cin + c) * a.taps + t];
+            a.dst_f32[n * K + k] = v;
+        }
+        if (hi) {
+            const __bf16 h = (__bf16)v;
+            hi[i] = h;
+            hi[total + i] = (__bf16)(v - (float)h);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t ape_conv2d_wgrad_workspace_bytes(const ape_conv_params* params)
@@ -337,21 +403,21 @@ extern "C" size_t ape_conv2d_wgrad_workspace_bytes(const ape_conv_params* params
     return (size_t)wgrad_splits(p, ncols, npix) * p.Cout * ncols * sizeof(float) + 256;
 }
 
-/* dw[Cout][KH][KW][Cin] (Cin % 4 == 0, the packed forward layout) = sum over the B*Ho*Wo output pixels */
-extern "C" int ape_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, const ape_conv_params* params, void* workspace,
-                                         size_t workspace_bytes, void* stream)
+static int wgrad_run(const float* x, const float* dy, float* dw, const ape_conv_params* params, int cin_param, void* workspace,
+                     size_t workspace_bytes, void* stream, const char* what)
 {
     if (!x || !dy || !dw || !params || !workspace) return APE_EINVAL;
     const ape_conv_params& p = *params;
     if (p.B < 0 || p.H < 1 || p.W < 1 || p.Ho < 1 || p.Wo < 1 || p.Cin < 4 || p.Cin % 4 || p.Cout < 1 || p.KH < 1 || p.KW < 1 ||
         p.stride < 1 || p.dil < 1 || p.pad < 0 || p.ldx % 4 || p.xoff % 4 || p.xoff + p.Cin > p.ldx || p.yoff + p.Cout > p.ldy)
         return APE_EINVAL;
+    if (cin_param > p.Cin) return APE_EINVAL;
     if ((p.H + 2 * p.pad - p.dil * (p.KH - 1) - 1) / p.stride + 1 != p.Ho || (p.W + 2 * p.pad - p.dil * (p.KW - 1) - 1) / p.stride + 1 != p.Wo)
         return APE_EINVAL;
     if (workspace_bytes < ape_conv2d_wgrad_workspace_bytes(params)) return APE_EWORKSPACE;
     const int ncols = p.KH * p.KW * p.Cin;
     const long npix = (long)p.B * p.Ho * p.Wo;
-    const long nw = (long)p.Cout * ncols;
+    const long nw = cin_param > 0 ? (long)p.Cout * cin_param * p.KH * p.KW : (long)p.Cout * ncols;
     hipStream_t st = (hipStream_t)stream;
     if (npix == 0) {
         if (hipMemsetAsync(dw, 0, nw * sizeof(float), st) != hipSuccess) { ape::set_last_error("hipMemsetAsync"); return APE_ELAUNCH; }
@@ -363,8 +429,26 @@ extern "C" int ape_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float*
     float* ws = (float*)workspace;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(ape::ceil_div(ncols, WG_N), ape::ceil_div(p.Cout, WG_M), splits), dim3(kT), 0, st, x, dy,
                        ws, p, ncols, npix, pps);
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(grid_for(nw)), dim3(kT), 0, st, ws, dw, nw, splits);
-    return ape::check_launch("ape_conv2d_wgrad_nhwc_f32");
+    if (cin_param > 0)
+        hipLaunchKernelGGL(split_reduce_param_kernel, dim3(grid_for(nw)), dim3(kT), 0, st, ws, dw, p.Cout, cin_param, p.KH * p.KW, p.Cin, splits);
+    else
+        hipLaunchKernelGGL(split_reduce_kernel, dim3(grid_for(nw)), dim3(kT), 0, st, ws, dw, nw, splits);
+    return ape::check_launch(what);
+}
+
+/* dw[Cout][KH][KW][Cin] (Cin % 4 == 0, the packed forward layout) = sum over the B*Ho*Wo output pixels */
+extern "C" int ape_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, const ape_conv_params* params, void* workspace,
+                                         size_t workspace_bytes, void* stream)
+{
+    return wgrad_run(x, dy, dw, params, 0, workspace, workspace_bytes, stream, "ape_conv2d_wgrad_nhwc_f32");
+}
+
+/* the same sums written as the reference's PARAMETER: dw[Cout][cin_param][KH][KW], cin_param <= Cin (the zero channels that pad x drop out) */
+extern "C" int ape_conv2d_wgrad_param_f32(const float* x, const float* dy, float* dw, const ape_conv_params* params, int cin_param,
+                                          void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (cin_param < 1) return APE_EINVAL;
+    return wgrad_run(x, dy, dw, params, cin_param, workspace, workspace_bytes, stream, "ape_conv2d_wgrad_param_f32");
 }
 
 extern "C" int ape_act_bwd_f32(const float* dy, const float* ref, float* dx, long n, int act, float alpha, void* stream)
@@ -493,4 +577,36 @@ extern "C" int ape_adam_step_f32(float* param, const float* grad, float* exp_avg
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, (float)bc1, (float)sqrt(bc2), weight_decay);
     return ape::check_launch("ape_adam_step_f32");
+}
+
+/* ape_adam_step_f32 for n parameter buffers, 64 per launch; bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step) per buffer (its own step) */
+extern "C" int ape_adam_step_multi_f32(int n, const ape_adam_job* jobs, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                       void* stream)
+{
+    if (n < 0 || (n && !jobs) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return APE_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!jobs[i].param || !jobs[i].grad || !jobs[i].exp_avg || !jobs[i].exp_avg_sq || jobs[i].n < 0 || !(jobs[i].bc1 > 0.f) || !(jobs[i].bc2_sqrt > 0.f))
+            return APE_EINVAL;
+    for (int i0 = 0; i0 < n; i0 += kAdamJobs) {
+        AdamBatch b{};
+        const int nb = n - i0 < kAdamJobs ? n - i0 : kAdamJobs;
+        long nmax = 1;
+        for (int i = 0; i < nb; ++i) { b.j[i] = jobs[i0 + i]; nmax = jobs[i0 + i].n > nmax ? jobs[i0 + i].n : nmax; }
+        int gx = grid_for(nmax);
+        gx = gx > 256 ? 256 : gx;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, nb), dim3(kT), 0, (hipStream_t)stream, b, lr, beta1, beta2, eps, weight_decay);
+    }
+    return ape::check_launch("ape_adam_step_multi_f32");
+}
+
+/* n jobs (DEVICE array) of parameter -> conv operand repacking in one launch; max_elems = the largest N * Kp among them */
+extern "C" int ape_pack_train_weights(int n, const ape_pack_job* jobs_device, long max_elems, void* stream)
+{
+    if (n < 0 || (n && !jobs_device) || max_elems < 0) return APE_EINVAL;
+    if (n == 0 || max_elems == 0) return APE_OK;
+    int gx = grid_for(max_elems);
+    gx = gx > 128 ? 128 : gx;
+    for (int i0 = 0; i0 < n; i0 += 65535)
+        hipLaunchKernelGGL(pack_train_weights_kernel, dim3(gx, n - i0 < 65535 ? n - i0 : 65535), dim3(kT), 0, (hipStream_t)stream, jobs_device + i0);
+    return ape::check_launch("ape_pack_train_weights");
 }

@@ -36,6 +36,8 @@ struct GemmArgs {
     int out_fmt;       // APE_FMT_F32 | APE_FMT_S32 (pre-split output for the S32 consumers; needs ldy % 32 == 0 and the vector path)
     int dbg;           // ablation bits (timing experiments only, results are wrong): 1 no in-loop global loads, 2 no in-loop LDS restage, 4 no MFMAs
     long plane_stride;
+    int nk_per;        // split-K (training tape, small M): blockIdx.y takes k-tiles [y * nk_per, ...) and writes RAW sums to y + blockIdx.y * split_stride; 0 = off
+    long split_stride;
 };
 
 // NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
@@ -138,6 +140,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     u32x4 breg[NPL][B_IT];
     unsigned a_ok = 0;                       // bit i: item i of the tile held in registers lies inside the image
     int t_ci0 = 0, t_ky = 0, t_kx = 0;       // (chunk, tap) of the NEXT tile to load; K order = chunk outer, taps inner
+    const int kt0 = a.nk_per ? (int)blockIdx.y * a.nk_per : 0;
+    if (a.nk_per) {
+        if (PURE) {
+            t_ci0 = kt0 * BK;
+        } else {
+            const int taps = p.KH * p.KW, chunk = kt0 / taps, tap = kt0 - chunk * taps;
+            t_ci0 = chunk * BK;
+            t_ky = tap / p.KW;
+            t_kx = tap - t_ky * p.KW;
+        }
+    }
+    float* const yb = a.nk_per ? a.y + (size_t)blockIdx.y * a.split_stride : a.y;
     auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
     auto load_tiles = [&]() {
         unsigned kb;
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             }
     };
 
-    const int nk = a.nk;
+    const int nk = a.nk_per ? (a.nk - kt0 < a.nk_per ? a.nk - kt0 : a.nk_per) : a.nk;
     // 8-wave blocks: dbg bit 8 = static priority 1 for waves 4-7 (cf. conv_gemm_s32.hip)
     if (NT == 512 && (a.dbg & 8) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     load_tiles();
@@ -314,14 +328,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
                     const float4 o4 = sigm ? make_float4(activate(vv[0], p.act, p.alpha), activate(vv[1], p.act, p.alpha), activate(vv[2], p.act, p.alpha),
                                                          activate(vv[3], p.act, p.alpha))
                                            : make_float4(ape::act_fast(vv[0], af), ape::act_fast(vv[1], af), ape::act_fast(vv[2], af), ape::act_fast(vv[3], af));
-                    if (a.out_fmt == APE_FMT_S32) ape::s32_store4(a.y, (long)m, p.ldy / 4, (p.yoff + n) / 4, o4);
-                    else *reinterpret_cast<float4*>(a.y + (size_t)m * p.ldy + p.yoff + n) = o4;
+                    if (a.out_fmt == APE_FMT_S32) ape::s32_store4(yb, (long)m, p.ldy / 4, (p.yoff + n) / 4, o4);
+                    else *reinterpret_cast<float4*>(yb + (size_t)m * p.ldy + p.yoff + n) = o4;
                 } else {
                     for (int k = 0; k < nvalid; ++k) {
                         float t = vv[k];
                         if (a.bias) t += (brow ? brow : a.bias)[n + k];
                         if (a.res) t += a.res[(size_t)m * p.ldr + p.roff + n + k];
-                        a.y[(size_t)m * p.ldy + p.yoff + n + k] = activate(t, p.act, p.alpha);
+                        yb[(size_t)m * p.ldy + p.yoff + n + k] = activate(t, p.act, p.alpha);
                     }
                 }
             }
@@ -334,10 +348,41 @@ void launch(GemmArgs& a, bool pure, hipStream_t st)
 {
     a.m_tiles = ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.p.Cout, BN);
+    const int gy = a.nk_per ? ape::ceil_div(a.nk, a.nk_per) : 1;
     if (pure)
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true, PP>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true, PP>), dim3(a.m_tiles * a.n_tiles, gy), dim3(WM * WN * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false, PP>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false, PP>), dim3(a.m_tiles * a.n_tiles, gy), dim3(WM * WN * 64), 0, st, a);
+}
+
+// split-K second pass: y = act(sum over the splits (fixed order) + bias + residual)
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, int splits, long M, int Cout, const float* __restrict__ bias, int bias_bstride,
+                                     int HoWo, const float* __restrict__ res, int ldr, int roff, float* __restrict__ y, int ldy, int yoff, int act,
+                                     float alpha)
+{
+    const long n = M * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / Cout;
+        const int c = (int)(i - m * Cout);
+        float v = ws[i];
+        for (int k = 1; k < splits; ++k) v += ws[(long)k * n + i];
+        if (bias) v += bias[(bias_bstride ? (m / HoWo) * bias_bstride : 0) + c];
+        if (res) v += res[m * ldr + roff + c];
+        y[m * ldy + yoff + c] = activate(v, act, alpha);
+    }
+}
+
+// k-tiles per split for a small-M problem on the 128 x 128 block (0: do not split)
+int splitk_tiles(const ape_conv_params& p, long M)
+{
+    const int nk = p.KH * p.KW * p.Cin / BK;
+    const long tiles = (long)ape::ceil_div(M, 128) * ape::ceil_div(p.Cout, 128);
+    if (p.Cout <= 64 || tiles >= 96 || nk < 8) return 0;
+    long splits = ape::ceil_div(256L, tiles);
+    splits = splits > nk / 4 ? nk / 4 : splits;
+    splits = splits > 32 ? 32 : splits;
+    if (splits < 2) return 0;
+    return ape::ceil_div(nk, (int)splits);
 }
 
 bool supported(const ape_conv_params& p)
@@ -391,6 +436,8 @@ extern "C" int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, cons
     a.plane_stride = (long)p.Cout * a.Kp;
     a.dbg = variant >> 4;
     a.out_fmt = out_fmt;
+    a.nk_per = 0;
+    a.split_stride = 0;
     variant &= 15;
     const bool pure = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
     hipStream_t st = (hipStream_t)stream;
@@ -417,4 +464,53 @@ extern "C" int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, cons
         if (nsplit == 3) launch<3, 128, 192, 2, 2>(a, pure, st); else launch<1, 128, 192, 2, 2>(a, pure, st);
     }
     return ape::check_launch("ape_conv_gemm_bf16");
+}
+
+/* Split-K form for the training tape's batch-1 layers (a 20 x 20 map is 4 row tiles: 4..16 workgroups walking K = 4608 alone took 89 us):
+ * the k-tiles are dealt to `splits` workgroups per output tile, raw sums go to the workspace and a second pass adds them in a fixed
+ * order with bias / residual / activation.  Same products, another summation order than ape_conv_gemm_bf16 -- the inference path
+ * never takes it.  ape_conv_gemm_splitk_workspace_bytes returns 0 when the shape is not worth splitting (use ape_conv_gemm_bf16). */
+extern "C" size_t ape_conv_gemm_splitk_workspace_bytes(const ape_conv_params* params)
+{
+    if (!params || !supported(*params)) return 0;
+    const ape_conv_params& p = *params;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    const int per = splitk_tiles(p, M);
+    if (!per) return 0;
+    const int nk = p.KH * p.KW * p.Cin / BK;
+    return (size_t)ape::ceil_div(nk, per) * M * p.Cout * sizeof(float);
+}
+
+extern "C" int ape_conv_gemm_bf16_splitk(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                                         const ape_conv_params* params, int nsplit, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!x || !w_packed || !y || !params || !workspace || (nsplit != 1 && nsplit != 3)) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (!supported(p)) return APE_EINVAL;
+    if (residual && p.roff + p.Cout > p.ldr) return APE_EINVAL;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    const size_t need = ape_conv_gemm_splitk_workspace_bytes(params);
+    if (!need) return APE_EINVAL;
+    if (workspace_bytes < need) return APE_EWORKSPACE;
+    GemmArgs a;
+    a.x = x; a.w = (const __bf16*)w_packed; a.bias = nullptr; a.res = nullptr; a.y = (float*)workspace; a.p = p;
+    a.p.ldy = p.Cout; a.p.yoff = 0; a.p.act = APE_ACT_NONE; a.p.bias_bstride = 0; a.p.ldr = 0; a.p.roff = 0;
+    a.M = (int)M;
+    const int K = p.KH * p.KW * p.Cin;
+    a.Kp = (K + 7) / 8 * 8;
+    a.nk = K / BK;
+    a.plane_stride = (long)p.Cout * a.Kp;
+    a.dbg = 0;
+    a.out_fmt = APE_FMT_F32;
+    a.nk_per = splitk_tiles(p, M);
+    a.split_stride = M * p.Cout;
+    const int splits = ape::ceil_div(a.nk, a.nk_per);
+    const bool pure = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (nsplit == 3) launch<3, 128, 128, 2, 2>(a, pure, st); else launch<1, 128, 128, 2, 2>(a, pure, st);
+    long g = (M * p.Cout + 255) / 256;
+    g = g > 4096 ? 4096 : g;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)g), dim3(256), 0, st, (const float*)workspace, splits, M, p.Cout, bias, p.bias_bstride,
+                       p.Ho * p.Wo, residual, p.ldr, p.roff, y, p.ldy, p.yoff, p.act, p.alpha);
+    return ape::check_launch("ape_conv_gemm_bf16_splitk");
 }

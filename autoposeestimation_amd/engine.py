@@ -164,6 +164,30 @@ class Conv:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.stride, self.pad, self.dil, self.act, self.alpha = stride, pad, dil, act, float(alpha)
 
+    @classmethod
+    def from_packed(cls, w, wp, cin_real, stride=1, pad=0, dil=1, act=ACT_NONE, alpha=0.0, precision="f32"):
+        """a layer over operands that are ALREADY packed (w: f32 [Cout,KH,KW,Cin4]; wp: the split-bf16 planes of the same weights, needed
+        unless precision == 'f32'): the training tape keeps them per parameter and re-packs them after each optimizer step
+        (autograd.WeightBank), instead of packing per call"""
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (PRECISIONS,))
+        self = cls.__new__(cls)
+        self.w = w
+        self.cout, self.kh, self.kw, self.cin = w.shape
+        self.cin_real = cin_real
+        self.precision = precision
+        self.nsplit = {"f32": 0, "bf16x3": 3, "bf16": 1}[precision]
+        if self.nsplit:
+            if wp is None:
+                raise ValueError("precision %s needs the packed bf16 planes" % precision)
+            self.wp = wp
+            self.variant = "conv_bf16_kernel<%d,%s>" % (self.nsplit, "128,128,2,2,64,false" if self.cout > 64 else "128,64,4,1,32,true")
+        else:
+            self.variant = "conv_f32_kernel<%s>" % ("128,2,2" if self.cout > 64 else "64,4,1" if self.cout > 32 else "32,4,1")
+        self.bias = None
+        self.stride, self.pad, self.dil, self.act, self.alpha = stride, pad, dil, act, float(alpha)
+        return self
+
     def s32k(self):
         """the weights in the S32K grouping ([Cout][K/32][hi 32 | lo 32] bf16) for the S32 consumers; built on first use"""
         ws = getattr(self, "_ws32", None)
@@ -207,7 +231,7 @@ class Conv:
         return ho, wo
 
     def __call__(self, x, out=None, xoff=0, yoff=0, residual=None, roff=0, bias=None, bias_bstride=0, act=None, upsample2x=False,
-                 out_fmt=FMT_F32):
+                 out_fmt=FMT_F32, splitk=False):
         """x[B,H,W,ldx] (reads channels xoff..xoff+cin) -> out[B,Ho,Wo,ldy] (writes yoff..yoff+cout).
         upsample2x: the conv runs on the bilinear x2 (align_corners=True) up-sampling of x, fused into the LDS-halo kernel
         when it applies, otherwise materialised by ape_bilinear_nhwc_f32 first.
@@ -255,6 +279,12 @@ class Conv:
                                                   _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
                                                   self.nsplit, _st())
             _lib.check(rc, "ape_conv3x3_halo_bf16")
+        elif gemm and splitk and out_fmt == FMT_F32 and _lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p)):
+            # the training tape's batch-1 layers (autograd.ConvFn): k-tiles dealt to several workgroups per output tile
+            ws = torch.empty(_lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p)), dtype=torch.uint8, device=x.device)
+            rc = _lib.lib().ape_conv_gemm_bf16_splitk(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias), _lib.dptr(residual),
+                                                      _lib.dptr(out, torch.float32), ctypes.byref(p), self.nsplit, _lib.dptr(ws), ws.numel(), _st())
+            _lib.check(rc, "ape_conv_gemm_bf16_splitk")
         elif gemm:
             rc = _lib.lib().ape_conv_gemm_bf16_fmt(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias),
                                                    _lib.dptr(residual), _lib.dptr(out, torch.float32), out_fmt, ctypes.byref(p),

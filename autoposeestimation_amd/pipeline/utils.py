@@ -23,6 +23,14 @@ from autoposeestimation_amd import engine as E
 from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
 
 
+def _pose_stream():
+    want = os.environ.get("APE_POSE_STREAM_PRIORITY", "low")
+    if want == "default":
+        return torch.cuda.Stream()
+    least, greatest = torch.cuda.Stream.priority_range()         # (numerically largest = least urgent, smallest = most urgent)
+    return torch.cuda.Stream(priority=least if want == "low" else greatest if want == "high" else int(want))
+
+
 class FramePipeline:
     def __init__(self, segmentor, estimator, refiner, class_names, num_points=1000, refine_mode="live_compat",
                  min_pixels=100, iterations=2, pose_stream=False):
@@ -37,7 +45,9 @@ class FramePipeline:
         # stream, so that the segmentation of the NEXT batch -- enqueued on the caller's stream as soon as run() returns -- fills
         # the chip beside it.  The returned dict then carries `stream`: whoever consumes pose / n_cand / choose enqueues on it
         # (or waits for it); torch.cuda.synchronize() covers both.
-        self.side = torch.cuda.Stream() if pose_stream else None
+        # The pose stream gets the LOWEST HIP stream priority the device offers: its small launches then take the CUs the segmentation
+        # kernels leave idle instead of competing with them for every slot (APE_POSE_STREAM_PRIORITY=default turns that off).
+        self.side = _pose_stream() if pose_stream else None
 
     # -- stage 1: segmentation + components, all on device ---------------------------------------------------------
     def segment(self, rgb, inject_logits=None):

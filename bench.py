@@ -467,6 +467,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    if os.environ.get("APE_MAIN_STREAM_PRIORITY", "default") == "high":
+        # everything the bench enqueues (segmentation, collectives) on a stream of the most urgent HIP priority; the pose stream of the
+        # software-pipelined loop keeps the default one, i.e. it is the LOWER-priority stream of the two
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=torch.cuda.Stream.priority_range()[1]))
     dist = None
     if world > 1 or "RANK" in os.environ:       # under torch.distributed.run the RCCL path is exercised even for one rank
         import torch.distributed as dist

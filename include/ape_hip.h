@@ -111,6 +111,13 @@ int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, 
  * feeds up_2's S32 channel mixing).  Declared further down next to their fp32 forms' documentation. */
 int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, const float* bias, const float* residual, void* y, int out_fmt,
                            const ape_conv_params* params_host, int nsplit, int variant, void* stream);
+/* Split-K form for the training tape's batch-1 layers (train.py:205-238 runs ONE 160x160 crop per step: its 20 x 20 feature maps are 4
+ * row tiles of the 128 x 128 block, K up to 4608): the k-tiles are dealt to several workgroups per output tile, raw sums go to the
+ * workspace, a second pass adds them in a fixed order with bias / residual / activation.  Same products, another summation order than
+ * ape_conv_gemm_bf16; the inference path never takes it.  ..._workspace_bytes returns 0 when the shape is not worth splitting. */
+size_t ape_conv_gemm_splitk_workspace_bytes(const ape_conv_params* params);
+int ape_conv_gemm_bf16_splitk(const float* x, const void* w_packed, const float* bias, const float* residual, float* y,
+                              const ape_conv_params* params, int nsplit, void* workspace, size_t workspace_bytes, void* stream);
 int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H, int W,
                                         int C, void* workspace, size_t workspace_bytes, void* stream);
 int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act, float alpha,
@@ -396,6 +403,10 @@ int ape_up3_seghead_stamps(void* device_buffer);
 size_t ape_conv2d_wgrad_workspace_bytes(const ape_conv_params* params);
 int ape_conv2d_wgrad_nhwc_f32(const float* x, const float* dy, float* dw, const ape_conv_params* params, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* the same sums written as the reference's parameter tensor: dw[Cout][cin_param][KH][KW] (cin_param <= Cin: the zero channels that pad x
+ * to a multiple of 4 drop out) -- what `weight.grad` holds after train.py:221 */
+int ape_conv2d_wgrad_param_f32(const float* x, const float* dy, float* dw, const ape_conv_params* params, int cin_param, void* workspace,
+                               size_t workspace_bytes, void* stream);
 /* dx = dy * act'(ref): ref = the OUTPUT for APE_ACT_RELU / APE_ACT_SIGMOID, the INPUT for APE_ACT_PRELU (nn.ReLU, nn.PReLU
  * pspnet.py:33, torch.sigmoid network.py:117); in place allowed */
 int ape_act_bwd_f32(const float* dy, const float* ref, float* dx, long n, int act, float alpha, void* stream);
@@ -426,6 +437,30 @@ int ape_adds_grad_f32(const float* pred_r, const float* pred_t, const float* poi
 /* optim.Adam(lr) update of one flat parameter buffer (train.py:109,113; torch defaults betas (0.9, 0.999), eps 1e-8) */
 int ape_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                       float beta2, float eps, int step, float weight_decay, void* stream);
+
+/* The same update for n parameter buffers at once (64 per launch): optimizer.step() of train.py:231-232 over all parameters of the
+ * estimator / refiner.  bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 - beta2^step) of each buffer's own step count. */
+typedef struct ape_adam_job {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long n;
+    float bc1, bc2_sqrt;
+} ape_adam_job;
+int ape_adam_step_multi_f32(int n, const ape_adam_job* jobs_host, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            void* stream);
+/* After an optimizer step the conv kernels' weight operands are stale: one launch re-packs many parameters ([Cout][Cin][taps] f32, the
+ * reference's nn.Conv2d / Conv1d / Linear layout) into f32 [N][taps][C4] (C4 = C rounded up to 4, zero channels) and, when dst_bf16 is
+ * set, the split-bf16 planes of ape_pack_weights_bf16.  transpose = 0: N = Cout, C = Cin (forward operand); 1: N = Cin, C = Cout, taps
+ * reversed (the flipped, transposed weights whose forward conv is the input gradient).  jobs: DEVICE array. */
+typedef struct ape_pack_job {
+    const float* src;
+    float* dst_f32;
+    void* dst_bf16;
+    int cout, cin, taps, transpose;
+} ape_pack_job;
+int ape_pack_train_weights(int n, const ape_pack_job* jobs_device, long max_elems, void* stream);
 
 #ifdef __cplusplus
 }

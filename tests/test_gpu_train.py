@@ -485,3 +485,96 @@ def test_train_epoch_fed_by_the_train_mode_dataset(tmp_path):
     assert st["samples"] == 10 and st["optimizer_steps"] == 3 and np.isfinite(st["loss"]) and np.isfinite(st["train_dis"])
     assert not torch.equal(est.get_parameter("conv1_r.weight").detach(), w0)
     assert np.isfinite(evaluate(est, ref, crit, crit_r, test_loader, opt))
+
+
+@pytest.mark.parametrize("shape", [(64, 3, 7, 7), (128, 64, 3, 3), (640, 384, 1), (512, 1024), (5, 6, 3, 3)])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_weight_bank_operands_equal_the_per_call_packing_bitwise(shape, precision):
+    """autograd.WeightBank (one launch packs the forward operand AND the flipped / transposed input-gradient operand straight from the
+    parameter, kept until the optimizer moves it) against the round-2 path: engine.Conv packing the tensor / its flipped transpose per
+    call.  Then the staleness rules: an in-place torch op on the parameter rebuilds the bank, Adam.step() refreshes it in place."""
+    from autoposeestimation_amd import autograd as AG
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    w = torch.nn.Parameter(torch.randn(*shape, generator=g).to(DEV))
+    bank = AG.weight_bank(w, precision)
+    w4 = AG._w4(w.detach())
+
+    def check(bank):
+        for tr, ref_w in ((False, w4), (True, w4.flip(2, 3).permute(1, 0, 2, 3))):
+            want = E.Conv(ref_w, device=DEV, precision=precision)
+            got = bank.conv(tr, 1, 0, 1, E.ACT_NONE)
+            assert torch.equal(got.w, want.w) and got.cin_real == want.cin_real and (got.cout, got.kh, got.kw, got.cin) == (want.cout, want.kh, want.kw, want.cin)
+            if precision != "f32":
+                assert torch.equal(got.wp.view(torch.int16), want.wp.view(torch.int16))
+    check(bank)
+    assert AG.weight_bank(w, precision) is bank                      # unchanged parameter: the same bank
+    with torch.no_grad():
+        w.mul_(1.5)                                                  # torch moved the parameter: stale
+    bank2 = AG.weight_bank(w, precision)
+    assert bank2 is not bank
+    check(bank2)
+    opt = AG.Adam([w], lr=1e-2)
+    w.grad = torch.randn(*shape, generator=g).to(DEV)
+    before = w.detach().clone()
+    opt.step()
+    assert not torch.equal(before, w.detach())
+    assert AG.weight_bank(w, precision) is bank2                     # refreshed in place by the optimizer
+    check(bank2)
+
+
+def test_multi_tensor_adam_equals_the_one_buffer_kernel_bitwise():
+    """ape_adam_step_multi_f32 (all parameters in one launch, 64 per launch: 150 buffers = 3 launches) against ape_adam_step_f32 buffer by
+    buffer, three steps, buffers of 1 .. 3 M elements, one without a gradient"""
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd import autograd as AG
+    g = torch.Generator().manual_seed(9)
+    sizes = [1, 3, 64, 1000, 3_000_000] + [17 * (i + 1) for i in range(145)]
+    ps = [torch.nn.Parameter(torch.randn(n, generator=g).to(DEV)) for n in sizes]
+    ref = [p.detach().clone() for p in ps]
+    m = [torch.zeros_like(r) for r in ref]
+    v = [torch.zeros_like(r) for r in ref]
+    opt = AG.Adam(ps, lr=3e-3, weight_decay=0.01)
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            p.grad = None if i == 7 else torch.randn(sizes[i], generator=g).to(DEV)
+        opt.step()
+        for i, p in enumerate(ps):
+            if p.grad is None:
+                continue
+            rc = _lib.lib().ape_adam_step_f32(_lib.dptr(ref[i]), _lib.dptr(p.grad), _lib.dptr(m[i]), _lib.dptr(v[i]), sizes[i], 3e-3, 0.9, 0.999, 1e-8,
+                                              step, 0.01, _lib.stream_ptr())
+            assert rc == 0
+    for p, r in zip(ps, ref):
+        assert torch.equal(p.detach(), r)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,h,w,act,res,bias", [
+    (512, 512, 3, 1, 4, 4, 20, 20, "relu", True, True),      # layer4 block conv at the training crop's 20 x 20 map: 16 tiles, 144 k-tiles
+    (64, 128, 3, 2, 1, 1, 40, 40, "none", False, False),     # layer2.0.conv1 (stride 2): 18 k-tiles
+    (256, 200, 3, 1, 2, 2, 20, 20, "prelu", False, True),    # ragged Cout
+    (1024, 512, 1, 1, 0, 1, 1, 300, "relu", False, True),    # a pure 1x1 over points
+])
+def test_split_k_conv_matches_the_one_pass_kernel(cin, cout, k, stride, pad, dil, h, w, act, res, bias):
+    """ape_conv_gemm_bf16_splitk (k-tiles dealt over workgroups, fixed-order second pass with bias / residual / activation) against
+    ape_conv_gemm_bf16 on the same operands: same products, other summation order -> 2e-6 of the output scale; and it must actually
+    split these shapes (workspace > 0) while leaving a chip-filling one alone"""
+    import ctypes
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, h, w, cin, generator=g).to(DEV)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    conv = E.Conv(wt, None, stride, pad, dil, {"none": E.ACT_NONE, "relu": E.ACT_RELU, "prelu": E.ACT_PRELU}[act], alpha=0.25, device=DEV, precision="bf16x3")
+    ho, wo = conv.out_hw(h, w)
+    r = torch.randn(1, ho, wo, cout, generator=g).to(DEV) if res else None
+    b = torch.randn(cout, generator=g).to(DEV) if bias else None
+    one = conv(x, residual=r, bias=b)
+    two = conv(x, residual=r, bias=b, splitk=True)
+    p = _lib.ConvParams(B=1, H=h, W=w, Cin=cin, ldx=cin, xoff=0, Ho=ho, Wo=wo, Cout=cout, ldy=cout, yoff=0, KH=k, KW=k, stride=stride, pad=pad, dil=dil,
+                        act=0, alpha=0.0, bias_bstride=0, ldr=0, roff=0, ups=0)
+    assert _lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p)) > 0
+    assert not torch.equal(one, two) or cin * k * k <= 256
+    assert float((one - two).abs().max()) <= 2e-6 * float(one.abs().max())
+    p.B = 64
+    assert _lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p)) == 0
