@@ -63,7 +63,15 @@ class _HipModule(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._plan = None
+        self._pcache = None
         return super()._apply(fn, *a, **k)
+
+    def param(self, name):
+        """get_parameter(name) through a dict built once (the training forward looks ~75 parameters up per step)"""
+        c = self.__dict__.get("_pcache")
+        if c is None:
+            c = self.__dict__["_pcache"] = dict(self.named_parameters())
+        return c[name]
 
     def train(self, mode=True):
         """train(True): parameters become leaves of the tape (autoposeestimation_amd/autograd.py) and forward() runs the
@@ -263,7 +271,7 @@ def _dropout2d(x, masks, key, p):
 def _pspnet_train(mod, prefix, backend, x, masks, precision):
     """x[B,H,W,4] -> log-softmax embedding [B,H,W,32] (pspnet.py:64-77 in train mode)"""
     from autoposeestimation_amd import autograd as A
-    P = lambda k: mod.get_parameter(prefix + k)  # noqa: E731
+    P = lambda k: mod.param(prefix + k)  # noqa: E731
     cv = lambda *a, **k: A.conv(*a, precision=precision, **k)  # noqa: E731
     y = A.MaxPoolFn.apply(cv(x, P("feats.conv1.weight"), stride=2, pad=3, act=E.ACT_RELU))
     inplanes = 64
@@ -294,7 +302,7 @@ def _pspnet_train(mod, prefix, backend, x, masks, precision):
 def _feat_train(mod, x4, emb, refine, precision):
     """PoseNetFeat / PoseRefineNetFeat (network.py:39-68, 136-168): x4[1,N,1,4], emb[1,N,1,32] -> pf[1,N,1,384], ap[1,1024]"""
     from autoposeestimation_amd import autograd as A
-    g = lambda k: (mod.get_parameter("feat.%s.weight" % k), mod.get_parameter("feat.%s.bias" % k))  # noqa: E731
+    g = lambda k: (mod.param("feat.%s.weight" % k), mod.param("feat.%s.bias" % k))  # noqa: E731
     cv = lambda x, k: A.conv(x, *g(k), act=E.ACT_RELU, precision=precision)  # noqa: E731
     c1, e1 = cv(x4, "conv1"), cv(emb, "e_conv1")
     c2, e2 = cv(c1, "conv2"), cv(e1, "e_conv2")
@@ -433,13 +441,13 @@ def _posenet_forward_train(self, img4, points4, choose, o):
     pf, ap = _feat_train(self, points4.view(1, n, 1, 4), emb.view(1, n, 1, 32), False, pr)
     outs = []
     for h, k in (("r", 4), ("t", 3), ("c", 1)):
-        w1 = self.get_parameter("conv1_%s.weight" % h)[:, :, 0]                              # [640,1408]
-        gb = A.conv(ap.view(1, 1, 1, 1024), w1[:, 384:], self.get_parameter("conv1_%s.bias" % h), precision=pr)
+        w1 = self.param("conv1_%s.weight" % h)[:, :, 0]                              # [640,1408]
+        gb = A.conv(ap.view(1, 1, 1, 1024), w1[:, 384:], self.param("conv1_%s.bias" % h), precision=pr)
         y = A.conv(pf, w1[:, :384], gb, act=E.ACT_RELU, precision=pr)
         for l in (2, 3):
-            y = A.conv(y, self.get_parameter("conv%d_%s.weight" % (l, h)), self.get_parameter("conv%d_%s.bias" % (l, h)),
+            y = A.conv(y, self.param("conv%d_%s.weight" % (l, h)), self.param("conv%d_%s.bias" % (l, h)),
                        act=E.ACT_RELU, precision=pr)
-        w4, b4 = _select_rows(self.get_parameter("conv4_%s.weight" % h), self.get_parameter("conv4_%s.bias" % h), o, k)
+        w4, b4 = _select_rows(self.param("conv4_%s.weight" % h), self.param("conv4_%s.bias" % h), o, k)
         y = A.conv(y, w4, b4, act=E.ACT_SIGMOID if h == "c" else E.ACT_NONE, precision=pr)
         outs.append(y.view(1, n, 4)[:, :, :k])
     return outs[0], outs[1], outs[2], emb.transpose(1, 2)
@@ -503,9 +511,9 @@ class PoseRefineNet(_HipModule):
         for h, k in (("r", 4), ("t", 3)):
             y = ap.view(1, 1, 1, 1024)
             for l in (1, 2):
-                y = A.conv(y, self.get_parameter("conv%d_%s.weight" % (l, h)), self.get_parameter("conv%d_%s.bias" % (l, h)),
+                y = A.conv(y, self.param("conv%d_%s.weight" % (l, h)), self.param("conv%d_%s.bias" % (l, h)),
                            act=E.ACT_RELU, precision=pr)
-            w3, b3 = _select_rows(self.get_parameter("conv3_%s.weight" % h), self.get_parameter("conv3_%s.bias" % h), o, k)
+            w3, b3 = _select_rows(self.param("conv3_%s.weight" % h), self.param("conv3_%s.bias" % h), o, k)
             outs.append(A.conv(y, w3, b3, precision=pr).view(1, 4)[:, :k])
         return outs[0], outs[1]
 

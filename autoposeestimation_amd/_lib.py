@@ -130,7 +130,7 @@ class AdamJob(_c.Structure):
 class PackJob(_c.Structure):
     """Mirror of `ape_pack_job` (include/ape_hip.h)."""
     _fields_ = [("src", _c.c_void_p), ("dst_f32", _c.c_void_p), ("dst_bf16", _c.c_void_p), ("cout", _c.c_int32), ("cin", _c.c_int32),
-                ("taps", _c.c_int32), ("transpose", _c.c_int32)]
+                ("taps", _c.c_int32), ("transpose", _c.c_int32), ("src_ld", _c.c_int32), ("reserved", _c.c_int32)]
 
 
 class ConvParams(_c.Structure):

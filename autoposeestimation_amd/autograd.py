@@ -62,6 +62,16 @@ def conv_wgrad(x, dy, cout, kh, kw, stride, pad, dil, param_shape=None):
     return dw
 
 
+def _rows_dense(w):
+    """every row w[i] is laid out like a contiguous tensor (rows may be further apart than their length)"""
+    expect = 1
+    for size, stride in zip(reversed(w.shape[1:]), reversed(w.stride()[1:])):
+        if size != 1 and stride != expect:
+            return False
+        expect *= size
+    return w.dim() >= 2 and (w.shape[0] == 1 or w.stride(0) >= expect)
+
+
 class WeightBank:
     """The conv kernels' operands of ONE parameter, kept while the parameter does not change ("keep packed weights
     until optimizer.step()"): the forward form ([Cout,KH,KW,Cin4] f32 + split-bf16 planes) and the input-gradient form (flipped taps,
@@ -73,16 +83,17 @@ class WeightBank:
         w = weight.detach()
         if not w.is_cuda:
             raise ValueError("the training path needs its parameters in device memory (no CPU fallback)")
-        own = w.dtype == torch.float32 and w.is_contiguous()
-        if not own:                    # a strided slice of a parameter (the per-object head rows / column blocks): packed from a copy, per call
+        shape = tuple(w.shape) + (1,) * (4 - w.dim())
+        self.cout, self.cin, self.kh, self.kw = shape
+        taps = self.kh * self.kw
+        # packed straight from the parameter's storage: the whole tensor, or a block of rows / columns of it whose rows stay dense
+        own = w.dtype == torch.float32 and _rows_dense(w)
+        if not own:                    # anything else (the zero-padded head rows built per call): packed from a dense copy, per call
             w = w.float().contiguous()
         self.src = w
         self.version = weight._version if own else None
         self.precision = precision
         nsplit = {"f32": 0, "bf16x3": 3, "bf16": 1}[precision]
-        shape = tuple(w.shape) + (1,) * (4 - w.dim())
-        self.cout, self.cin, self.kh, self.kw = shape
-        taps = self.kh * self.kw
         dev = w.device
         self.ops = []
         jobs = (_lib.PackJob * 2)()
@@ -94,7 +105,7 @@ class WeightBank:
             wp = torch.empty(2 * n * kp, dtype=torch.bfloat16, device=dev) if nsplit else None
             self.ops.append((wf, wp, c))
             jobs[tr] = _lib.PackJob(src=w.data_ptr(), dst_f32=wf.data_ptr(), dst_bf16=wp.data_ptr() if nsplit else None, cout=self.cout,
-                                    cin=self.cin, taps=taps, transpose=tr)
+                                    cin=self.cin, taps=taps, transpose=tr, src_ld=w.stride(0) if self.cout > 1 else self.cin * taps, reserved=0)
             self.max_elems = max(self.max_elems, n * kp)
         self.jobs = jobs
         self.convs = {}
@@ -114,20 +125,38 @@ class WeightBank:
 
 
 def weight_bank(weight, precision):
-    bank = getattr(weight, "_ape_bank", None)
+    """the (cached) bank of a parameter, or of a dense-row block of one (kept on the parameter it is a view of)"""
+    base = weight._base if weight._is_view() else None
+    if base is not None:
+        key = (weight.storage_offset(), tuple(weight.shape), tuple(weight.stride()))
+        slices = getattr(base, "_ape_slices", None)
+        bank = slices.get(key) if slices is not None else None
+    else:
+        bank = getattr(weight, "_ape_bank", None)
     if (bank is None or bank.version is None or bank.version != weight._version or bank.precision != precision
             or bank.src.data_ptr() != weight.data_ptr()):
         bank = WeightBank(weight, precision)
         try:
-            weight._ape_bank = bank
+            if base is None:
+                weight._ape_bank = bank
+            elif bank.version is not None:
+                if slices is None:
+                    slices = base._ape_slices = {}
+                slices[key] = bank
         except AttributeError:
             pass
     return bank
 
 
 def refresh_banks(params):
-    """re-pack the operands of every parameter in `params` that has a bank: one launch (their job tables concatenated once and kept)"""
-    banks = [b for b in (getattr(p, "_ape_bank", None) for p in params) if b is not None and b.version is not None]
+    """re-pack the operands of every parameter in `params` that has banks (its own and those of its row / column blocks): one launch (their
+    job tables concatenated once and kept)"""
+    banks = []
+    for p in params:
+        b = getattr(p, "_ape_bank", None)
+        if b is not None and b.version is not None:
+            banks.append(b)
+        banks.extend(getattr(p, "_ape_slices", {}).values())
     if not banks:
         return
     key = tuple(id(b) for b in banks)

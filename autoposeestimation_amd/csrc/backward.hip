@@ -364,7 +364,7 @@ __global__ void adam_multi_kernel(const AdamBatch b, float lr, float b1, float b
     }
 }
 
-// parameter layout [Cout][Cin][taps] -> the conv kernels' operand layouts, many parameters per launch (blockIdx.y = job):
+// parameter layout [Cout][Cin][taps] (rows src_ld elements apart: a column block of a wider parameter packs in place) -> the conv kernels' operand layouts, many parameters per launch (blockIdx.y = job):
 // f32 [N][taps][C4] and the split-bf16 planes hi [N][Kp] | lo [N][Kp] (K = taps * C4, Kp = K rounded up to 8, zero padded).
 // transpose = 0: N = Cout, C = Cin (the forward operand); 1: N = Cin, C = Cout with the taps reversed = the flipped, transposed
 // weights whose forward conv is the input gradient.
@@ -381,7 +381,7 @@ __global__ void pack_train_weights_kernel(const ape_pack_job* __restrict__ jobs)
         float v = 0.f;
         if (k < K) {
             const int t = k / C4, c = k - t * C4;
-            if (c < C) v = a.transpose ? a.src[((long)c * a.cin + n) * a.taps + (a.taps - 1 - t)] : a.src[(n * a.cin + c) * a.taps + t];
+            if (c < C) v = a.transpose ? a.src[(long)c * a.src_ld + n * a.taps + (a.taps - 1 - t)] : a.src[n * a.src_ld + (long)c * a.taps + t];
             a.dst_f32[n * K + k] = v;
         }
         if (hi) {

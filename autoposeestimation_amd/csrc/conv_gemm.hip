@@ -75,7 +75,8 @@ __device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^
 // other one does its LDS reads / split / ds_writes / global loads, instead of all eight waves queueing on the LDS port and
 // then all eight on the matrix pipes.  The LDS stage protocol is unchanged (tile t+1 is written >= 2 barriers after the last
 // read of tile t-1 and >= 2 barriers before the first read of tile t+1 by either group).
-template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP>
+// SK: the split-K build (training tape only; the inference instantiations do not carry its code or registers)
+template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP, bool SK = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a)
 {
     static_assert(!PP || WM == 2, "the ping-pong schedule pairs the two row halves of an 8-wave block");
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     u32x4 breg[NPL][B_IT];
     unsigned a_ok = 0;                       // bit i: item i of the tile held in registers lies inside the image
     int t_ci0 = 0, t_ky = 0, t_kx = 0;       // (chunk, tap) of the NEXT tile to load; K order = chunk outer, taps inner
-    const int kt0 = a.nk_per ? (int)blockIdx.y * a.nk_per : 0;
-    if (a.nk_per) {
+    const int kt0 = SK ? (int)blockIdx.y * a.nk_per : 0;
+    if (SK) {
         if (PURE) {
             t_ci0 = kt0 * BK;
         } else {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             t_kx = tap - t_ky * p.KW;
         }
     }
-    float* const yb = a.nk_per ? a.y + (size_t)blockIdx.y * a.split_stride : a.y;
+    float* const yb = SK ? a.y + (size_t)blockIdx.y * a.split_stride : a.y;
     auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
     auto load_tiles = [&]() {
         unsigned kb;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
             }
     };
 
-    const int nk = a.nk_per ? (a.nk - kt0 < a.nk_per ? a.nk - kt0 : a.nk_per) : a.nk;
+    const int nk = SK ? (a.nk - kt0 < a.nk_per ? a.nk - kt0 : a.nk_per) : a.nk;
     // 8-wave blocks: dbg bit 8 = static priority 1 for waves 4-7 (cf. conv_gemm_s32.hip)
     if (NT == 512 && (a.dbg & 8) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     load_tiles();
@@ -348,11 +349,22 @@ void launch(GemmArgs& a, bool pure, hipStream_t st)
 {
     a.m_tiles = ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.p.Cout, BN);
-    const int gy = a.nk_per ? ape::ceil_div(a.nk, a.nk_per) : 1;
     if (pure)
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true, PP>), dim3(a.m_tiles * a.n_tiles, gy), dim3(WM * WN * 64), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, true, PP>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false, PP>), dim3(a.m_tiles * a.n_tiles, gy), dim3(WM * WN * 64), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, BM, BN, WM, WN, false, PP>), dim3(a.m_tiles * a.n_tiles), dim3(WM * WN * 64), 0, st, a);
+}
+
+template <int NSPLIT>
+void launch_splitk(GemmArgs& a, bool pure, hipStream_t st)
+{
+    a.m_tiles = ape::ceil_div(a.M, 128);
+    a.n_tiles = ape::ceil_div(a.p.Cout, 128);
+    const int gy = ape::ceil_div(a.nk, a.nk_per);
+    if (pure)
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, 128, 128, 2, 2, true, false, true>), dim3(a.m_tiles * a.n_tiles, gy), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, 128, 128, 2, 2, false, false, true>), dim3(a.m_tiles * a.n_tiles, gy), dim3(256), 0, st, a);
 }
 
 // split-K second pass: y = act(sum over the splits (fixed order) + bias + residual)
@@ -469,7 +481,9 @@ extern "C" int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, cons
 /* Split-K form for the training tape's batch-1 layers (a 20 x 20 map is 4 row tiles: 4..16 workgroups walking K = 4608 alone took 89 us):
  * the k-tiles are dealt to `splits` workgroups per output tile, raw sums go to the workspace and a second pass adds them in a fixed
  * order with bias / residual / activation.  Same products, another summation order than ape_conv_gemm_bf16 -- the inference path
- * never takes it.  ape_conv_gemm_splitk_workspace_bytes returns 0 when the shape is not worth splitting (use ape_conv_gemm_bf16). */
+ * never takes it.  ape_conv_gemm_splitk_workspace_bytes returns 0 when the shape is not worth splitting (use ape_conv_gemm_bf16).
+ * (A single-launch form -- the last split of a tile to arrive reduces -- was measured and dropped: its device-scope fences write back
+ * and invalidate whole XCD L2s per workgroup, 7.8 -> 18.8 ms per training step.) */
 extern "C" size_t ape_conv_gemm_splitk_workspace_bytes(const ape_conv_params* params)
 {
     if (!params || !supported(*params)) return 0;
@@ -507,7 +521,7 @@ extern "C" int ape_conv_gemm_bf16_splitk(const float* x, const void* w_packed, c
     const int splits = ape::ceil_div(a.nk, a.nk_per);
     const bool pure = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
     hipStream_t st = (hipStream_t)stream;
-    if (nsplit == 3) launch<3, 128, 128, 2, 2>(a, pure, st); else launch<1, 128, 128, 2, 2>(a, pure, st);
+    if (nsplit == 3) launch_splitk<3>(a, pure, st); else launch_splitk<1>(a, pure, st);
     long g = (M * p.Cout + 255) / 256;
     g = g > 4096 ? 4096 : g;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)g), dim3(256), 0, st, (const float*)workspace, splits, M, p.Cout, bias, p.bias_bstride,

@@ -257,16 +257,32 @@ class Conv:
         if residual is not None and tuple(residual.shape[:3]) != (b, ho, wo):
             raise ValueError("residual shape mismatch")
         bias = self.bias if bias is None else bias
-        p = ConvParams(B=b, H=h, W=w, Cin=self.cin, ldx=ldx, xoff=xoff, Ho=ho, Wo=wo, Cout=self.cout,
-                       ldy=out.shape[3], yoff=yoff, KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad,
-                       dil=self.dil, act=self.act if act is None else act, alpha=self.alpha,
-                       bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff,
-                       ups=int(bool(upsample2x)))
-        # the halo kernel tiles the image in 16x16 pixels: use it only when those tiles are mostly full (crop feature maps of
-        # 20x20 / 40x40 would waste 30..60 % of the MFMAs; the flattened-M generic kernel has no such edge effect)
-        halo = (self.nsplit and USE_HALO_KERNEL and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256))
-                and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
-        gemm = bool(not halo and self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)))
+        # the parameter block and the kernel choice depend on shapes only: kept per call signature (the training tape calls every layer
+        # with the same shapes step after step; building the ctypes struct and asking the library twice cost ~15 us per call)
+        key = (b, h, w, ldx, xoff, out.shape[3], yoff, self.act if act is None else act, bias_bstride, 0 if residual is None else residual.shape[3], roff,
+               bool(upsample2x), splitk, USE_HALO_KERNEL, USE_GEMM_KERNEL)
+        plans = self.__dict__.get("_plans")
+        if plans is None:
+            plans = self.__dict__["_plans"] = {}
+        plan = plans.get(key)
+        if plan is None:
+            p = ConvParams(B=b, H=h, W=w, Cin=self.cin, ldx=ldx, xoff=xoff, Ho=ho, Wo=wo, Cout=self.cout,
+                           ldy=out.shape[3], yoff=yoff, KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad,
+                           dil=self.dil, act=self.act if act is None else act, alpha=self.alpha,
+                           bias_bstride=bias_bstride, ldr=0 if residual is None else residual.shape[3], roff=roff,
+                           ups=int(bool(upsample2x)))
+            # the halo kernel tiles the image in 16x16 pixels: use it only when those tiles are mostly full (crop feature maps of
+            # 20x20 / 40x40 would waste 30..60 % of the MFMAs; the flattened-M generic kernel has no such edge effect)
+            halo = bool(self.nsplit and USE_HALO_KERNEL and (upsample2x or (h * w) >= 0.8 * (-(-h // 16) * -(-w // 16) * 256))
+                        and _lib.lib().ape_conv3x3_halo_supported(ctypes.byref(p)))
+            gemm = bool(not halo and self.nsplit and USE_GEMM_KERNEL and _lib.lib().ape_conv_gemm_supported(ctypes.byref(p)))
+            sk_bytes = int(_lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p))) if (gemm and splitk) else 0
+            if len(plans) > 64:
+                plans.clear()
+            plan = plans[key] = (p, halo, gemm, sk_bytes)
+        p, halo, gemm, sk_bytes = plan
+        if p.alpha != self.alpha:
+            p.alpha = self.alpha
         if out_fmt == FMT_S32 and not gemm:
             raise ValueError("an S32 output from an fp32 input exists only on the conv_gemm kernel (Cin % 32 == 0, not a halo layer)")
         e0 = None
@@ -279,9 +295,9 @@ class Conv:
                                                   _lib.dptr(residual), _lib.dptr(out, torch.float32), ctypes.byref(p),
                                                   self.nsplit, _st())
             _lib.check(rc, "ape_conv3x3_halo_bf16")
-        elif gemm and splitk and out_fmt == FMT_F32 and _lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p)):
+        elif gemm and sk_bytes and out_fmt == FMT_F32:
             # the training tape's batch-1 layers (autograd.ConvFn): k-tiles dealt to several workgroups per output tile
-            ws = torch.empty(_lib.lib().ape_conv_gemm_splitk_workspace_bytes(ctypes.byref(p)), dtype=torch.uint8, device=x.device)
+            ws = torch.empty(sk_bytes, dtype=torch.uint8, device=x.device)
             rc = _lib.lib().ape_conv_gemm_bf16_splitk(_lib.dptr(x, torch.float32), _lib.dptr(self.wp), _lib.dptr(bias), _lib.dptr(residual),
                                                       _lib.dptr(out, torch.float32), ctypes.byref(p), self.nsplit, _lib.dptr(ws), ws.numel(), _st())
             _lib.check(rc, "ape_conv_gemm_bf16_splitk")

@@ -459,6 +459,9 @@ typedef struct ape_pack_job {
     float* dst_f32;
     void* dst_bf16;
     int cout, cin, taps, transpose;
+    int src_ld;            /* elements between two output-channel rows of src (cin * taps when src is the whole parameter; larger for a
+                              column block of a wider one, network.py:104-121 feeds conv1_r/t/c two column blocks of one weight) */
+    int reserved;
 } ape_pack_job;
 int ape_pack_train_weights(int n, const ape_pack_job* jobs_device, long max_elems, void* stream);
 
