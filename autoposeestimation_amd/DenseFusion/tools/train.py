@@ -21,16 +21,17 @@ def train_step(estimator, refiner, criterion, criterion_refine, data, opt, devic
     points, choose, img, target, model_points, idx = _dev(data[:6], device)
     pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx)
     loss, dis, new_points, new_target, _ = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, opt.w, opt.refine_start)
-    loss_value, refiner_value = float(loss.detach()), 0.0
     if opt.refine_start:
         for _ in range(opt.iteration):
             pred_r, pred_t = refiner(new_points, emb, idx)
             dis, new_points, new_target, _ = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
             dis.backward()
-        refiner_value = float(dis.detach())
     else:
         loss.backward()
-    return loss_value, refiner_value, float(dis.detach())
+    # the values are read only AFTER the backward launches are queued: a read straight behind the loss (as train.py:207-226 logs it) parks
+    # the host until the forward has drained, and the step is bound by the host's launch rate
+    loss_value, dis_value = float(loss.detach()), float(dis.detach())
+    return loss_value, (dis_value if opt.refine_start else 0.0), dis_value
 
 
 def train_epoch(estimator, refiner, optimizer, criterion, criterion_refine, dataloader, opt, device="cuda:0"):

@@ -27,10 +27,10 @@ for refine in (False, True):
     if refine: est.eval(); ref.train()
     else: est.train()
     optim = Adam(net.parameters(), lr=1e-4)
-    for _ in range(2):
+    for _ in range(3):
         optim.zero_grad(); train_step(est, ref, crit, crit_r, data, opt, dev); optim.step()
     torch.cuda.synchronize(); t = time.perf_counter()
-    n = 5
+    n = 20
     for _ in range(n):
         optim.zero_grad(); train_step(est, ref, crit, crit_r, data, opt, dev); optim.step()
     torch.cuda.synchronize()
