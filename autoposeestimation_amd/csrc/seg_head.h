@@ -81,26 +81,32 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
 #pragma unroll
     for (int r = 0; r < 4; ++r) { e[r] = (kq * 4 + r < C) ? __expf(acc[r] - m) : 0.f; s += e[r]; }
     s = quad_sum(s, lane);
-    // The reference's arg-max runs over the PROBABILITIES (pipeline/utils.py:430-435): a class whose logit lies so close below the
-    // maximum that exp(l - m) rounds to 1 has the same float32 probability and torch.argmax returns the LOWER index -- take the
-    // lowest class with e == 1 (the maximum itself always qualifies)
-    {
-        int tmin = am;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (e[r] == 1.f && kq * 4 + r < tmin) tmin = kq * 4 + r;
-        const int o16 = (int)lane_xor16_u((unsigned)tmin, lane);
-        tmin = o16 < tmin ? o16 : tmin;
-        const int o32 = (int)lane_xor32_u((unsigned)tmin, lane);
-        am = o32 < tmin ? o32 : tmin;
-    }
+    // The reference's arg-max runs over the PROBABILITIES it finally holds (pipeline/utils.py:430-435): after ONE softmax a class whose
+    // logit lies so close below the maximum that exp(l - m) rounds to 1 has the same float32 probability; after TWO (the live path:
+    // predict's activation, then F.softmax) the band is wider -- every class whose exp(p1 - p1max) rounds to 1.  torch.argmax returns
+    // the LOWEST index of such a tie: take the lowest class whose last exponential is exactly 1 (the maximum itself always qualifies;
+    // e == 1 implies p1 == p1max, so the two-softmax test contains the one-softmax one).
     float pm = 1.f / s;
+    float t[4];
     if (double_softmax) {
         const float inv = pm;
         float s2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s2 += (kq * 4 + r < C) ? __expf(e[r] * inv - pm) : 0.f;
+        for (int r = 0; r < 4; ++r) { t[r] = (kq * 4 + r < C) ? __expf(e[r] * inv - pm) : 0.f; s2 += t[r]; }
         pm = 1.f / quad_sum(s2, lane);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = e[r];
+    }
+    {
+        int tmin = am;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (t[r] == 1.f && kq * 4 + r < tmin) tmin = kq * 4 + r;
+        const int o16 = (int)lane_xor16_u((unsigned)tmin, lane);
+        tmin = o16 < tmin ? o16 : tmin;
+        const int o32 = (int)lane_xor32_u((unsigned)tmin, lane);
+        am = o32 < tmin ? o32 : tmin;
     }
     am_out = am;
     pm_out = pm;
@@ -165,13 +171,37 @@ __device__ __forceinline__ void seg_head_groups(const float4 (&x)[G][4], const f
     for (int g = 0; g < G; ++g) s[g] += lane_xor16(s[g], lane);
 #pragma unroll
     for (int g = 0; g < G; ++g) s[g] += lane_xor32(s[g], lane);
+    float pm[G], t[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) pm[g] = 1.f / s[g];
+    if (double_softmax) {
+        float s2[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float inv = pm[g];
+            s2[g] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { t[g][r] = (kq * 4 + r < C) ? __expf(e[g][r] * inv - pm[g]) : 0.f; s2[g] += t[g][r]; }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) s2[g] += lane_xor16(s2[g], lane);
+#pragma unroll
+        for (int g = 0; g < G; ++g) s2[g] += lane_xor32(s2[g], lane);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pm[g] = 1.f / s2[g];
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[g][r] = e[g][r];
+    }
     int tmin[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         tmin[g] = am[g];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (e[g][r] == 1.f && kq * 4 + r < tmin[g]) tmin[g] = kq * 4 + r;
+            if (t[g][r] == 1.f && kq * 4 + r < tmin[g]) tmin[g] = kq * 4 + r;
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -182,25 +212,6 @@ __device__ __forceinline__ void seg_head_groups(const float4 (&x)[G][4], const f
     for (int g = 0; g < G; ++g) {
         const int o32 = (int)lane_xor32_u((unsigned)tmin[g], lane);
         am[g] = o32 < tmin[g] ? o32 : tmin[g];
-    }
-    float pm[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) pm[g] = 1.f / s[g];
-    if (double_softmax) {
-        float s2[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float inv = pm[g];
-            s2[g] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s2[g] += (kq * 4 + r < C) ? __expf(e[g][r] * inv - pm[g]) : 0.f;
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) s2[g] += lane_xor16(s2[g], lane);
-#pragma unroll
-        for (int g = 0; g < G; ++g) s2[g] += lane_xor32(s2[g], lane);
-#pragma unroll
-        for (int g = 0; g < G; ++g) pm[g] = 1.f / s2[g];
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) { am_out[g] = am[g]; pm_out[g] = pm[g]; }

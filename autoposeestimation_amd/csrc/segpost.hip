@@ -39,19 +39,24 @@ __global__ void seg_argmax_kernel(const float* __restrict__ logits, int ld, int 
         int am = 0;
         for (int c = 1; c < C; ++c)
             if (l[c] > m) { m = l[c]; am = c; }  // first maximum, like torch.argmax on the CPU
-        // The reference takes the arg-max of the PROBABILITIES (pipeline/utils.py:430-435): a class whose logit is so close below the
-        // maximum that exp(l - m) rounds to 1 has the same float32 probability, and torch.argmax then returns the LOWER index.
+        // The reference takes the arg-max of the PROBABILITIES it finally holds (pipeline/utils.py:430-435): a class whose last exponential
+        // (exp(l - m) after one softmax, exp(p1 - p1max) after two) rounds to 1 has the maximum's float32 probability, and torch.argmax
+        // then returns the LOWEST such index (e == 1 implies p1 == p1max: the two-softmax test contains the one-softmax one).
         float s = 0.f;
         for (int c = 0; c < C; ++c) {
             const float e = expf(l[c] - m);
-            if (e == 1.f && c < am) am = c;
+            if (!double_softmax && e == 1.f && c < am) am = c;
             s += e;
         }
         float pm = 1.f / s;  // softmax(logits)[am]  (activation='softmax' inside predict, create_labels.py:23)
         if (double_softmax) {
             // F.softmax applied again on the probabilities (pipeline/utils.py:430): the maximum is p1[am]
             float s2 = 0.f;
-            for (int c = 0; c < C; ++c) s2 += expf(expf(l[c] - m) / s - pm);
+            for (int c = 0; c < C; ++c) {
+                const float e2 = expf(expf(l[c] - m) / s - pm);
+                if (e2 == 1.f && c < am) am = c;
+                s2 += e2;
+            }
             pm = 1.f / s2;
         }
         label[p] = (uint8_t)am;

@@ -247,3 +247,31 @@ def test_argmax_breaks_probability_ties_like_torch():
     w[3, 1] = 0.5
     l2, _ = E.seg_head(feat.cuda(), w.cuda().contiguous(), b.cuda(), True)
     assert torch.equal(l2[0, 0].cpu().long(), want)
+
+
+def test_argmax_ties_of_the_second_softmax_resolve_like_torch():
+    """The live path applies softmax twice (pipeline/utils.py:429-435) and torch.argmax sees p2 = softmax(softmax(l)).  Logit gaps of
+    5..10 ulp (3.9e-8 .. 7.6e-8 at 0.1) are NOT ties after the first softmax (p1 differs by one ulp, a one-softmax arg-max returns the
+    higher class 3) but round to equal p2 -- torch returns the lower class 1.  Both device arg-max forms (ape_seg_argmax_f32 and the
+    fused 64 -> C head) must follow; the band's outer edge (12 ulp here) depends on the last bit of p1 and is not asserted."""
+    from autoposeestimation_amd import engine as E
+    C = 5
+    x = torch.tensor(0.1)
+    for k in range(1, 11):
+        x = torch.nextafter(x, torch.tensor(1.0))
+        logits = torch.full((1, 1, 32, 8), -4.0)
+        logits[..., 1] = 0.1
+        logits[..., 3] = float(x)
+        p1 = F.softmax(logits[..., :C], -1)
+        want = int(F.softmax(p1, -1).argmax(-1)[0, 0, 0])
+        assert want == 1
+        if k >= 5:
+            assert int(p1.argmax(-1)[0, 0, 0]) == 3                       # the premise: only the SECOND softmax ties
+        lab, _ = E.seg_argmax(logits.cuda(), C, double_softmax=True)
+        assert int(lab.max()) == 1 and int(lab.min()) == 1, k
+        feat = torch.zeros(1, 1, 32, 64)
+        feat[..., 0] = 1.0
+        w = torch.zeros(C, 64)
+        w[:, 0] = torch.tensor([-4.0, 0.1, -4.0, float(x), -4.0])
+        l2, _ = E.seg_head(feat.cuda(), w.cuda().contiguous(), torch.zeros(C).cuda(), True)
+        assert int(l2.max()) == 1 and int(l2.min()) == 1, k
