@@ -76,8 +76,8 @@ __device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^
 // then all eight on the matrix pipes.  The LDS stage protocol is unchanged (tile t+1 is written >= 2 barriers after the last
 // read of tile t-1 and >= 2 barriers before the first read of tile t+1 by either group).
 // SK: the split-K build (training tape only; the inference instantiations do not carry its code or registers)
-template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP, bool SK = false>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a)
+template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP, bool SK>
+__device__ __forceinline__ void conv_gemm_body(const GemmArgs& a)
 {
     static_assert(!PP || WM == 2, "the ping-pong schedule pairs the two row halves of an 8-wave block");
     constexpr int NT = WM * WN * 64;
@@ -344,6 +344,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmAr
     }
 }
 
+template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a)
+{
+    conv_gemm_body<NSPLIT, BM, BN, WM, WN, PURE, PP, false>(a);
+}
+
+template <int NSPLIT, bool PURE>
+__global__ __launch_bounds__(256, 2) void conv_gemm_splitk_kernel(const GemmArgs a)
+{
+    conv_gemm_body<NSPLIT, 128, 128, 2, 2, PURE, false, true>(a);
+}
+
 template <int NSPLIT, int BM, int BN, int WM, int WN, bool PP = false>
 void launch(GemmArgs& a, bool pure, hipStream_t st)
 {
@@ -362,9 +374,9 @@ void launch_splitk(GemmArgs& a, bool pure, hipStream_t st)
     a.n_tiles = ape::ceil_div(a.p.Cout, 128);
     const int gy = ape::ceil_div(a.nk, a.nk_per);
     if (pure)
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, 128, 128, 2, 2, true, false, true>), dim3(a.m_tiles * a.n_tiles, gy), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_splitk_kernel<NSPLIT, true>), dim3(a.m_tiles * a.n_tiles, gy), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_gemm_kernel<NSPLIT, 128, 128, 2, 2, false, false, true>), dim3(a.m_tiles * a.n_tiles, gy), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_gemm_splitk_kernel<NSPLIT, false>), dim3(a.m_tiles * a.n_tiles, gy), dim3(256), 0, st, a);
 }
 
 // split-K second pass: y = act(sum over the splits (fixed order) + bias + residual)

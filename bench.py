@@ -598,7 +598,7 @@ def main():
     # HIP-event durations in the timed region include what the co-running launches cost them (throughput goes up, every kernel takes
     # longer).  A short single-stream pass AFTER the timed region (not part of `value`) times the same five kernels alone; both sets
     # are reported (`frac` / `avg_launch_us` = timed region, `isolated_*` = alone).
-    iso_summ = None
+    iso_summ = iso_by_shape = None
     if args.overlap and top_only:
         pipe_iso = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
         E.PROFILE = E.LaunchProfile(only=top_only)
@@ -607,6 +607,7 @@ def main():
                 tail(pipe_iso.run(rgb[c], depth[c], S.REALSENSE_META, seed=i), (10 ** 6 + i, c))
         fence()
         iso_summ = E.PROFILE.summary()
+        iso_by_shape = E.PROFILE.summary(by_shape=True)
         E.PROFILE = None
 
     if rank == 0:
@@ -644,9 +645,23 @@ def main():
                 bound, peak, unit = kernel_peak(label)
                 sec = d["ms"] * 1e-3
                 ach = (d["bytes"] / sec / 1e9) if bound == "hbm" else (d["flop"] / sec / 1e12)
-                shapes.append({"shape": shape, "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
-                               "gflop": round(d["flop"] / d["launches"] / 1e9, 3), "algorithmic_mb": round(d["bytes"] / d["launches"] / 1e6, 1),
-                               "achieved": round(ach, 2), "frac": round(ach / peak, 4)})
+                row = {"shape": shape, "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
+                       "gflop": round(d["flop"] / d["launches"] / 1e9, 3), "algorithmic_mb": round(d["bytes"] / d["launches"] / 1e6, 1),
+                       "achieved": round(ach, 2), "frac": round(ach / peak, 4)}
+                # the shape's OWN roofline: whichever of the two limits (algorithmic flop at the kernel's matrix peak, algorithmic bytes at
+                # the HBM peak) takes longer bounds it -- a 1x1 layer with K = 128 is an HBM-bound launch of an MFMA kernel
+                if bound == "mfma":
+                    t_flop, t_hbm = d["flop"] / (peak * 1e12), d["bytes"] / (PEAK_HBM_GBS * 1e9)
+                    row["hbm_frac"] = round(t_hbm / sec, 4)
+                    row["roofline_bound"] = "hbm" if t_hbm > t_flop else "mfma"
+                    row["roofline_frac"] = round(max(t_flop, t_hbm) / sec, 4)
+                    di = iso_by_shape.get((lab, shape)) if iso_by_shape else None
+                    if di:
+                        sec_i = di["ms"] * 1e-3
+                        row["isolated_avg_launch_us"] = round(di["ms"] / di["launches"] * 1e3, 1)
+                        row["isolated_frac"] = round(di["flop"] / sec_i / 1e12 / peak, 4)
+                        row["isolated_roofline_frac"] = round(max(di["flop"] / (peak * 1e12), di["bytes"] / (PEAK_HBM_GBS * 1e9)) / sec_i, 4)
+                shapes.append(row)
             kernels.append(entry(label, summ[label], shapes))
         # the dominant kernel: largest summed time over the timed region (deterministic given the timings)
         roofline = None
@@ -655,7 +670,9 @@ def main():
             roofline["kernels"] = kernels
             roofline["note"] = ("achieved = algorithmic flop (2*M*Cout*KH*KW*Cin; a split-bf16 kernel issues 3 MFMAs per product, so its peak is the bf16 "
                                 "dense peak / 3) or algorithmic bytes per launch / HIP-event time on the launch stream, timed region only; traffic = "
-                                "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), averaged over the kernel's shapes"
+                                "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), averaged over the kernel's shapes; per shape: roofline_bound / "
+                                "roofline_frac price the launch against the slower of its two limits (algorithmic flop at the matrix peak, algorithmic bytes "
+                                "at 8 TB/s), hbm_frac = the byte limit alone"
                                 + ("; the loop is software-pipelined (pose stage of the previous batch on a second stream beside these kernels), so the "
                                    "timed-region durations include the co-running launches; isolated_* = the same kernels in a single-stream pass "
                                    "of 3 steps after the timed region" if args.overlap else ""))
