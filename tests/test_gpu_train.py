@@ -523,6 +523,38 @@ def test_weight_bank_operands_equal_the_per_call_packing_bitwise(shape, precisio
     check(bank2)
 
 
+def test_weight_bank_of_a_column_block_packs_in_place_and_follows_the_optimizer():
+    """network.py:104-121 feeds conv1_r/t/c two COLUMN blocks of one [640, 1408, 1] weight (`W[:, :384]` on the point features,
+    `W[:, 384:]` on the global feature): their banks are packed straight from the parameter's storage (row stride 1408, `src_ld`), kept on
+    the parameter, and refreshed by Adam.step() together with the parameter's own bank"""
+    from autoposeestimation_amd import autograd as AG
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(21)
+    w = torch.nn.Parameter(torch.randn(640, 1408, 1, generator=g).to(DEV))
+    w2 = w[:, :, 0]
+    blocks = [w2[:, :384], w2[:, 384:]]
+
+    def check():
+        for blk in (w2[:, :384], w2[:, 384:]):
+            bank = AG.weight_bank(blk, "bf16x3")
+            assert bank.version is not None and bank.src.data_ptr() == blk.data_ptr()            # no dense copy was made
+            dense = blk.detach().contiguous()
+            for tr, ref_w in ((False, dense[:, :, None, None]), (True, dense.t().contiguous()[:, :, None, None])):
+                want = E.Conv(ref_w, device=DEV, precision="bf16x3")
+                got = bank.conv(tr, 1, 0, 1, E.ACT_NONE)
+                assert torch.equal(got.w, want.w) and torch.equal(got.wp.view(torch.int16), want.wp.view(torch.int16))
+    check()
+    banks = [AG.weight_bank(b, "bf16x3") for b in blocks]
+    assert [AG.weight_bank(b, "bf16x3") for b in (w2[:, :384], w2[:, 384:])] == banks           # fresh views find the kept banks
+    opt = AG.Adam([w], lr=1e-2)
+    w.grad = torch.randn(640, 1408, 1, generator=g).to(DEV)
+    before = w.detach().clone()
+    opt.step()
+    assert not torch.equal(before, w.detach())
+    assert [AG.weight_bank(b, "bf16x3") for b in (w2[:, :384], w2[:, 384:])] == banks           # refreshed in place
+    check()
+
+
 def test_multi_tensor_adam_equals_the_one_buffer_kernel_bitwise():
     """ape_adam_step_multi_f32 (all parameters in one launch, 64 per launch: 150 buffers = 3 launches) against ape_adam_step_f32 buffer by
     buffer, three steps, buffers of 1 .. 3 M elements, one without a gradient"""
