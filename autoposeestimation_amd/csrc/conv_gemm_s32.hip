@@ -56,7 +56,7 @@ struct GemmS32Args {
     int m_tiles, n_tiles, nk;
     int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads;
                             // 16: per-workgroup k-tile rotation (valid results; tested against L2 hot-spotting on the shared weight lines: +-0);
-                            // 32: no static priority for waves 4-7
+                            // 32: no static priority for waves 4-7; 64: one tile per workgroup (no persistent walk)
 };
 
 // NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
@@ -115,8 +115,11 @@ __device__ __forceinline__ void keep_regs(const u32x4& a, const u32x4& b)
 constexpr int BM = 256;
 constexpr int A_STAGE = BM * 128;        // bytes of the A image of one k-tile
 
-template <int BN>
-__global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
+// RES: the build with the residual operand.  Its epilogue needs 64 more registers (the residual tile requested four rows ahead), which the
+// tile walk below cannot spare (hipcc spills 116 VGPRs in the loop form), so it stays one tile per workgroup: has_next is constant false
+// and the tile loop folds away.
+template <int BN, bool RES>
+__device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)      // (see APE_DS_READ: the host pass only needs the kernel's stub)
     constexpr int TN = BN / 64;                  // 16-channel blocks per wave
@@ -128,52 +131,68 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     constexpr int B_BASE = NA * A_STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // PERSISTENT workgroups: gridDim.x = G <= tiles; this workgroup walks the tiles first, first + G, ... (`first` = the XCD-aware
+    // position of the block among the G resident ones, so at any time the chip works on G consecutive tiles: the channel tiles of a
+    // pixel tile, and neighbouring pixel tiles, side by side on one XCD).  The k-tile stream runs THROUGH the tile boundary: the DMA
+    // requests of the next tile's first k-tiles go out from the last k-tiles of this one (same ring discipline), so they land while
+    // the epilogue stores this tile, instead of a cold start behind a drained workgroup.  G = tiles reproduces one tile per workgroup.
     const int nwg = a.m_tiles * a.n_tiles;
+    const int G = gridDim.x;
     const int orig = blockIdx.x;
-    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-    const int n_tile = logical % a.n_tiles;
-    const int m_tile = logical / a.n_tiles;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int xcd = orig % 8, q = G / 8, r = G % 8;
+    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
     // ---- LDS-DMA sources: buffer descriptors whose range ends at the last valid row (rows beyond read as zeros) -----------
-    const long a_bytes = ((long)(a.M - m0) * a.ldx - a.xoff) * 4;
-    const long b_bytes = (long)(a.Cout - n0) * a.K * 4;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.x + ((long)m0 * a.ldx + a.xoff) * 4), 0, (int)(a_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)a_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.w + (long)n0 * a.K * 4), 0, (int)(b_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)b_bytes), 0x00020000);
+    auto make_rs_a = [&](int m0_) {
+        const long a_bytes = ((long)(a.M - m0_) * a.ldx - a.xoff) * 4;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((long)m0_ * a.ldx + a.xoff) * 4), 0,
+                                                 (int)(a_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)a_bytes), 0x00020000);
+    };
+    auto make_rs_b = [&](int n0_) {
+        const long b_bytes = (long)(a.Cout - n0_) * a.K * 4;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long)n0_ * a.K * 4), 0,
+                                                 (int)(b_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)b_bytes), 0x00020000);
+    };
+    int m0 = (logical / a.n_tiles) * BM, n0 = (logical % a.n_tiles) * BN;
+    __amdgpu_buffer_rsrc_t rs_a = make_rs_a(m0), rs_b = make_rs_b(n0);
+    bool has_next = false;                                    // (the NEXT tile's descriptors are built where a k-tile index wraps into it)
     // one DMA = 8 rows x 128 B: lanes 8 r .. 8 r + 7 fetch ONE row (a whole 128-B line), its 16-B chunks permuted by the row's XOR
     // swizzle ((row >> 1) & 7: the rows of a block are 8-aligned, so this is ((lane >> 4) & 3) | parity-free bits of the block)
+    // (every per-lane address below is rebuilt at the start of each tile from an opaque copy of the lane id: kept loop-invariant they would
+    // stay live across the epilogue, which needs the registers)
     unsigned va[4], vb[NB];
+    auto setup_dma_lane = [&](int ln) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        va[i] = (unsigned)(row * a.ldx * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + (ln >> 3);
+            va[i] = (unsigned)(row * a.ldx * 4 + (((ln & 7) ^ ((row >> 1) & 7)) * 16));
+        }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int row = (wave * NB + i) * 8 + (lane >> 3);
-        vb[i] = (unsigned)(row * a.K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
-    }
+        for (int i = 0; i < NB; ++i) {
+            const int row = (wave * NB + i) * 8 + (ln >> 3);
+            vb[i] = (unsigned)(row * a.K * 4 + (((ln & 7) ^ ((row >> 1) & 7)) * 16));
+        }
+    };
+    setup_dma_lane(lane);
     // experiment (dbg bit 16): every workgroup starts its k-loop at a different k-tile (sum order changes, results stay valid)
-    const int krot = (a.dbg & 16) ? (m_tile * 5 + n_tile * 3) % a.nk : 0;
+    const int krot = ((a.dbg & 16) && G == nwg) ? ((logical / a.n_tiles) * 5 + (logical % a.n_tiles) * 3) % a.nk : 0;
     auto koff = [&](int kt) { const int k = kt + krot; return (k >= a.nk ? k - a.nk : k) * 128; };
     auto dma_a = [&](int kt, int slot_bytes) {        // 4 pieces per wave into A ring slot `slot_bytes` / A_STAGE
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], koff(kt), 0, 0);
     };
-    auto dma_a_piece = [&](int kt, int slot_bytes, int i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], koff(kt), 0, 0);
+    // (the in-loop pieces: `rs` = this tile's or the next tile's descriptor, chosen once per k-tile; k-tile index already reduced)
+    auto dma_a_piece = [&](__amdgpu_buffer_rsrc_t rs, int kt, int slot_bytes, int i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot_bytes + (wave * 4 + i) * 1024), 16, va[i], koff(kt), 0, 0);
     };
-    auto dma_b_piece = [&](int kt, int stage, int i) {
+    auto dma_b_piece = [&](__amdgpu_buffer_rsrc_t rs, int kt, int stage, int i) {
         if (i < NB)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], koff(kt), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + B_BASE + stage * B_STAGE + (wave * NB + i) * 1024), 16, vb[i], koff(kt), 0, 0);
     };
     auto dma_b = [&](int kt, int stage) {             // NB pieces per wave
 #pragma unroll
@@ -182,17 +201,26 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     };
 
     // ---- fragment addresses: lane (frow, fc) reads chunk fc (hi) / 4 + fc (lo) of row frow of a 16-row block ----------------
-    const int frow = lane & 15, fc = lane >> 4;
+    int frow = lane & 15, fc = lane >> 4;
     // LDS image: rows of 128 B, 16-B chunk c of row r at slot c ^ ((r >> 1) & 7).  The hi chunk fc and the lo chunk 4 + fc of a lane
     // are 64 B apart, but on which side depends on the row: one base register per plane; the 16-row block (i | j) is at + 2048,
     // an immediate.  B: one pair per stage (compile-time stage); A: the ring slot of the current tile ([0]) and of the next one
     // ([1]) rotate, two v_add per k-tile.
-    const int swz = (frow >> 1) & 7;
-    const int lane_hi = frow * 128 + ((fc ^ swz) * 16), lane_lo = frow * 128 + (((4 + fc) ^ swz) * 16);
-    const unsigned a_lane[2] = {(unsigned)(wm * 16 * 1024 + lane_hi), (unsigned)(wm * 16 * 1024 + lane_lo)};
-    unsigned a_addr[2][2] = {{a_lane[0], a_lane[1]}, {a_lane[0] + A_STAGE, a_lane[1] + A_STAGE}};
-    const unsigned b_addr[2][2] = {{(unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_hi), (unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_lo)},
-                                   {(unsigned)(B_BASE + B_STAGE + wn * (TN * 2) * 1024 + lane_hi), (unsigned)(B_BASE + B_STAGE + wn * (TN * 2) * 1024 + lane_lo)}};
+    unsigned a_lane[2], a_addr[2][2], b_addr[2][2];
+    auto setup_frag_lane = [&](int ln, int slot_cur) {       // slot_cur: byte offset of the A ring slot of the tile's first k-tile
+        frow = ln & 15;
+        fc = ln >> 4;
+        const int swz = (frow >> 1) & 7;
+        const int lane_hi = frow * 128 + ((fc ^ swz) * 16), lane_lo = frow * 128 + (((4 + fc) ^ swz) * 16);
+        a_lane[0] = (unsigned)(wm * 16 * 1024 + lane_hi);
+        a_lane[1] = (unsigned)(wm * 16 * 1024 + lane_lo);
+        const int slot_nxt = slot_cur + A_STAGE == NA * A_STAGE ? 0 : slot_cur + A_STAGE;
+        a_addr[0][0] = a_lane[0] + (unsigned)slot_cur; a_addr[0][1] = a_lane[1] + (unsigned)slot_cur;
+        a_addr[1][0] = a_lane[0] + (unsigned)slot_nxt; a_addr[1][1] = a_lane[1] + (unsigned)slot_nxt;
+        b_addr[0][0] = (unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_hi); b_addr[0][1] = (unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_lo);
+        b_addr[1][0] = b_addr[0][0] + B_STAGE; b_addr[1][1] = b_addr[0][1] + B_STAGE;
+    };
+    setup_frag_lane(lane, 0);
     // The fragment reads are inline asm so that they stay where the schedule puts them -- at the HEAD of the phase before the one
     // that consumes them (left to hipcc they sink to the last use of the registers they reuse, i.e. to the end of the phase, in
     // front of the wait) -- which also makes their completion invisible to the compiler: every phase ends with lgkmcnt(0) and a
@@ -282,13 +310,32 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NB) : "memory");
     else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int slot_free = 0;             // byte offset of the A ring slot that holds the current tile (free after its barrier)
+#pragma unroll 1
+    for (;;) {
+    // A tile after the first: its k-tiles 0, 1 (and A of 2) were requested from the previous tile's last k-tiles and the ring
+    // positions simply continue (nk is even on this path, so k-tile 0 is B stage 0 again).
+    has_next = !RES && logical + G < nwg;
+    {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        setup_dma_lane(ln);
+        setup_frag_lane(ln, slot_free);
+        // every fragment register is (re)defined below before its first use: tell the allocator so (no instruction)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "=v"(A[st][i][0]), "=v"(A[st][i][1]));
+#pragma unroll
+            for (int j = 0; j < TNH; ++j) asm volatile("" : "=v"(B[st][j][0]), "=v"(B[st][j][1]));
+        }
+    }
     __builtin_amdgcn_s_barrier();
     read_a(I0{}, I0{}, I0{});
     read_b(I0{}, I0{}, I0{});
     phase_end();
     keep_a(I0{});
     keep_b(I0{});
-    int slot_free = 0;             // byte offset of the A ring slot that holds the current tile (free after its barrier)
 
     // one k-tile; X = kt & 1 = its B stage = the B register set that holds its B0
     auto ktile = [&](int kt, auto xc) {
@@ -308,22 +355,27 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
         phase_end();
         keep_a(I1{});
         // every read of tile kt is back; tile kt+1 must have landed (only A(kt+2)'s four pieces may still be in flight)
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + 2 < nk || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!ABL(2)) __builtin_amdgcn_s_barrier();
-        const bool more_b = kt + 2 < nk && !ABL(1), more_a = kt + 3 < nk && !ABL(1);
+        const bool more_b = (kt + 2 < nk || has_next) && !ABL(1), more_a = (kt + 3 < nk || has_next) && !ABL(1);
+        // k-tiles past the end of this tile are the first ones of the next tile
+        const bool wrap_b = kt + 2 >= nk, wrap_a = kt + 3 >= nk;
+        const int nl = logical + G;
+        const __amdgpu_buffer_rsrc_t rs_b_use = wrap_b ? make_rs_b((nl % a.n_tiles) * BN) : rs_b, rs_a_use = wrap_a ? make_rs_a((nl / a.n_tiles) * BM) : rs_a;
+        const int kb = wrap_b ? kt + 2 - nk : kt + 2, ka = wrap_a ? kt + 3 - nk : kt + 3;
         const int slot = slot_free;
         slot_free = slot_free + A_STAGE == NA * A_STAGE ? 0 : slot_free + A_STAGE;
         __builtin_amdgcn_sched_barrier(0);
         // phase 2: (A1, B1) while A0 of the next tile is read; B(kt+2) goes out piece by piece between the MFMA rows
         read_a(I1{}, I0{}, I0{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma(I1{}, I1{}, I1{}, T{}, [&](int i) { if (more_b) dma_b_piece(kt + 2, X, i); });
+        mfma(I1{}, I1{}, I1{}, T{}, [&](int i) { if (more_b) dma_b_piece(rs_b_use, kb, X, i); });
         phase_end();
         keep_a(I0{});
         // phase 3: (A1, B0) while B0 of the next tile is read into the set B1 just left; A(kt+3) goes out likewise
         read_b(T{}, I0{}, T{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma(I1{}, I1{}, I0{}, S{}, [&](int i) { if (more_a) dma_a_piece(kt + 3, slot, i); });
+        mfma(I1{}, I1{}, I0{}, S{}, [&](int i) { if (more_a) dma_a_piece(rs_a_use, ka, slot, i); });
         // rotate the A slot addresses: next becomes current, the one after it is slot_free + A_STAGE (mod the ring)
         {
             const int nxt = slot_free + A_STAGE == NA * A_STAGE ? 0 : slot_free + A_STAGE;
@@ -342,7 +394,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
     if (kt < nk) ktile(kt, I0{});
 
     // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel 16 i + frow ---------
-    const int nq = n0 + wn * (TN * 16) + fc * 4;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int frow_e = lane_e & 15, fc_e = lane_e >> 4;
+    const int nq = n0 + wn * (TN * 16) + fc_e * 4;
     const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);
     const bool sigm = a.act == APE_ACT_SIGMOID;
     float4 b4[TN];
@@ -360,10 +415,10 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
 #pragma unroll
     for (int i0 = 0; i0 < 8; i0 += 4) {
         uint2 rlo[4][TN], rhi[4][TN];
-        if (a.res) {
+        if constexpr (RES) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
-                const int m = m0 + wm * 128 + (i0 + ii) * 16 + frow;
+                const int m = m0 + wm * 128 + (i0 + ii) * 16 + frow_e;
                 const size_t mc = m < a.M ? m : a.M - 1;                       // (a clamped, never-used address for rows past M)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -378,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = i0 + ii;
-            const int m = m0 + wm * 128 + i * 16 + frow;
+            const int m = m0 + wm * 128 + i * 16 + frow_e;
             if (m >= a.M) continue;
             const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
 #pragma unroll
@@ -388,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
                 float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
                 else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
-                if (a.res) {
+                if constexpr (RES) {
                     if (rs32) {
                         const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[ii][j]), l = __builtin_bit_cast(bf16x4, rhi[ii][j]);
                         // (hi + lo first, then the add: the order of the row-at-a-time form)
@@ -415,15 +470,42 @@ __global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
             }
         }
     }
+    if (RES || !has_next) break;
+    // ---- on to the next tile: its first k-tiles are in flight or landed ----
+    logical += G;
+    m0 = (logical / a.n_tiles) * BM;
+    n0 = (logical % a.n_tiles) * BN;
+    rs_a = make_rs_a(m0);
+    rs_b = make_rs_b(n0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    // (vmcnt(0) also drains this tile's stores -- issued up to an epilogue ago, mostly acknowledged by now)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 #endif
 }
 
 template <int BN>
-int launch_s32(GemmS32Args& a, hipStream_t st)
+__global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
+{
+    gemm_s32_body<BN, false>(a);
+}
+template <int BN>
+__global__ __launch_bounds__(512, 2) void gemm_s32_res_kernel(const GemmS32Args a)
+{
+    gemm_s32_body<BN, true>(a);
+}
+
+template <int BN, bool RES>
+int launch_s32_res(GemmS32Args& a, hipStream_t st)
 {
     constexpr size_t lds = 3 * (size_t)A_STAGE + 2 * (size_t)BN * 128;
-    auto kern = gemm_s32_kernel<BN>;
-    static bool attr_set = false;
+    auto kern = RES ? gemm_s32_res_kernel<BN> : gemm_s32_kernel<BN>;
+    static bool attr_set = false;      // (one per instantiation of this function, i.e. per kernel)
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -433,8 +515,25 @@ int launch_s32(GemmS32Args& a, hipStream_t st)
     }
     a.m_tiles = ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(512), lds, st, a);
+    // persistent walk (one workgroup per CU) where the k-tile stream can run through the tile boundary: an even number of k-tiles (the
+    // weight stage parity repeats) and at least four (the look-ahead of three stays inside one tile); dbg bit 64: one tile per workgroup
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { ape::set_last_error("hipGetDeviceProperties"); return APE_ELAUNCH; }
+        ncu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    const int tiles = a.m_tiles * a.n_tiles;
+    const bool walk = !RES && !(a.dbg & 64) && a.nk >= 4 && a.nk % 2 == 0 && tiles > ncu;
+    hipLaunchKernelGGL(kern, dim3(walk ? ncu : tiles), dim3(512), lds, st, a);
     return ape::check_launch("ape_conv_gemm_s32");
+}
+
+template <int BN>
+int launch_s32(GemmS32Args& a, hipStream_t st)
+{
+    return a.res ? launch_s32_res<BN, true>(a, st) : launch_s32_res<BN, false>(a, st);
 }
 
 bool supported_s32(const ape_conv_params& p)

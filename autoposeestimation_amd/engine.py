@@ -352,7 +352,7 @@ def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride,
     else:
         if not _lib.lib().ape_conv_gemm_s32_supported(ctypes.byref(p)):
             raise ValueError("no S32 kernel for this layer geometry (%dx%d, stride %d, Cin %d, Cout %d)" % (self.kh, self.kw, self.stride, self.cin, self.cout))
-        label = "gemm_s32_kernel<%d>" % (128 if self.cout <= 128 else 192 if (-(-self.cout // 192) * 192 - self.cout) < (-(-self.cout // 256) * 256 - self.cout) else 256)
+        label = ("gemm_s32_res_kernel<%d>" if res_t is not None else "gemm_s32_kernel<%d>") % (128 if self.cout <= 128 else 192 if (-(-self.cout // 192) * 192 - self.cout) < (-(-self.cout // 256) * 256 - self.cout) else 256)
     e0 = _prof_begin(label)
     fn = _lib.lib().ape_conv3x3_halo_s32 if is3 else _lib.lib().ape_conv_gemm_s32
     rc = fn(_lib.dptr(xt, torch.float32), _lib.dptr(self.s32k()), _lib.dptr(bias), _lib.dptr(res_t), res_fmt,
