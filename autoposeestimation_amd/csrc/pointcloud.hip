@@ -1314,10 +1314,11 @@ __global__ __launch_bounds__(64) void icp_reduce_step_batch(const Batch<BIcp> b,
 // hipCUB's radix sort walks all 64 key bits in 8 passes of several launches (its segmented form: 405 us per call for eight 5 k-point
 // segments -- half the label path's GPU time); the keys are cell coordinates of a compact cloud, so here (cx, cy, cz) is re-coded as the
 // lexicographic rank (cx * ny + cy) * nz + cz < 2^46 (ny, nz: 1 + the cloud's largest cell coordinate; same order as the packed 3 x 21-bit
-// key), packed with the 17-bit index into ONE 64-bit word and sorted by a bitonic network in LDS (runs of 16 k words = 128 KB, one
-// workgroup per run; ascending-everywhere "flip + disperse" form, so positions past n act as +infinity without being stored); a cloud of
+// key), packed with the 17-bit index into ONE 64-bit word, and runs of 16 k words (128 KB of LDS, one workgroup per run) are sorted by a
+// stable LSD radix sort over the rank's bits only (radix_lds: 4 bits per pass, 5 passes for a 10^6-cell grid; a first version used a
+// bitonic network in LDS -- ~78 trips of every word through LDS, LDS-bandwidth bound at 88 us per call against 52 now); a cloud of
 // several runs (a raw 640x480 surface: 20..60 k points) is then merged by rank (seg_merge_batch).  Clouds beyond 128 k points or 2^46
-// cells take the same network over the global key / index arrays with the (key, index) compare.
+// cells take a bitonic network over the global key / index arrays with the (key, index) compare.
 struct BSort { const u64* k_in; const unsigned* i_in; u64* k_out; unsigned* i_out; u64* k_scratch; unsigned* i_scratch; int* flag; int n, gx; };
 constexpr int kSortLdsMax = 16384, kSortRuns = 8, kSortIdxBits = 17;       // runs of 16 k words (128 KB of LDS), 8 x 16 k = 2^17 indices
 
@@ -1360,53 +1361,84 @@ __device__ __forceinline__ void bitonic_network(int n, CE cmpex)
     }
 }
 
-__device__ __forceinline__ void cswap(u64& x, u64& y) { const u64 lo = x < y ? x : y, hi = x < y ? y : x; x = lo; y = hi; }
-// the network's steps of stride 4, 2, 1 on eight neighbours held in registers
-__device__ __forceinline__ void disperse8(u64 (&v)[8])
+// LDS position of sort word i: two pad words behind every 32, so that the lanes of a wave, each reading ITS run of consecutive words
+// (radix_lds: lane stride E words), do not all start in the same banks
+__device__ __forceinline__ int sw(int i) { return i + ((i >> 5) << 1); }
+
+// STABLE least-significant-digit radix sort of the n <= 16 k words at s[sw(i)] by the bits [shift0, shift0 + bits) (the cell rank; the
+// words start in index order, so stability IS the (key, index) order), 4 bits per pass, in place.  The bitonic network above moves every
+// word through LDS ~78 times for 16 k words (LDS-bandwidth bound: 88 us); this moves it twice per pass and a 10^6-cell grid is 5
+// passes.  Thread t owns the E = ceil(n / 1024) consecutive words [t E, (t + 1) E): it counts their digits into sixteen 16-bit fields
+// packed in four 64-bit registers (fields never exceed n <= 16384, so packed adds do not carry), an inclusive scan of the packed words over
+// the lanes (shuffles) and the waves gives each thread its first slot per digit -- digit-major, thread-minor, word order: stable --
+// and after a barrier (every thread holds its words in registers) the words are written to their slots.
+__device__ __forceinline__ void radix_lds(u64* s, int n, int shift0, int bits)
 {
-    cswap(v[0], v[4]); cswap(v[1], v[5]); cswap(v[2], v[6]); cswap(v[3], v[7]);
-    cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
-    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
-}
-__device__ __forceinline__ void sort8(u64 (&v)[8])
-{
-    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);                       // k = 2
-    cswap(v[0], v[3]); cswap(v[1], v[2]); cswap(v[4], v[7]); cswap(v[5], v[6]);                       // k = 4: flip
-    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
-    cswap(v[0], v[7]); cswap(v[1], v[6]); cswap(v[2], v[5]); cswap(v[3], v[4]);                       // k = 8: flip
-    cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
-    cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
-}
-// LDS words s[0, n8), n8 a multiple of 8 with +infinity in [n, n8): strides >= 8 through LDS, strides 4, 2, 1 in registers (one barrier
-// for three steps, 16-byte LDS accesses)
-template <bool First>
-__device__ __forceinline__ void regs8_pass(u64* s, int n8)
-{
-    for (int g = threadIdx.x * 8; g < n8; g += blockDim.x * 8) {
-        u64 v[8];
-        #pragma unroll
-        for (int e = 0; e < 8; e += 2) { const ulonglong2 t = *reinterpret_cast<const ulonglong2*>(s + g + e); v[e] = t.x; v[e + 1] = t.y; }
-        if (First) sort8(v); else disperse8(v);
-        #pragma unroll
-        for (int e = 0; e < 8; e += 2) *reinterpret_cast<ulonglong2*>(s + g + e) = ulonglong2{v[e], v[e + 1]};
-    }
-}
-__device__ __forceinline__ void bitonic_lds(u64* s, int n8)
-{
-    int lpad = 3;
-    while ((1 << lpad) < n8) ++lpad;
-    const int half_pairs = (1 << lpad) >> 1;
-    auto cmpex = [&](int i, int l) { const u64 x = s[i], y = s[l]; if (x > y) { s[i] = y; s[l] = x; } };
-    regs8_pass<true>(s, n8);
-    __syncthreads();
-    for (int lk = 4; lk <= lpad; ++lk) {
-        bitonic_flip(n8, lk, half_pairs, cmpex);
-        __syncthreads();
-        for (int lj = lk - 2; lj >= 3; --lj) {
-            bitonic_disperse(n8, lj, half_pairs, cmpex);
-            __syncthreads();
+    __shared__ u64 wave_tot[kCT / 64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = (n + kCT - 1) / kCT;                       // <= 16
+    const int base = tid * E;
+    for (int shift = shift0; shift < shift0 + bits; shift += 4) {
+        u64 v[16];
+        u64 cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < E && base + e < n) {
+                v[e] = s[sw(base + e)];
+                const int d = (int)(v[e] >> shift) & 15;
+                const u64 inc = 1ULL << ((d & 3) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cnt[q] += (d >> 2) == q ? inc : 0ULL;
+            } else {
+                v[e] = 0;
+            }
         }
-        regs8_pass<false>(s, n8);
+        u64 inc4[4] = {cnt[0], cnt[1], cnt[2], cnt[3]};
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u64 t = (u64)__shfl_up((unsigned long long)inc4[q], o, 64);
+                if (lane >= o) inc4[q] += t;
+            }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wave_tot[wave][q] = inc4[q];
+        }
+        __syncthreads();                                     // wave totals visible; every word of the pass is in a register
+        u64 pre[4] = {0, 0, 0, 0}, tot[4] = {0, 0, 0, 0};
+        for (int w = 0; w < kCT / 64; ++w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u64 t = wave_tot[w][q];
+                tot[q] += t;
+                pre[q] += w < wave ? t : 0ULL;
+            }
+        }
+        u64 start[4] = {0, 0, 0, 0};
+        unsigned run = 0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const int q = d >> 2, sh = (d & 3) * 16;
+            const unsigned total = (unsigned)(tot[q] >> sh) & 0xFFFFu;
+            const unsigned mine = run + ((unsigned)(pre[q] >> sh) & 0xFFFFu) + (((unsigned)(inc4[q] >> sh) & 0xFFFFu) - ((unsigned)(cnt[q] >> sh) & 0xFFFFu));
+            start[q] |= (u64)mine << sh;
+            run += total;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < E && base + e < n) {
+                const int d = (int)(v[e] >> shift) & 15;
+                const int q = d >> 2, sh = (d & 3) * 16;
+                const u64 word = q == 0 ? start[0] : q == 1 ? start[1] : q == 2 ? start[2] : start[3];
+                const int pos = (int)((word >> sh) & 0xFFFFu);
+                const u64 inc = 1ULL << sh;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) start[qq] += q == qq ? inc : 0ULL;
+                s[sw(pos)] = v[e];
+            }
+        }
         __syncthreads();
     }
 }
@@ -1440,20 +1472,22 @@ __global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
         for (int i = threadIdx.x; i < len; i += blockDim.x) {
             const u64 key = a.k_in[r0 + i];
             const u64 cx = key >> 42, cy = (key >> 21) & 2097151ULL, cz = key & 2097151ULL;
-            sort_lds[i] = ((((cx * dim[1]) + cy) * dim[2] + cz) << kSortIdxBits) | (u64)(r0 + i);       // i_in[i] == i (keys_kernel)
+            sort_lds[sw(i)] = ((((cx * dim[1]) + cy) * dim[2] + cz) << kSortIdxBits) | (u64)(r0 + i);       // i_in[i] == i (keys_kernel)
         }
-        const int n8 = (len + 7) & ~7;
-        if ((int)threadIdx.x < n8 - len) sort_lds[len + threadIdx.x] = ~0ULL;
         __syncthreads();
-        bitonic_lds(sort_lds, n8);
+        {
+            const u64 cells = dim[0] * dim[1] * dim[2];                       // exact: <= 2^46
+            const int bits = cells > 1 ? 64 - __builtin_clzll(cells - 1) : 0;
+            radix_lds(sort_lds, len, kSortIdxBits, bits);
+        }
         if (nruns == 1) {
             for (int i = threadIdx.x; i < len; i += blockDim.x) {
-                const unsigned src = (unsigned)(sort_lds[i] & ((1ULL << kSortIdxBits) - 1));
+                const unsigned src = (unsigned)(sort_lds[sw(i)] & ((1ULL << kSortIdxBits) - 1));
                 a.i_out[i] = src;
                 a.k_out[i] = a.k_in[src];
             }
         } else {
-            for (int i = threadIdx.x; i < len; i += blockDim.x) a.k_scratch[r0 + i] = sort_lds[i];     // a sorted run; seg_merge_batch places it
+            for (int i = threadIdx.x; i < len; i += blockDim.x) a.k_scratch[r0 + i] = sort_lds[sw(i)];     // a sorted run; seg_merge_batch places it
         }
         return;
     }
@@ -1527,10 +1561,11 @@ int keys_and_sort(int nb, const double* const* pts, const int* n, const int* off
     launch_batch(keys_batch, bk, nb, mg2, kT, st);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_batch), hipFuncAttributeMaxDynamicSharedMemorySize, kSortLdsMax * 8) != hipSuccess) return APE_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (kSortLdsMax + kSortLdsMax / 16) * 8) != hipSuccess) return APE_ELAUNCH;
         attr_set = true;
     }
-    const size_t lds = (size_t)(((nmax < kSortLdsMax ? nmax : kSortLdsMax) + 7) & ~7) * 8;
+    const size_t lds_words = (size_t)(((nmax < kSortLdsMax ? nmax : kSortLdsMax) + 31) & ~31);
+    const size_t lds = (lds_words + lds_words / 16) * 8;
     const int runs = (nmax + kSortLdsMax - 1) / kSortLdsMax;
     hipLaunchKernelGGL(seg_sort_batch, dim3(runs < 1 ? 1 : (runs > kSortRuns ? kSortRuns : runs), nb), dim3(kCT), lds, st, bs);
     if (runs > 1) launch_batch(seg_merge_batch, bs, nb, mg2, kT, st);

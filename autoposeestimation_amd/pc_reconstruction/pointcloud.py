@@ -47,10 +47,21 @@ class _Points:
         return self.t.shape[0]
 
 
+_EMPTY_POINTS = {}
+
+
+def _empty_points(device):
+    """the shared [0, 3] tensor of a device (an empty cloud has nothing to write to; the batched label path makes ~2 k clouds per step)"""
+    t = _EMPTY_POINTS.get(device)
+    if t is None:
+        t = _EMPTY_POINTS[device] = torch.zeros(0, 3, dtype=_D, device=device)
+    return t
+
+
 class PointCloud:
     def __init__(self, points=None, device="cuda"):
-        self.device = torch.device(device)
-        self._p = torch.zeros(0, 3, dtype=_D, device=self.device)
+        self.device = device if isinstance(device, torch.device) else torch.device(device)
+        self._p = _empty_points(self.device)
         self._n = None   # normals
         self._epoch = 0  # bumped by every in-place change of the coordinates (transform): invalidates the cached search grid
         self._gcache = None
