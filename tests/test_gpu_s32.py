@@ -38,6 +38,33 @@ def test_gemm_s32_equals_conv_gemm_bitwise(shape):
     assert (got.double() - ref).abs().max().item() <= 5e-5 * ref.abs().max().item()
 
 
+# more tiles than CUs: the residual-free kernel then WALKS its tiles (one workgroup per CU, the k-tile stream running through the tile
+# boundary); ragged M and Cout, 4 / 6 / 8 k-tiles, an odd k-tile count (no walk), both output formats
+@pytest.mark.parametrize("shape", [(16, 60, 80, 128, 256), (5, 61, 83, 256, 576), (10, 50, 70, 192, 300), (16, 60, 80, 160, 256)])
+@pytest.mark.parametrize("out_s32", [False, True])
+def test_gemm_s32_tile_walk_equals_one_tile_per_workgroup_bitwise(shape, out_s32):
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd import engine as E
+    b, h, w, cin, cout = shape
+    if out_s32 and cout % 32:
+        pytest.skip("S32 output needs Cout % 32 == 0")
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = (torch.randn(b, h, w, cin, generator=g) * 3).cuda()
+    conv = E.Conv(torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g), act=E.ACT_RELU, device="cuda", precision="bf16x3")
+    xs = E.S32.from_f32(x)
+    fmt = E.FMT_S32 if out_s32 else E.FMT_F32
+    try:
+        walk = conv(xs, out_fmt=fmt)
+        assert _lib.lib().ape_conv_gemm_s32_debug(64) == 0          # bit 64: one tile per workgroup
+        one = conv(xs, out_fmt=fmt)
+    finally:
+        _lib.lib().ape_conv_gemm_s32_debug(0)
+    wt, ot = (walk.t, one.t) if out_s32 else (walk, one)
+    assert torch.equal(wt.view(torch.int32), ot.view(torch.int32))
+    if not out_s32:
+        assert torch.equal(walk, conv(x))                            # and the fp32-activation kernel, as above
+
+
 def test_gemm_s32_output_residual_and_slices():
     from autoposeestimation_amd import engine as E
     g = torch.Generator().manual_seed(3)
