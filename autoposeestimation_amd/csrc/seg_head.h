@@ -86,14 +86,14 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
     // predict's activation, then F.softmax) the band is wider -- every class whose exp(p1 - p1max) rounds to 1.  torch.argmax returns
     // the LOWEST index of such a tie: take the lowest class whose last exponential is exactly 1 (the maximum itself always qualifies;
     // e == 1 implies p1 == p1max, so the two-softmax test contains the one-softmax one).
-    float pm = 1.f / s;
+    float pm = __builtin_amdgcn_rcpf(s);                    // v_rcp_f32 (1 ulp): `1.f / s` is a ten-instruction IEEE division
     float t[4];
     if (double_softmax) {
         const float inv = pm;
         float s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t[r] = (kq * 4 + r < C) ? __expf(e[r] * inv - pm) : 0.f; s2 += t[r]; }
-        pm = 1.f / quad_sum(s2, lane);
+        pm = __builtin_amdgcn_rcpf(quad_sum(s2, lane));
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = e[r];
@@ -173,7 +173,7 @@ __device__ __forceinline__ void seg_head_groups(const float4 (&x)[G][4], const f
     for (int g = 0; g < G; ++g) s[g] += lane_xor32(s[g], lane);
     float pm[G], t[G][4];
 #pragma unroll
-    for (int g = 0; g < G; ++g) pm[g] = 1.f / s[g];
+    for (int g = 0; g < G; ++g) pm[g] = __builtin_amdgcn_rcpf(s[g]);
     if (double_softmax) {
         float s2[G];
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ __forceinline__ void seg_head_groups(const float4 (&x)[G][4], const f
 #pragma unroll
         for (int g = 0; g < G; ++g) s2[g] += lane_xor32(s2[g], lane);
 #pragma unroll
-        for (int g = 0; g < G; ++g) pm[g] = 1.f / s2[g];
+        for (int g = 0; g < G; ++g) pm[g] = __builtin_amdgcn_rcpf(s2[g]);
     } else {
 #pragma unroll
         for (int g = 0; g < G; ++g)
