@@ -18,6 +18,8 @@ Differences from the reference that do not change results beyond fp32 rounding:
     from the full map);  `PSPNet.forward` still returns the full map;
   * `forward_batch` generalises the reference's batch-1-only forward (network.py:123, b = 0) to B independent crops.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -324,6 +326,9 @@ def _select_rows(w, b, obj, k):
 # ----------------------------------------------------------------------------------------------------------------
 # PointNet trunks and heads
 # ----------------------------------------------------------------------------------------------------------------
+S32_MIN_ROWS = int(os.environ.get("APE_POSE_S32_MIN_ROWS", "16384"))      # rows (crops x points) from which the PointNet trunk / heads take the pre-split route (256-row tiles; below, the 128-row blocks of conv_gemm fill the chip better)
+
+
 class _FeatPlan:
     """PoseNetFeat / PoseRefineNetFeat (network.py:39-68, 136-168) writing straight into the concatenated buffer
     pf[B*N, 384] = [conv1(x) 64 | e_conv1(emb) 64 | conv2 128 | e_conv2 128]."""
@@ -338,6 +343,8 @@ class _FeatPlan:
         self.conv5 = E.Conv(*g("conv5"), **kw)
         self.conv6 = E.Conv(*g("conv6"), **kw)
         self.refine = refine
+        self.precision = precision
+        self.pf_s32 = None
 
     def __call__(self, x4, emb):
         """x4[B,N,4], emb[B,N,32] -> pf[B,N,1,384], ap[B,1024]"""
@@ -349,8 +356,17 @@ class _FeatPlan:
         self.e_conv1(emb, out=pf, yoff=64)
         self.conv2(pf, out=pf, xoff=0, yoff=128)
         self.e_conv2(pf, out=pf, xoff=64, yoff=256)
-        x5 = self.conv5(pf, xoff=0 if self.refine else 128)
-        x6 = self.conv6(x5)
+        # Enough rows to fill 256-row tiles: the 1x1 layers run on PRE-SPLIT activations (conv_gemm_s32.hip, LDS-DMA operands) -- the same
+        # MFMA operands as the on-the-fly split of conv_gemm.hip, so every value below is bit for bit what the fp32 route gives
+        # (tests/test_gpu_posenet.py); `self.pf_s32` hands the split point features to the estimator's heads
+        self.pf_s32 = None
+        if self.precision == "bf16x3" and E.USE_S32 and b * n >= S32_MIN_ROWS:
+            pfs = self.pf_s32 = E.S32.from_f32(pf)
+            x5 = self.conv5(pfs, xoff=0 if self.refine else 128, out_fmt=E.FMT_S32)
+            x6 = self.conv6(x5)
+        else:
+            x5 = self.conv5(pf, xoff=0 if self.refine else 128)
+            x6 = self.conv6(x5)
         return pf, E.mean_rows(x6.view(b, n, 1024))
 
 
@@ -400,12 +416,19 @@ class PoseNet(_HipModule):
         emb = E.log_softmax_rows(pl.cnn.final(g.view(b, n, 1, 64)).view(b, n, 32))
         pf, ap = pl.feat(points4, emb)
         gb = pl.l1_global(ap.view(b, 1, 1, 1024)).view(b, 1920)            # W[:, 384:] . ap_x + b
-        h1 = pl.l1_point(pf, bias=gb, bias_bstride=1920)                    # [B,N,1,1920]
-        h2 = torch.empty(b, n, 1, 768, dtype=torch.float32, device=img4.device)
         h3 = torch.empty(b, n, 1, 384, dtype=torch.float32, device=img4.device)
-        for i in range(3):
-            pl.l2[i](h1, out=h2, xoff=640 * i, yoff=256 * i)
-            pl.l3[i](h2, out=h3, xoff=256 * i, yoff=128 * i)
+        if pl.feat.pf_s32 is not None:                                          # pre-split route (see _FeatPlan): h1, h2 stay split
+            h1 = pl.l1_point(pl.feat.pf_s32, bias=gb, bias_bstride=1920, out_fmt=E.FMT_S32)
+            h2 = E.S32(torch.empty(b, n, 1, 768, dtype=torch.float32, device=img4.device))
+            for i in range(3):
+                pl.l2[i](h1, out=h2, xoff=640 * i, yoff=256 * i, out_fmt=E.FMT_S32)
+                pl.l3[i](h2, out=h3, xoff=256 * i, yoff=128 * i)
+        else:
+            h1 = pl.l1_point(pf, bias=gb, bias_bstride=1920)                    # [B,N,1,1920]
+            h2 = torch.empty(b, n, 1, 768, dtype=torch.float32, device=img4.device)
+            for i in range(3):
+                pl.l2[i](h1, out=h2, xoff=640 * i, yoff=256 * i)
+                pl.l3[i](h2, out=h3, xoff=256 * i, yoff=128 * i)
         heads = E.head_select(h3.view(b * n, 384), 0, 128, 256, *pl.l4, obj, b, n, 128)
         if taps is not None:
             taps["pf"], taps["ap"], taps["emb"] = pf, ap, emb

@@ -168,3 +168,39 @@ def test_split_bf16_pose_within_tolerance(case, precision):
     E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
     np.testing.assert_allclose(pose[0, :4].cpu().numpy(), g["fin_r"], atol=1e-4)
     np.testing.assert_allclose(pose[0, 4:].cpu().numpy(), g["fin_t"], atol=1e-4)
+
+
+def test_presplit_route_of_the_pointnet_trunk_equals_the_fp32_route_bitwise():
+    """From 16 k rows (crops x points) the 1x1 layers of the PointNet trunk, the heads and the refiner trunk run on PRE-SPLIT activations
+    (conv_gemm_s32.hip): the same MFMA operands as the on-the-fly split, so heads / embedding / refiner output are bit for bit those
+    of the fp32-activation route (network.S32_MIN_ROWS moved out of reach switches it off)."""
+    from autoposeestimation_amd import engine as E
+    from autoposeestimation_amd.DenseFusion.lib import network as NW
+    g = golden("posenet_n1000_o12_40x40")
+    est, refiner = _models(12, 1000)
+    est.set_precision("bf16x3")
+    refiner.set_precision("bf16x3")
+    rng = np.random.default_rng(1)
+    B = 20                                                                    # 20 000 rows
+    img = torch.from_numpy(g["img"]).unsqueeze(0).cuda()
+    imgs = torch.cat([img + 0.1 * i for i in range(B)], 0)
+    pts = torch.from_numpy(g["points"]).unsqueeze(0).cuda()
+    ptss = torch.cat([pts * (1 + 0.01 * i) for i in range(B)], 0)
+    ch = torch.from_numpy(np.stack([rng.permutation(1600)[:1000] for _ in range(B)])).cuda()
+    obj = torch.from_numpy(rng.integers(0, 12, B)).cuda()
+    img4 = torch.zeros(B, 40, 40, 4, device="cuda")
+    img4[..., :3] = imgs.permute(0, 2, 3, 1)
+    p4 = E.pad3to4(ptss)
+    assert B * 1000 >= NW.S32_MIN_ROWS
+    heads, emb = est.forward_batch(img4, p4, ch, obj)
+    assert est.plan().feat.pf_s32 is not None                                 # the pre-split route ran
+    out = refiner.forward_batch(p4, emb, obj)
+    keep = NW.S32_MIN_ROWS
+    try:
+        NW.S32_MIN_ROWS = 1 << 40
+        heads0, emb0 = est.forward_batch(img4, p4, ch, obj)
+        assert est.plan().feat.pf_s32 is None
+        out0 = refiner.forward_batch(p4, emb0, obj)
+    finally:
+        NW.S32_MIN_ROWS = keep
+    assert torch.equal(heads, heads0) and torch.equal(emb, emb0) and torch.equal(out, out0)
