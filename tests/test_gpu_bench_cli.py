@@ -41,6 +41,12 @@ def test_default_line_has_roofline_cpu_baseline_and_parity():
     for k in ks:
         assert k["launches"] > 0 and k["avg_launch_us"] > 0 and 0 < k["frac"] < 1 and k["shapes"] and "isolated_frac" in k
         assert sum(s["launches"] for s in k["shapes"]) == k["launches"]
+        for s in k["shapes"]:                           # every shape priced against its OWN limit (flop at the matrix peak / bytes at 8 TB/s)
+            assert s["roofline_bound"] in ("hbm", "mfma") and 0 < s["roofline_frac"] < 1 and s["roofline_frac"] >= max(s["frac"], s["hbm_frac"]) - 1e-3
+            assert "isolated_roofline_frac" in s and s["isolated_avg_launch_us"] > 0
+    # the five kernels are ranked by what they cost alone: the first one is a segmentation conv kernel, not a starved pose-stage launch
+    iso = [k["isolated_avg_launch_us"] * k["launches"] for k in ks]
+    assert iso == sorted(iso, reverse=True) and ks[0]["kernel"].startswith(("halo_s32_kernel", "gemm_s32_kernel", "conv3x3_halo_kernel"))
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "single_thread_value", "cpu_model"):
         assert k in c, k
