@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from autoposeestimation_amd import _lib, engine as E  # noqa: E402
 
-OLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libape_hip_r2.so")
+OLD = os.environ.get("APE_AB_OLD") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libape_hip_r2.so")
 
 
 def bind(path):
