@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(64) void icp_reduce_step_batch(const Batch<BIcp> b,
 // bitonic network in LDS -- ~78 trips of every word through LDS, LDS-bandwidth bound at 88 us per call against 52 now); a cloud of
 // several runs (a raw 640x480 surface: 20..60 k points) is then merged by rank (seg_merge_batch).  Clouds beyond 128 k points or 2^46
 // cells take a bitonic network over the global key / index arrays with the (key, index) compare.
-struct BSort { const u64* k_in; const unsigned* i_in; u64* k_out; unsigned* i_out; u64* k_scratch; unsigned* i_scratch; int* flag; int n, gx; };
+struct BSort { const u64* k_in; const unsigned* i_in; u64* k_out; unsigned* i_out; u64* k_scratch; unsigned* i_scratch; int* flag; const double* bounds6; double h, shift; int n, gx; };
 constexpr int kSortLdsMax = 16384, kSortRuns = 8, kSortIdxBits = 17;       // runs of 16 k words (128 KB of LDS), 8 x 16 k = 2^17 indices
 
 // positions >= n are +infinity and never touched; all block sizes are powers of two, so the pair -> (i, l) maps are shifts, and i grows
@@ -1450,21 +1450,16 @@ __global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
     const int n = a.n, run = blockIdx.x;
     const int nruns = (n + kSortLdsMax - 1) / kSortLdsMax;
     if (n <= 0 || (run > 0 && run >= nruns)) return;
-    // cells per axis = 1 + the largest cell coordinate among THIS cloud's keys (every run's workgroup walks the whole cloud: same value)
-    __shared__ unsigned cmax[3];
-    if (threadIdx.x < 3) cmax[threadIdx.x] = 0;
-    __syncthreads();
-    {
-        unsigned mx = 0, my = 0, mz = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const u64 key = a.k_in[i];
-            const unsigned cx = (unsigned)(key >> 42), cy = (unsigned)((key >> 21) & 2097151ULL), cz = (unsigned)(key & 2097151ULL);
-            mx = cx > mx ? cx : mx; my = cy > my ? cy : my; mz = cz > mz ? cz : mz;
-        }
-        atomicMax(&cmax[0], mx); atomicMax(&cmax[1], my); atomicMax(&cmax[2], mz);
+    // cells per axis: the cell of the cloud's upper bound (the expression of keys_kernel on the bound itself: (p - origin) / h is monotone in
+    // p, so no point lands in a higher cell) + 2 -- any count above the largest coordinate keeps the rank's order; walking the keys for
+    // their maxima cost a global round trip and 3 k LDS atomics per call
+    u64 dim[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        long v = (long)floor((a.bounds6[3 + d] - (a.bounds6[d] - a.shift)) / a.h);
+        v = v < 0 ? 0 : (v > 2097151 ? 2097151 : v);
+        dim[d] = (u64)v + 2;
     }
-    __syncthreads();
-    const u64 dim[3] = {(u64)cmax[0] + 1, (u64)cmax[1] + 1, (u64)cmax[2] + 1};
     const bool compact = nruns <= kSortRuns && (double)dim[0] * (double)dim[1] * (double)dim[2] <= 70368744177664.0;      // 2^46
     if (run == 0 && threadIdx.x == 0) *a.flag = compact ? 1 : 0;
     if (compact) {
@@ -1482,9 +1477,10 @@ __global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
         }
         if (nruns == 1) {
             for (int i = threadIdx.x; i < len; i += blockDim.x) {
-                const unsigned src = (unsigned)(sort_lds[sw(i)] & ((1ULL << kSortIdxBits) - 1));
-                a.i_out[i] = src;
-                a.k_out[i] = a.k_in[src];
+                const u64 word = sort_lds[sw(i)];
+                a.i_out[i] = (unsigned)(word & ((1ULL << kSortIdxBits) - 1));
+                const u64 code = word >> kSortIdxBits, cxy = code / dim[2];      // the key back from its rank (no dependent gather of k_in)
+                a.k_out[i] = pack_key((long)(cxy / dim[1]), (long)(cxy % dim[1]), (long)(code % dim[2]));
             }
         } else {
             for (int i = threadIdx.x; i < len; i += blockDim.x) a.k_scratch[r0 + i] = sort_lds[sw(i)];     // a sorted run; seg_merge_batch places it
@@ -1551,7 +1547,7 @@ int keys_and_sort(int nb, const double* const* pts, const int* n, const int* off
         const int g = n[c] > 0 ? grid_for(n[c], 1024) : 0;
         bp.t[c] = BPts{pts[c], part + (size_t)c * (1024 * 6 + 8), part + (size_t)c * (1024 * 6 + 8) + 1024 * 6, n[c], g};
         bk.t[c] = BKeys{pts[c], bp.t[c].out6, k0 + off[c], i0 + off[c], origin ? origin[c] : nullptr, n[c], n[c] > 0 ? grid_for(n[c]) : 0, h, shift};
-        bs.t[c] = BSort{k0 + off[c], i0 + off[c], k_out[c], i_out[c], ks + off[c], is + off[c], reinterpret_cast<int*>(bp.t[c].out6 + 7), n[c], bk.t[c].gx};
+        bs.t[c] = BSort{k0 + off[c], i0 + off[c], k_out[c], i_out[c], ks + off[c], is + off[c], reinterpret_cast<int*>(bp.t[c].out6 + 7), bp.t[c].out6, h, shift, n[c], bk.t[c].gx};
         mg1 = g > mg1 ? g : mg1;
         mg2 = bk.t[c].gx > mg2 ? bk.t[c].gx : mg2;
         nmax = n[c] > nmax ? n[c] : nmax;
