@@ -1451,14 +1451,14 @@ __global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
     const int nruns = (n + kSortLdsMax - 1) / kSortLdsMax;
     if (n <= 0 || (run > 0 && run >= nruns)) return;
     // cells per axis: the cell of the cloud's upper bound (the expression of keys_kernel on the bound itself: (p - origin) / h is monotone in
-    // p, so no point lands in a higher cell) + 2 -- any count above the largest coordinate keeps the rank's order; walking the keys for
-    // their maxima cost a global round trip and 3 k LDS atomics per call
+    // p and the bound IS a point's coordinate, so this is the largest cell coordinate) + 1; walking the keys for their maxima cost a
+    // global round trip and 3 k LDS atomics per call
     u64 dim[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         long v = (long)floor((a.bounds6[3 + d] - (a.bounds6[d] - a.shift)) / a.h);
         v = v < 0 ? 0 : (v > 2097151 ? 2097151 : v);
-        dim[d] = (u64)v + 2;
+        dim[d] = (u64)v + 1;
     }
     const bool compact = nruns <= kSortRuns && (double)dim[0] * (double)dim[1] * (double)dim[2] <= 70368744177664.0;      // 2^46
     if (run == 0 && threadIdx.x == 0) *a.flag = compact ? 1 : 0;
