@@ -35,6 +35,10 @@ SIGNATURES = {
     "ape_conv_gemm_bf16_splitk": [_P, _P, _P, _P, _P, _P, _I, _P, _c.c_size_t, _P],
     "ape_adaptive_avgpool_multi_nhwc_fmt": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_upconv3x3_gather_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ape_upconv3x3_gather_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ape_upconv3x3_fused_supported": [_I, _I, _I, _I],
+    "ape_upconv3x3_fused_s32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ape_upconv3x3_fused_seghead_s32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _P, _P, _I, _P],
     "ape_conv3x3_halo_s32_supported": [_P],
     "ape_conv3x3_halo_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
     "ape_stem_conv_pool_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

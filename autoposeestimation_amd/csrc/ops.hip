@@ -356,7 +356,10 @@ __global__ void head_select_kernel(const float* __restrict__ h, int ldh, int off
 // and the upsampled 2h x 2w x Cin tensor is never written.
 constexpr int kUpCols = 12;     // low-resolution columns under 16 + 2 output columns at scale ~1/2 (at most 11)
 
-template <bool S32OUT>
+// FMA: the two interpolation steps as chained fused multiply-adds, acc = fma(l1, v1, fma(l0, v0, acc)), instead of the separately rounded
+// acc + (l0 * v0 + l1 * v1): half the vector instructions.  It is the arithmetic of the fused kernel's fast form (upconv_fused.hip), whose
+// unfused twin this kernel is; up_1 / up_2 keep the separately rounded form.
+template <bool S32OUT, bool FMA = false>
 __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __restrict__ z, const float* __restrict__ bias,
                                                             float4* __restrict__ out, int B, int h, int w, int C4, float sh, float sw,
                                                             int act, float alpha)
@@ -432,6 +435,13 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 if (!yok[ky]) continue;
+                if (FMA) {
+                    acc.x = fmaf(ly1[ky], v1[u][ky].x, fmaf(ly0[ky], v0[u][ky].x, acc.x));
+                    acc.y = fmaf(ly1[ky], v1[u][ky].y, fmaf(ly0[ky], v0[u][ky].y, acc.y));
+                    acc.z = fmaf(ly1[ky], v1[u][ky].z, fmaf(ly0[ky], v0[u][ky].z, acc.z));
+                    acc.w = fmaf(ly1[ky], v1[u][ky].w, fmaf(ly0[ky], v0[u][ky].w, acc.w));
+                    continue;
+                }
                 acc.x += ly0[ky] * v0[u][ky].x + ly1[ky] * v1[u][ky].x;
                 acc.y += ly0[ky] * v0[u][ky].y + ly1[ky] * v1[u][ky].y;
                 acc.z += ly0[ky] * v0[u][ky].z + ly1[ky] * v1[u][ky].z;
@@ -454,6 +464,13 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
             const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
             const float lx1 = fx - (float)ix0, lx0 = 1.f - lx1;
             const float4 s0 = S[(kx * kUpCols + ix0 - ix_lo) * C4 + c], s1 = S[(kx * kUpCols + ix1 - ix_lo) * C4 + c];
+            if (FMA) {
+                acc.x = fmaf(lx1, s1.x, fmaf(lx0, s0.x, acc.x));
+                acc.y = fmaf(lx1, s1.y, fmaf(lx0, s0.y, acc.y));
+                acc.z = fmaf(lx1, s1.z, fmaf(lx0, s0.z, acc.z));
+                acc.w = fmaf(lx1, s1.w, fmaf(lx0, s0.w, acc.w));
+                continue;
+            }
             acc.x += lx0 * s0.x + lx1 * s1.x;
             acc.y += lx0 * s0.y + lx1 * s1.y;
             acc.z += lx0 * s0.z + lx1 * s1.z;
@@ -725,7 +742,15 @@ extern "C" int ape_upconv3x3_gather_f32(const float* z, const float* bias, float
 extern "C" int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act,
                                         float alpha, void* stream)
 {
-    if ((out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) || (out_fmt == APE_FMT_S32 && C % 32)) return APE_EINVAL;
+    return ape_upconv3x3_gather_ex(z, bias, out, out_fmt, B, h, w, C, act, alpha, 0, stream);
+}
+
+/* ... and with the choice of the interpolation arithmetic: fma = 0 the separately rounded products of ape_bilinear_nhwc_f32, fma = 1 chained
+ * fused multiply-adds (the unfused twin of ape_upconv3x3_fused_* built with fma = 1) */
+extern "C" int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act,
+                                       float alpha, int fma, void* stream)
+{
+    if ((out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) || (out_fmt == APE_FMT_S32 && C % 32) || (fma != 0 && fma != 1)) return APE_EINVAL;
     if (!z || !out || B < 0 || h < 1 || w < 1 || C < 4 || C % 4 || act < APE_ACT_NONE || act > APE_ACT_PRELU) return APE_EINVAL;
     const long total = (long)B * 4 * h * w * (C / 4);
     if (total == 0) return APE_OK;
@@ -735,12 +760,12 @@ extern "C" int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void*
     if (g >= (1L << 31)) return APE_EINVAL;
     const size_t lds = (size_t)3 * kUpCols * (C / 4) * sizeof(float4);
     if (lds > 64 * 1024) return APE_EINVAL;             // C <= 1364
-    if (out_fmt == APE_FMT_S32)
-        hipLaunchKernelGGL(upconv_gather_kernel<true>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
-                           h, w, C / 4, sh, sw, act, alpha);
-    else
-        hipLaunchKernelGGL(upconv_gather_kernel<false>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, (float4*)out, B,
-                           h, w, C / 4, sh, sw, act, alpha);
+#define APE_UPG_LAUNCH(S32O, FM)                                                                                                          \
+    hipLaunchKernelGGL((upconv_gather_kernel<S32O, FM>), dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, (const float4*)z, bias, \
+                       (float4*)out, B, h, w, C / 4, sh, sw, act, alpha)
+    if (out_fmt == APE_FMT_S32) { if (fma) APE_UPG_LAUNCH(true, true); else APE_UPG_LAUNCH(true, false); }
+    else { if (fma) APE_UPG_LAUNCH(false, true); else APE_UPG_LAUNCH(false, false); }
+#undef APE_UPG_LAUNCH
     return ape::check_launch("ape_upconv3x3_gather_f32");
 }
 

@@ -43,19 +43,13 @@ __device__ __forceinline__ void seg_head_load_weights(const float* __restrict__ 
     for (int r = 0; r < 4; ++r) breg[r] = (kq * 4 + r < C && bias) ? bias[kq * 4 + r] : 0.f;
 }
 
-// -> am (arg-max class, first maximum) and pm (its probability after one or two softmaxes), valid on every lane of the pixel
-__device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float (&wreg)[16], const float (&breg)[4], int C, int lane,
-                                               int double_softmax, int& am_out, float& pm_out)
+// Everything behind the 16 matrix instructions of seg_head_group: arg-max over the classes, softmax (+ softmax), tie rule.
+// acc[r] = logit of class 4 * (lane >> 4) + r of pixel lane & 15 (C/D map of v_mfma_f32_16x16x4_f32).  A caller that produces the 64 input
+// channels 16 at a time (upconv_fused.hip) runs the four instructions of each 16-channel block itself, in seg_head_group's order, and
+// ends here: bit-identical labels and scores.
+__device__ __forceinline__ void seg_head_finish(const f32x4h& acc, int C, int lane, int double_softmax, int& am_out, float& pm_out)
 {
     const int kq = lane >> 4;
-    f32x4h acc = {breg[0], breg[1], breg[2], breg[3]};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 0], x[j].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 1], x[j].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 2], x[j].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 3], x[j].w, acc, 0, 0, 0);
-    }
     // acc[r] = logit of class kq*4 + r for pixel px (C/D map of 16x16x4: row = 4*(lane>>4) + r, col = lane&15)
     float m = -__builtin_inff();
     int am = 0x7fffffff;
@@ -110,6 +104,21 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
     }
     am_out = am;
     pm_out = pm;
+}
+
+// -> am (arg-max class, first maximum) and pm (its probability after one or two softmaxes), valid on every lane of the pixel
+__device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float (&wreg)[16], const float (&breg)[4], int C, int lane,
+                                               int double_softmax, int& am_out, float& pm_out)
+{
+    f32x4h acc = {breg[0], breg[1], breg[2], breg[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 0], x[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 1], x[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 2], x[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 3], x[j].w, acc, 0, 0, 0);
+    }
+    seg_head_finish(acc, C, lane, double_softmax, am_out, pm_out);
 }
 
 

@@ -474,30 +474,84 @@ def psp_prior_sum(zs, h, w):
     return out
 
 
-class UpConv:
-    """PSPUpsample (pspnet.py:27-37) as  1x1 conv at low resolution (9*Cout channels) + ape_upconv3x3_gather_f32."""
+USE_UPFUSE = os.environ.get("APE_USE_UPFUSE", "1") != "0"    # 64-channel PSPUpsample layers on S32 inputs as ONE kernel (upconv_fused.hip)
 
-    def __init__(self, weight, bias, alpha, device="cuda", precision="f32"):
+
+class UpConv:
+    """PSPUpsample (pspnet.py:27-37) as  1x1 conv at low resolution (9*Cout channels) + ape_upconv3x3_gather_f32 -- or, for a 64 -> 64
+    layer on an S32 input (up_3), as the ONE kernel of upconv_fused.hip that keeps the 9*Cout-channel tensor on the chip (bit-identical
+    to the two calls).  fma: both interpolation steps as chained fused multiply-adds instead of separately rounded products."""
+
+    def __init__(self, weight, bias, alpha, device="cuda", precision="f32", fma=False):
         cout, cin, kh, kw = weight.shape
         assert (kh, kw) == (3, 3)
         w9 = weight.detach().permute(2, 3, 0, 1).reshape(9 * cout, cin)            # row = (ky*3+kx)*Cout + co
         self.mix = Conv(w9, None, device=device, precision=precision)
         self.bias = bias.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.alpha, self.cout = float(alpha), cout
+        self.alpha, self.cout, self.cin, self.fma = float(alpha), cout, cin, bool(fma)
 
-    def __call__(self, x, out_fmt=FMT_F32):
-        """x fp32 or S32 -> [B,2h,2w,Cout] in `out_fmt` (the 9*Cout-channel intermediate z stays fp32: the gather is VALU work)"""
-        b, h, w, _ = x.shape
-        z = self.mix(x)
+    def fusable(self, x):
+        """the one-kernel form applies: split-bf16 operands, an S32 input, and a geometry upconv_fused.hip serves"""
+        return bool(USE_UPFUSE and isinstance(x, S32) and self.mix.nsplit == 3 and x.shape[3] == self.cin
+                    and _lib.lib().ape_upconv3x3_fused_supported(x.shape[1], x.shape[2], self.cin, self.cout))
+
+    def _gather(self, z, out_fmt):
+        b, h, w, _ = z.shape
         out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=z.device)
-        glabel = "upconv_gather_kernel<%s>" % ("true" if out_fmt == FMT_S32 else "false")
+        glabel = "upconv_gather_kernel<%s%s>" % ("true" if out_fmt == FMT_S32 else "false", ",true" if self.fma else "")
         e0 = _prof_begin(glabel)
-        rc = _lib.lib().ape_upconv3x3_gather_fmt(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), out_fmt, b, h, w,
-                                                 self.cout, ACT_PRELU, self.alpha, _st())
-        _lib.check(rc, "ape_upconv3x3_gather_fmt")
+        rc = _lib.lib().ape_upconv3x3_gather_ex(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), out_fmt, b, h, w,
+                                                self.cout, ACT_PRELU, self.alpha, int(self.fma), _st())
+        _lib.check(rc, "ape_upconv3x3_gather_ex")
         if e0 is not None:      # HBM-bound: z read once (9 * Cout channels at low resolution) + the output written once
             _prof_end(e0, glabel, "%dx%dx%d C%d" % (b, 2 * h, 2 * w, self.cout), 0.0, 4.0 * (b * h * w * 9 * self.cout + b * 4 * h * w * self.cout))
         return S32(out) if out_fmt == FMT_S32 else out
+
+    def __call__(self, x, out_fmt=FMT_F32, fused=None):
+        """x fp32 or S32 -> [B,2h,2w,Cout] in `out_fmt` (two-call form: the 9*Cout-channel intermediate z stays fp32, the gather is
+        VALU work).  fused: None = the one-kernel form whenever it applies, False = never, True = required."""
+        if fused is None:
+            fused = self.fusable(x)
+        if not fused:
+            return self._gather(self.mix(x), out_fmt)
+        if not self.fusable(x):
+            raise ValueError("no fused PSPUpsample kernel for this layer / input (needs split-bf16 operands, an S32 input, 64 -> 64 channels)")
+        b, h, w, _ = x.shape
+        out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=x.device)
+        label = "upconv_fused_kernel<%d,false,%s>" % (self.cin // 32, "true" if self.fma else "false")
+        e0 = _prof_begin(label)
+        rc = _lib.lib().ape_upconv3x3_fused_s32(_lib.dptr(x.t, torch.float32), _lib.dptr(self.mix.s32k()), _lib.dptr(self.bias), _lib.dptr(out),
+                                                out_fmt, b, h, w, self.cin, ACT_PRELU, self.alpha, int(self.fma), _st())
+        _lib.check(rc, "ape_upconv3x3_fused_s32")
+        if e0 is not None:
+            _prof_end(e0, label, "%dx%dx%d %d->%d up" % (b, 2 * h, 2 * w, self.cin, self.cout), *self._fused_cost(b, h, w, 4.0 * self.cout))
+        return S32(out) if out_fmt == FMT_S32 else out
+
+    def _fused_cost(self, b, h, w, out_bytes_per_pixel):
+        """(algorithmic flop, algorithmic bytes) of the one-kernel form: the reference's convolution at HIGH resolution (what the layer
+        computes, pspnet.py:30-33) and the input read + the output written once"""
+        return (2.0 * b * 4 * h * w * self.cout * 9 * self.cin,
+                4.0 * (b * h * w * self.cin + 9 * self.cout * self.cin) + out_bytes_per_pixel * b * 4 * h * w)
+
+    def seg_head(self, x, head_w, head_b, double_softmax=True, fused=None):
+        """`seg_head(self(x))`: label[B,2h,2w] u8, score f32 -- in the one-kernel form the 64-channel activation is never stored"""
+        if fused is None:
+            fused = self.fusable(x) and head_w.shape[0] <= 16 and self.cout == 64
+        if not fused:
+            return seg_head(self(x, fused=False), head_w, head_b, double_softmax)
+        b, h, w, _ = x.shape
+        c = head_w.shape[0]
+        label = torch.empty(b, 2 * h, 2 * w, dtype=torch.uint8, device=x.device)
+        score = torch.empty(b, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+        klabel = "upconv_fused_kernel<%d,true,%s>" % (self.cin // 32, "true" if self.fma else "false")
+        e0 = _prof_begin(klabel)
+        rc = _lib.lib().ape_upconv3x3_fused_seghead_s32(_lib.dptr(x.t, torch.float32), _lib.dptr(self.mix.s32k()), _lib.dptr(self.bias), b, h, w,
+                                                        self.cin, ACT_PRELU, self.alpha, int(self.fma), _lib.dptr(head_w, torch.float32),
+                                                        _lib.dptr(head_b), c, _lib.dptr(label), _lib.dptr(score), int(bool(double_softmax)), _st())
+        _lib.check(rc, "ape_upconv3x3_fused_seghead_s32")
+        if e0 is not None:
+            _prof_end(e0, klabel, "%dx%dx%d %d->%d up +head" % (b, 2 * h, 2 * w, self.cin, self.cout), *self._fused_cost(b, h, w, 5.0))
+        return label, score
 
 
 def gather_rows(x, index):

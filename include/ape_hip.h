@@ -122,6 +122,27 @@ int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, float* const*
                                         int C, void* workspace, size_t workspace_bytes, void* stream);
 int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act, float alpha,
                              void* stream);
+/* ... and with the interpolation arithmetic chosen: fma = 0 separately rounded products like ape_bilinear_nhwc_f32 (what the two entry
+ * points above use), fma = 1 chained fused multiply-adds acc = fma(l1, v1, fma(l0, v0, acc)) -- the unfused twin of
+ * ape_upconv3x3_fused_* called with fma = 1 */
+int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act, float alpha,
+                            int fma, void* stream);
+/* PSPUpsample with 64 output channels (DenseFusion/lib/pspnet.py:27-37: nn.Upsample x2 align_corners=True -> Conv2d 3x3 pad 1 -> PReLU;
+ * up_2 and up_3 of pspnet.py:50-51) as ONE kernel on an S32 input x[B][h][w][Cin] (Cin = 64): the low-resolution channel mixing
+ * z = W9 . x (W9 S32K [9*64][Cin], row = tap*64 + co, as ape_upconv3x3_gather_f32 expects) runs on the matrix cores for the 10 x 16
+ * low-resolution pixels under a 16 x 24 output tile, the row interpolation + tap-row sum happen on the accumulators (a lane holds one
+ * low-resolution column in all rows), the column interpolation + tap-column sum through LDS; the 9*64-channel tensor z never exists
+ * in memory.  Values are bit for bit those of ape_conv_gemm_s32 (z) followed by ape_upconv3x3_gather_ex(fma) on the same operands.
+ * ..._fused_s32 writes out[B][2h][2w][64] in out_fmt; ..._fused_seghead_s32 feeds the pixels straight into the segmentation head
+ * (ape_seg_head_f32: final 1x1 conv rows 0..C-1 + softmax(+softmax) + arg-max, pspnet.py:53-55, pipeline/utils.py:429-435) and writes
+ * label[B][2h][2w] u8 / score f32 only.  ..._supported: 1 when the geometry is served (Cin == 64, Cout == 64, and the floor pattern of the
+ * align_corners source index that the register form relies on holds for h and w; always true for the sizes of the reference). */
+int ape_upconv3x3_fused_supported(int h, int w, int Cin, int Cout);
+int ape_upconv3x3_fused_s32(const void* x_s32, const void* w9_s32k, const float* bias, void* out, int out_fmt, int B, int h, int w, int Cin,
+                            int act, float alpha, int fma, void* stream);
+int ape_upconv3x3_fused_seghead_s32(const void* x_s32, const void* w9_s32k, const float* bias, int B, int h, int w, int Cin, int act, float alpha,
+                                    int fma, const float* head_w, const float* head_b, int C, uint8_t* label, float* score, int double_softmax,
+                                    void* stream);
 /* 3x3 / stride 1 / pad == dilation in {1,2,4} convolutions with Cout >= 128 on S32 activations (extractors.py:29-43 blocks of layers
  * 2-4): the LDS-halo kernel with the halo rows and the weight tiles streamed by LDS-DMA into rings and every fragment read
  * prefetched one tap ahead.  Same accumulators as ape_conv3x3_halo_bf16(nsplit = 3) on the fp32 form of x; weights S32K in the
