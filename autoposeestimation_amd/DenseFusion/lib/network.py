@@ -150,19 +150,33 @@ class _PSPPlan:
                             device=dev, precision=precision) for n in ("up_1", "up_2")]
         self.up3 = _Conv(g("up_3.conv.1.weight"), g("up_3.conv.1.bias"), 1, 1, 1, E.ACT_PRELU,
                          alpha=float(g("up_3.conv.2.weight").reshape(-1)[0]), device=dev)
+        # the segmentor's up_3 in up_1 / up_2's low-resolution form, ONE kernel with the head (engine.UpConv.seg_head, upconv_fused.hip):
+        # 4x fewer matrix flops than the direct 3x3 conv on the up-sampled map
+        self.up3_low = (E.UpConv(g("up_3.conv.1.weight"), g("up_3.conv.1.bias"), float(g("up_3.conv.2.weight").reshape(-1)[0]),
+                                 device=dev, precision=precision, fma=True) if precision == "bf16x3" else None)
         self.final = _Conv(g("final.0.weight"), g("final.0.bias"), device=dev)
+
+    def _s32_graph(self, x):
+        """the S32 graph's 3x3 kernel tiles the 1/8-resolution map in 16x16 pixels: worth it only when those tiles are mostly full
+        (the 480x640 segmentor: 60x80 -> 94 %; a 160x160 crop: 20x20 -> 39 %, which stays on the flattened-M kernels)"""
+        h8, w8 = -(-x.shape[1] // 8), -(-x.shape[2] // 8)
+        return self.precision == "bf16x3" and E.USE_S32 and h8 * w8 >= 0.8 * (-(-h8 // 16) * -(-w8 // 16) * 256)
 
     def label_score(self, x, head_w, head_b, double_softmax=True):
         """x[B,H,W,4] -> (label u8, score f32)[B,H,W]: features with the classification head (first C rows of the final 1x1 conv +
-        softmax(+softmax) + arg-max) fused into up_3's epilogue -- the full-resolution 64-channel activation is never stored."""
+        softmax(+softmax) + arg-max) fused into up_3 -- the full-resolution 64-channel activation is never stored.  On the S32 graph
+        up_2 hands up_3 a pre-split map and up_3 + head is the one low-resolution kernel; otherwise the head rides in the epilogue of the
+        direct 3x3 conv on the (virtually) up-sampled map."""
+        if self.up3_low is not None and E.USE_UPFUSE and self._s32_graph(x) and head_w.shape[0] <= 16:
+            p2 = self._features_s32(x, None, True, up2_fmt=E.FMT_S32)
+            if self.up3_low.fusable(p2):
+                return self.up3_low.seg_head(p2, head_w, head_b, double_softmax)
+            return E.conv_seg_head(self.up3, p2.to_f32(), head_w, head_b, double_softmax, upsample2x=True)
         return E.conv_seg_head(self.up3, self.features(x, stop_before_up3=True), head_w, head_b, double_softmax, upsample2x=True)
 
     def features(self, x, taps=None, stop_before_up3=False):
         """x[B,H,W,4] (RGB + zero pad) -> up_3 activation [B,H,W,64]"""
-        # the S32 graph's 3x3 kernel tiles the 1/8-resolution map in 16x16 pixels: worth it only when those tiles are mostly full
-        # (the 480x640 segmentor: 60x80 -> 94 %; a 160x160 crop: 20x20 -> 39 %, which stays on the flattened-M kernels)
-        h8, w8 = -(-x.shape[1] // 8), -(-x.shape[2] // 8)
-        if self.precision == "bf16x3" and E.USE_S32 and h8 * w8 >= 0.8 * (-(-h8 // 16) * -(-w8 // 16) * 256):
+        if self._s32_graph(x):
             return self._features_s32(x, taps, stop_before_up3)
         y = E.stem_pool(self.stem, x)
         for c1, c2, down in self.blocks:
@@ -188,7 +202,7 @@ class _PSPPlan:
             taps["up_3"] = p
         return p
 
-    def _features_s32(self, x, taps, stop_before_up3):
+    def _features_s32(self, x, taps, stop_before_up3, up2_fmt=E.FMT_F32):
         """The same graph with PRE-SPLIT ("S32", include/ape_hip.h) activations between the split-bf16 layers from layer 2 on: every
         producer writes the bf16 hi | lo pair its consumers' matrix cores take, the 3x3 and 1x1 layers stream it HBM -> LDS by
         LDS-DMA (conv3x3_halo_s32.hip, conv_gemm_s32.hip).  The MFMA operands are bit-identical to the fp32-activation graph; residual
@@ -217,7 +231,7 @@ class _PSPPlan:
         p = self.up[0](p, out_fmt=S)
         if taps is not None:
             taps["up_1"] = p.to_f32()
-        p = self.up[1](p)
+        p = self.up[1](p, out_fmt=up2_fmt)          # (S32 only for the fused up_3 + head of label_score)
         if taps is not None:
             taps["up_2"] = p
         if stop_before_up3:

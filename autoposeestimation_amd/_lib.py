@@ -37,6 +37,8 @@ SIGNATURES = {
     "ape_upconv3x3_gather_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "ape_upconv3x3_gather_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "ape_upconv3x3_fused_supported": [_I, _I, _I, _I],
+    "ape_upconv3x3_fused_debug": [_I],
+    "ape_upconv3x3_fused_stamps": [_P],
     "ape_upconv3x3_fused_s32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "ape_upconv3x3_fused_seghead_s32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _P, _P, _I, _P],
     "ape_conv3x3_halo_s32_supported": [_P],

@@ -44,9 +44,8 @@ __device__ __forceinline__ void seg_head_load_weights(const float* __restrict__ 
 }
 
 // Everything behind the 16 matrix instructions of seg_head_group: arg-max over the classes, softmax (+ softmax), tie rule.
-// acc[r] = logit of class 4 * (lane >> 4) + r of pixel lane & 15 (C/D map of v_mfma_f32_16x16x4_f32).  A caller that produces the 64 input
-// channels 16 at a time (upconv_fused.hip) runs the four instructions of each 16-channel block itself, in seg_head_group's order, and
-// ends here: bit-identical labels and scores.
+// acc[r] = logit of class 4 * (lane >> 4) + r of pixel lane & 15 (C/D map of v_mfma_f32_16x16x4_f32).  Split out of seg_head_group so that a
+// caller may run the matrix instructions itself (in seg_head_group's order: bit-identical labels and scores).
 __device__ __forceinline__ void seg_head_finish(const f32x4h& acc, int C, int lane, int double_softmax, int& am_out, float& pm_out)
 {
     const int kq = lane >> 4;

@@ -292,7 +292,8 @@ def kernel_peak(label):
         return "hbm", PEAK_HBM_GBS, "GB/s"
     if "conv_f32" in label:
         return "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
-    split = "_s32_kernel" in label or "<3," in label        # split-bf16: three bf16 MFMAs per algorithmic product
+    # split-bf16: three bf16 MFMAs per algorithmic product (upconv_fused.hip exists in that precision only)
+    split = "_s32_kernel" in label or "<3," in label or "upconv_fused_kernel" in label
     return "mfma", PEAK_BF16_MFMA_TFLOPS / (3.0 if split else 1.0), "TFLOP/s"
 
 
@@ -645,8 +646,8 @@ def main():
 
         kernels = []
         # order (and the dominant kernel): by the time the kernels take ALONE when the isolated pass exists, else by timed-region time
-        rank = (lambda k: -(iso_summ[k]["ms"] if k in iso_summ else 0.0)) if iso_summ else (lambda k: -summ[k]["ms"])
-        for label in sorted(summ, key=rank):
+        order_key = (lambda k: -(iso_summ[k]["ms"] if k in iso_summ else 0.0)) if iso_summ else (lambda k: -summ[k]["ms"])
+        for label in sorted(summ, key=order_key):
             shapes = []
             for (lab, shape), d in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"]):
                 if lab != label:
@@ -670,9 +671,17 @@ def main():
                         row["isolated_avg_launch_us"] = round(di["ms"] / di["launches"] * 1e3, 1)
                         row["isolated_frac"] = round(di["flop"] / sec_i / 1e12 / peak, 4)
                         row["isolated_roofline_frac"] = round(max(di["flop"] / (peak * 1e12), di["bytes"] / (PEAK_HBM_GBS * 1e9)) / sec_i, 4)
+                else:       # a byte-moving kernel: its one limit is the HBM peak
+                    row["hbm_frac"] = row["frac"]
+                    row["roofline_bound"] = "hbm"
+                    row["roofline_frac"] = row["frac"]
+                    di = iso_by_shape.get((lab, shape)) if iso_by_shape else None
+                    if di:
+                        row["isolated_avg_launch_us"] = round(di["ms"] / di["launches"] * 1e3, 1)
+                        row["isolated_frac"] = row["isolated_roofline_frac"] = round(di["bytes"] / (di["ms"] * 1e-3) / 1e9 / peak, 4)
                 shapes.append(row)
             kernels.append(entry(label, summ[label], shapes))
-        # the dominant kernel: largest summed time (alone, when the loop is software-pipelined; see `rank`); its frac / avg_launch_us are timed-region figures
+        # the dominant kernel: largest summed time (alone, when the loop is software-pipelined; see `order_key`); its frac / avg_launch_us are timed-region figures
         roofline = None
         if kernels:
             roofline = {k: v for k, v in kernels[0].items() if k != "shapes"}

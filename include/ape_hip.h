@@ -138,6 +138,8 @@ int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* out, int ou
  * label[B][2h][2w] u8 / score f32 only.  ..._supported: 1 when the geometry is served (Cin == 64, Cout == 64, and the floor pattern of the
  * align_corners source index that the register form relies on holds for h and w; always true for the sizes of the reference). */
 int ape_upconv3x3_fused_supported(int h, int w, int Cin, int Cout);
+int ape_upconv3x3_fused_stamps(void* device_buffer);   /* diagnostic build (make stamps) only: [workgroups][12 waves][16] u64 cycle sums; NULL = off */
+int ape_upconv3x3_fused_debug(int bits);    /* timing-only ablations for tools/mb_upfuse.py (0 = off; anything else gives WRONG results) */
 int ape_upconv3x3_fused_s32(const void* x_s32, const void* w9_s32k, const float* bias, void* out, int out_fmt, int B, int h, int w, int Cin,
                             int act, float alpha, int fma, void* stream);
 int ape_upconv3x3_fused_seghead_s32(const void* x_s32, const void* w9_s32k, const float* bias, int B, int h, int w, int Cin, int act, float alpha,
