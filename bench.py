@@ -36,10 +36,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA, de
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md "HBM3E peak BW" (spec; 6.29 TB/s measured by a float4 copy)
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, shape=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json, made by
     tools/pmc_summary.py with the guide's FETCH_SIZE x2 gfx950 correction); None when no PMC run covers this kernel.
-    PMC collection cannot run inside bench.py itself (it needs rocprofv3 around the process)."""
+    `shape`: the launches of that one layer shape only (the passes record every dispatch of the last step in launch order, and
+    tools/pmc_summary.py --shapes labels them from bench.py's own launch list of the same step), so a kernel that serves layers of very
+    different sizes is compared like with like.  PMC collection cannot run inside bench.py itself (it needs rocprofv3 around the process)."""
     import glob
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
@@ -47,7 +49,10 @@ def pmc_traffic(kernel):
         except (OSError, ValueError, KeyError):
             continue
         if k:
-            return k["hbm_bytes_per_launch"]
+            if shape is None:
+                return k["hbm_bytes_per_launch"]
+            row = (k.get("shapes") or {}).get(shape)
+            return None if row is None else row["hbm_bytes_per_launch"]
     return None
 
 
@@ -213,7 +218,10 @@ def cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=16, n_fram
         with ThreadPoolExecutor(max_workers=workers_all) as ex:
             results.update(zip(range(n_frames, n_frames + n_all), ex.map(run, range(n_frames, n_frames + n_all))))
         dt_all = time.time() - t
-        all_cores = {"value": round(n_all / dt_all, 4), "cores": workers_all, "frames": n_all}
+        quota = _cpu_quota()
+        # `cores` = the CPUs those workers can actually occupy: a cgroup quota below the worker count makes them time-slice
+        all_cores = {"value": round(n_all / dt_all, 4), "cores": int(min(workers_all, quota)) if quota else workers_all, "workers": workers_all,
+                     "frames": n_all}
     torch.set_num_threads(old_threads)
     found = sum(len(r) for r in results.values())
     return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": workers, "kind": "port",
@@ -223,7 +231,8 @@ def cpu_baseline(frames, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=16, n_fram
                       "single-threaded workers side by side; single_thread_value = 1 frame on 1 thread; all_cores_value = %s "
                       "(%d objects found over both legs)"
                       % (n_frames, workers, "not run" if all_cores is None else "%d further frames of the batch on %d single-threaded "
-                         "workers (one per physical core the process may use)" % (n_all, workers_all), found)}, results
+                         "workers (one per physical core the process may use; `all_cores.cores` = min(workers, cgroup CPU quota), what they can occupy)"
+                         % (n_all, workers_all), found)}, results
 
 
 def parity_block(out, oracle_results, frames, seg_sd):
@@ -450,6 +459,9 @@ def main():
                          "loop, every step still does all of its work inside the fences): +4 %% frames/s; the per-kernel event timings "
                          "of the roofline leg then include whatever the co-running pose kernels cost them")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="one stream, segmentation and pose stage back to back")
+    ap.add_argument("--dump-launches", default="", help="write [[kernel label, layer shape], ...] of ONE step's profiled launches in launch order "
+                    "(for tools/pmc_summary.py --shapes: per-shape HBM traffic from the rocprofv3 PMC passes; use with --no-overlap)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the secondary `modes` leg (two steps of the exact-fp32 operand mode after the timed region)")
     ap.add_argument("--seg-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--pose-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
@@ -586,6 +598,9 @@ def main():
         wsum = E.PROFILE.summary()
         if wsum:
             top_only = set(sorted(wsum, key=lambda k: -wsum[k]["ms"])[:5])
+        if args.dump_launches and rank == 0:
+            with open(args.dump_launches, "w") as f:
+                json.dump([[r[0], r[1]] for r in E.PROFILE.records], f)
     prof = E.PROFILE = E.LaunchProfile(only=top_only)
     t0 = time.perf_counter()
     out = run_steps(args.warmup, args.steps)
@@ -618,6 +633,36 @@ def main():
         iso_by_shape = E.PROFILE.summary(by_shape=True)
         E.PROFILE = None
 
+    # Secondary, AFTER the timed region (not part of `value`): the same step with exact-fp32 operands on the matrix cores -- what the
+    # default mode's split-bf16 operands (three products per term, ~2^-16 operand error, inside the 1e-4 parity bar) buy.  Two
+    # single-stream steps behind one warm-up step; every rank runs them (the step's gather is a collective), rank 0 reports.
+    modes = None
+    if not args.no_modes and (args.seg_precision, args.pose_precision) == ("bf16x3", "bf16x3"):
+        for m in (seg, est, ref):
+            m.set_precision("f32")
+        pipe_f = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
+        for c in range(n_chunks):
+            tail(pipe_f.run(rgb[c], depth[c], S.REALSENSE_META, seed=0), (2 * 10 ** 6, c))
+        fence()
+        tf = time.perf_counter()
+        f32_steps = 2
+        for i in range(f32_steps):
+            for c in range(n_chunks):
+                tail(pipe_f.run(rgb[c], depth[c], S.REALSENSE_META, seed=i), (2 * 10 ** 6 + 1 + i, c))
+        fence()
+        dtf = time.perf_counter() - tf
+        if dist:
+            t = torch.tensor([dtf], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t[0])
+        modes = {"f32": {"value": round(per_rank * world * f32_steps / dtf, 2), "unit": "frames/s", "ms_per_step": round(dtf / f32_steps * 1e3, 3),
+                         "steps": f32_steps, "note": "exact fp32 operands on the matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak), one stream, "
+                                                      "run after the timed region; never part of `value`"}}
+        seg.set_precision(args.seg_precision)
+        est.set_precision(args.pose_precision)
+        ref.set_precision(args.pose_precision)
+        del pipe_f
+
     if rank == 0:
         summ = prof.summary()
         by_shape = prof.summary(by_shape=True)
@@ -628,6 +673,10 @@ def main():
             ach = (d["bytes"] / sec / 1e9) if bound == "hbm" else (d["flop"] / sec / 1e12)
             traffic = pmc_traffic(label)
             alg_b = d["bytes"] / d["launches"]
+            if shapes and all("traffic" in r for r in shapes):
+                # like with like: the PMC bytes of each shape weighted by THIS run's launches of it (a plain per-kernel PMC average mixes
+                # the big segmentation launches with the pose stage's small ones in another proportion than the timed region does)
+                traffic = round(sum(r["traffic"] * r["launches"] for r in shapes) / d["launches"])
             e = {"kernel": label, "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
                  "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
                  "avg_launch_gflop": round(d["flop"] / d["launches"] / 1e9, 3), "avg_launch_algorithmic_mb": round(alg_b / 1e6, 1),
@@ -658,6 +707,10 @@ def main():
                 row = {"shape": shape, "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
                        "gflop": round(d["flop"] / d["launches"] / 1e9, 3), "algorithmic_mb": round(d["bytes"] / d["launches"] / 1e6, 1),
                        "achieved": round(ach, 2), "frac": round(ach / peak, 4)}
+                tr = pmc_traffic(label, shape)
+                if tr is not None:          # HBM bytes of THIS shape's launches (PMC) against its algorithmic bytes
+                    row["traffic"] = tr
+                    row["traffic_over_algorithmic"] = round(tr / (d["bytes"] / d["launches"]), 2)
                 # the shape's OWN roofline: whichever of the two limits (algorithmic flop at the kernel's matrix peak, algorithmic bytes at
                 # the HBM peak) takes longer bounds it -- a 1x1 layer with K = 128 is an HBM-bound launch of an MFMA kernel
                 if bound == "mfma":
@@ -721,6 +774,7 @@ def main():
             "overlap": bool(args.overlap),
             "ranks_seen": args.ranks_seen, "distinct_gpus": len({tuple(r[1:3]) for r in args.ranks_seen}),
             "roofline": roofline,
+            "modes": modes,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             if out.get("stream") is not None:

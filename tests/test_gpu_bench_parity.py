@@ -128,8 +128,12 @@ def test_bench_batch_equals_64_single_frame_runs(bench_setup):
 
 
 def test_bench_segmentor_fused_head_equals_unfused_at_batch_64(bench_setup):
-    """label_score_nhwc (up_3 with the x2 up-sampling fused into its halo load and the head in its epilogue: 19 200 workgroups per
-    frame, 1.2 M for the batch) == materialised features -> ape_seg_head_f32, labels and scores bit for bit, at B = 64, 480x640."""
+    """label_score_nhwc at B = 64, 480x640 -- up_2 handing up_3 a pre-split map, up_3 + head as the ONE low-resolution kernel of
+    csrc/upconv_fused.hip (51 840 tiles walked by one workgroup per CU) -- against
+      * its own unfused form: ape_conv_gemm_s32 (the 9 x 64 tap channels at 240x320) -> ape_upconv3x3_gather_ex -> ape_seg_head_f32,
+        labels and scores bit for bit;
+      * the reference's formulation of up_3 (pspnet.py:30-33,51: 3x3 conv on the up-sampled map; the halo kernel) -> ape_seg_head_f32: the
+        same labels except where the two top classes are a rounding error apart, scores to 1e-5."""
     from autoposeestimation_amd import engine as E
     s = bench_setup
     seg = s["pipe"].segmentor
@@ -139,9 +143,22 @@ def test_bench_segmentor_fused_head_equals_unfused_at_batch_64(bench_setup):
     x4 = E.preprocess_u8(s["rgb"], rects.cuda(), 480, 640, div255=True)
     label, score = seg.label_score_nhwc(x4, double_softmax=True)
     pl = seg.plan()
-    low = pl.features(x4, stop_before_up3=True)
-    for lo, hi in ((0, 32), (32, 64)):           # the unfused side in two halves (a 5 GB activation each)
+    assert pl.up3_low is not None and pl._s32_graph(x4)
+    p2 = pl._features_s32(x4, None, True, up2_fmt=E.FMT_S32)
+    assert pl.up3_low.fusable(p2)
+    for lo in range(0, b, 8):                       # the unfused side eight frames at a time (its tap tensor is 1.4 GB per eight)
+        want_label, want_score = pl.up3_low.seg_head(p2[lo:lo + 8], seg._head_w, seg._head_b, True, fused=False)
+        assert torch.equal(label[lo:lo + 8], want_label) and torch.equal(score[lo:lo + 8], want_score)
+    low = p2.to_f32()
+    flipped, worst = 0, 0.0
+    for lo, hi in ((0, 32), (32, 64)):              # the direct form in two halves (a 5 GB activation each)
         feat = pl.up3(E.bilinear(low[lo:hi], 480, 640, True))
         want_label, want_score = E.seg_head(feat, seg._head_w, seg._head_b, True)
-        assert torch.equal(label[lo:hi], want_label) and torch.equal(score[lo:hi], want_score)
         del feat
+        same = label[lo:hi] == want_label
+        flipped += int((~same).sum())
+        worst = max(worst, float((score[lo:hi] - want_score)[same].abs().max()))
+        if bool((~same).any()):     # a flipped pixel is an arg-max near-tie: both forms give it (nearly) the same winning probability
+            assert float((score[lo:hi] - want_score)[~same].abs().max()) <= 1e-4
+    print("low-resolution up_3 + head vs the direct 3x3 form: %d of %d labels differ (near-ties), max |score diff| elsewhere %.3g" % (flipped, label.numel(), worst))
+    assert flipped <= 64 * 4 and worst <= 1e-5
