@@ -28,6 +28,23 @@ class _KnnPytorch:
         return 1  # knn.h:63
 
 
+def load_compiled():
+    """The COMPILED binding (src/knn_binding.cpp over src/knn_rocm.h, built by build_ext.py / __graft_entry__.build()): the pybind11
+    module the reference's `from lib.knn import knn_pytorch` resolves to, calling ape_knn_f32 through the C ABI from C++.  None when it
+    has not been built."""
+    import importlib.util
+    import os
+    import sysconfig
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "knn_pytorch" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location("knn_pytorch", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# the ctypes form is the default (no build step beyond libape_hip.so); both call the same exported symbol
 knn_pytorch = _KnnPytorch()
 
 

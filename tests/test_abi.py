@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import REPO
 
 
@@ -72,3 +74,17 @@ def test_product_path_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_reference_ffi_binding_compiles_links_and_imports():
+    """The reference's one native interface (`knn_pytorch.knn`, DenseFusion/lib/knn/src/knn.h:12, vision.cpp:3-5) as a compiled pybind11
+    module over the C ABI: builds with the image's g++ + torch headers + -lape_hip (no GPU), imports, exports `knn`, and refuses host
+    tensors instead of computing on the CPU (compute parity: tests/test_gpu_knn.py)."""
+    import torch
+    from autoposeestimation_amd.DenseFusion.lib.knn import build_ext, load_compiled
+    path = build_ext.build()
+    assert os.path.exists(path)
+    mod = load_compiled()
+    assert mod is not None and callable(mod.knn)
+    with pytest.raises(RuntimeError, match="GPU"):
+        mod.knn(torch.zeros(1, 3, 4), torch.zeros(1, 3, 5), torch.zeros(1, 1, 5, dtype=torch.int64))
