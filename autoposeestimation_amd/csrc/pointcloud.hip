@@ -11,10 +11,11 @@
 //   knn_mean_dist      brute-force k-NN mean distance, LDS-tiled (RemoveStatisticalOutliers, :208-211, unbounded radius).
 //   icp_*_sums         one-pass reductions for the two ICP estimators: Umeyama sums (point-to-point) and the 6x6 normal
 //                      equations J^T J, J^T r with r = (s - t).n_t, J = [s x n_t, n_t] (point-to-plane).
-// All of it is HBM/latency-bound index work; sorting and scans come from hipCUB (rocPRIM), everything else is hand written.
+// All of it is HBM/latency-bound index work, all of it hand written (the sort: seg_sort_batch / seg_merge_batch; the scans and the
+// ordered compactions: scan_block / compact_block); the one-cloud entry points are the batched ones called with one cloud.
 // Reductions use fixed-order two-stage trees => bitwise reproducible.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
+#include <atomic>
 
 namespace {
 
@@ -25,16 +26,6 @@ inline int grid_for(long work, int cap = 4096) { long g = (work + kT - 1) / kT; 
 struct Mat4 { double m[16]; };
 
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void surface_flags_kernel_body(const uint8_t* __restrict__ label, const uint16_t* __restrict__ depth, uint8_t* __restrict__ flag, int n, const int bx, const int gx)
-{
-    for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
-        flag[i] = (label[i] != 0 && depth[i] != 0) ? 1 : 0;
-}
-
-__global__ void surface_flags_kernel(const uint8_t* __restrict__ label, const uint16_t* __restrict__ depth, uint8_t* __restrict__ flag, int n)
-{
-    surface_flags_kernel_body(label, depth, flag, n, blockIdx.x, gridDim.x);
-}
 
 __device__ __forceinline__ void surface_points_kernel_body(const int* __restrict__ pix, const int* __restrict__ n_sel, const uint16_t* __restrict__ depth, int W, double fx, double fy, double ppx, double ppy, Mat4 T, double* __restrict__ out, const int bx, const int gx)
 {
@@ -48,12 +39,6 @@ __device__ __forceinline__ void surface_points_kernel_body(const int* __restrict
         for (int r = 0; r < 3; ++r)                          // robot2obj = robot2Cam . [I | p] -> column 3
             out[(size_t)i * 3 + r] = ((T.m[r * 4 + 0] * p0 + T.m[r * 4 + 1] * p1) + T.m[r * 4 + 2] * p2) + T.m[r * 4 + 3];
     }
-}
-
-__global__ void surface_points_kernel(const int* __restrict__ pix, const int* __restrict__ n_sel, const uint16_t* __restrict__ depth,
-                                      int W, double fx, double fy, double ppx, double ppy, Mat4 T, double* __restrict__ out)
-{
-    surface_points_kernel_body(pix, n_sel, depth, W, fx, fy, ppx, ppy, T, out, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ void transform_kernel_body(double* __restrict__ pts, int n, Mat4 T, double* __restrict__ normals, const int bx, const int gx)
@@ -94,10 +79,6 @@ __device__ __forceinline__ void bounds_stage1_body(const double* __restrict__ pt
     if (threadIdx.x < 6) part[bx * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
-__global__ void bounds_stage1(const double* __restrict__ pts, int n, double* __restrict__ part)
-{
-    bounds_stage1_body(pts, n, part, blockIdx.x, gridDim.x);
-}
 
 __device__ __forceinline__ void bounds_stage2_body(const double* __restrict__ part, int g, double* __restrict__ out6, const int bx, const int gx)
 {
@@ -108,10 +89,6 @@ __device__ __forceinline__ void bounds_stage2_body(const double* __restrict__ pa
     }
 }
 
-__global__ void bounds_stage2(const double* __restrict__ part, int g, double* __restrict__ out6)
-{
-    bounds_stage2_body(part, g, out6, blockIdx.x, gridDim.x);
-}
 
 __device__ __forceinline__ u64 pack_key(long cx, long cy, long cz) { return ((u64)cx << 42) | ((u64)cy << 21) | (u64)cz; }
 
@@ -119,7 +96,7 @@ __device__ __forceinline__ u64 pack_key(long cx, long cy, long cz) { return ((u6
 __device__ __forceinline__ void cell_of(const double* p, const double* o, double h, long c[3])
 {
     for (int d = 0; d < 3; ++d) {
-        long v = (long)floor((p[d] - o[d]) / h);   // the same division keys_kernel uses => identical cell borders
+        long v = (long)floor((p[d] - o[d]) / h);   // the same division keys_kernel_body uses => identical cell borders
         c[d] = v < 0 ? 0 : (v > 2097151 ? 2097151 : v);
     }
 }
@@ -140,22 +117,12 @@ __device__ __forceinline__ void keys_kernel_body(const double* __restrict__ pts,
     }
 }
 
-__global__ void keys_kernel(const double* __restrict__ pts, int n, const double* __restrict__ bounds6, double h, double shift,
-                            u64* __restrict__ keys, unsigned* __restrict__ idx, double* __restrict__ origin_out)
-{
-    keys_kernel_body(pts, n, bounds6, h, shift, keys, idx, origin_out, blockIdx.x, gridDim.x);
-}
-
 __device__ __forceinline__ void heads_kernel_body(const u64* __restrict__ keys, int n, int* __restrict__ head, const int bx, const int gx)
 {
     for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
         head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 
-__global__ void heads_kernel(const u64* __restrict__ keys, int n, int* __restrict__ head)
-{
-    heads_kernel_body(keys, n, head, blockIdx.x, gridDim.x);
-}
 
 // seg[i] = exclusive-scan(head)[i] + head[i] - 1 = segment id; one thread per segment start averages its run in order
 __device__ __forceinline__ void voxel_mean_kernel_body(const double* __restrict__ pts, const u64* __restrict__ keys, const unsigned* __restrict__ order, const int* __restrict__ head, const int* __restrict__ scan, int n, double* __restrict__ out, int* __restrict__ n_out, const int bx, const int gx)
@@ -172,23 +139,12 @@ __device__ __forceinline__ void voxel_mean_kernel_body(const double* __restrict_
     if (bx == 0 && threadIdx.x == 0) *n_out = scan[n - 1] + head[n - 1];
 }
 
-__global__ void voxel_mean_kernel(const double* __restrict__ pts, const u64* __restrict__ keys, const unsigned* __restrict__ order,
-                                  const int* __restrict__ head, const int* __restrict__ scan, int n, double* __restrict__ out,
-                                  int* __restrict__ n_out)
-{
-    voxel_mean_kernel_body(pts, keys, order, head, scan, n, out, n_out, blockIdx.x, gridDim.x);
-}
-
 __device__ __forceinline__ void gather_sorted_kernel_body(const double* __restrict__ pts, const unsigned* __restrict__ order, int n, double* __restrict__ out, const int bx, const int gx)
 {
     for (int i = bx * blockDim.x + threadIdx.x; i < n; i += gx * blockDim.x)
         for (int d = 0; d < 3; ++d) out[(size_t)i * 3 + d] = pts[(size_t)order[i] * 3 + d];
 }
 
-__global__ void gather_sorted_kernel(const double* __restrict__ pts, const unsigned* __restrict__ order, int n, double* __restrict__ out)
-{
-    gather_sorted_kernel_body(pts, order, n, out, blockIdx.x, gridDim.x);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 struct Grid {
@@ -643,10 +599,6 @@ __device__ __forceinline__ void select_rows_kernel_body(const double* __restrict
         for (int d = 0; d < 3; ++d) out[(size_t)i * 3 + d] = pts[(size_t)sel[i] * 3 + d];
 }
 
-__global__ void select_rows_kernel(const double* __restrict__ pts, const int* __restrict__ sel, const int* __restrict__ n_sel, double* __restrict__ out)
-{
-    select_rows_kernel_body(pts, sel, n_sel, out, blockIdx.x, gridDim.x);
-}
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -655,48 +607,9 @@ struct Carver {
     template <class T> T* take(size_t count) { T* r = (T*)p; p += align_up(count * sizeof(T)); return p <= end ? r : nullptr; }
 };
 
-size_t sort_temp_bytes(int n)
-{
-    size_t b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (u64*)nullptr, (u64*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, n, 0, 63);
-    size_t c = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, (int*)nullptr, (int*)nullptr, n);
-    size_t d = 0;
-    (void)hipcub::DeviceSelect::Flagged(nullptr, d, hipcub::CountingInputIterator<int>(0), (uint8_t*)nullptr, (int*)nullptr, (int*)nullptr, n);
-    return align_up(b > c ? (b > d ? b : d) : (c > d ? c : d));
-}
-
 Mat4 load_mat(const double* T16_host) { Mat4 m; for (int i = 0; i < 16; ++i) m.m[i] = T16_host[i]; return m; }
 
 }  // namespace
-
-extern "C" size_t ape_pc_workspace_bytes(int n)
-{
-    if (n < 1) n = 1;
-    // keys in/out, order in/out, heads, scan, bounds partials, cub temp
-    return sort_temp_bytes(n) + 2 * align_up((size_t)n * 8) + 4 * align_up((size_t)n * 4) + align_up((size_t)n) + align_up(4096 * 32 * 8) + 4096;
-}
-
-/* label[H][W] u8, depth[H][W] u16 -> points[n][3] f64 in raster order (capacity H*W), *n_out on the device */
-extern "C" int ape_surface_points_f64(const uint8_t* label, const uint16_t* depth, int H, int W, double fx, double fy, double ppx,
-                                      double ppy, const double* T16_host, double* points, int* n_out, void* ws, size_t ws_bytes,
-                                      void* stream)
-{
-    if (!label || !depth || !T16_host || !points || !n_out || !ws || H < 1 || W < 1) return APE_EINVAL;
-    const int n = H * W;
-    if (ws_bytes < ape_pc_workspace_bytes(n)) return APE_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    Carver c{(char*)ws, (char*)ws + ws_bytes};
-    uint8_t* flag = c.take<uint8_t>(n);
-    int* pix = c.take<int>(n);
-    size_t tb = sort_temp_bytes(n);
-    void* tmp = c.take<char>(tb);
-    if (!tmp) return APE_EWORKSPACE;
-    hipLaunchKernelGGL(surface_flags_kernel, dim3(grid_for(n)), dim3(kT), 0, st, label, depth, flag, n);
-    if (hipcub::DeviceSelect::Flagged(tmp, tb, hipcub::CountingInputIterator<int>(0), flag, pix, n_out, n, st) != hipSuccess) return APE_ELAUNCH;
-    hipLaunchKernelGGL(surface_points_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pix, n_out, depth, W, fx, fy, ppx, ppy, load_mat(T16_host), points);
-    return ape::check_launch("ape_surface_points_f64");
-}
 
 extern "C" int ape_transform_points_f64(double* pts, double* normals_or_null, int n, const double* T16_host, void* stream)
 {
@@ -704,56 +617,6 @@ extern "C" int ape_transform_points_f64(double* pts, double* normals_or_null, in
     if (n == 0) return APE_OK;
     hipLaunchKernelGGL(transform_kernel, dim3(grid_for(n)), dim3(kT), 0, (hipStream_t)stream, pts, n, load_mat(T16_host), normals_or_null);
     return ape::check_launch("ape_transform_points_f64");
-}
-
-/* out capacity n points; *n_out on the device */
-extern "C" int ape_voxel_down_sample_f64(const double* pts, int n, double voxel, double* out, int* n_out, void* ws, size_t ws_bytes,
-                                         void* stream)
-{
-    if (!pts || !out || !n_out || !ws || n < 1 || !(voxel > 0)) return APE_EINVAL;
-    if (ws_bytes < ape_pc_workspace_bytes(n)) return APE_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    Carver c{(char*)ws, (char*)ws + ws_bytes};
-    u64* k0 = c.take<u64>(n); u64* k1 = c.take<u64>(n);
-    unsigned* i0 = c.take<unsigned>(n); unsigned* i1 = c.take<unsigned>(n);
-    int* head = c.take<int>(n); int* scan = c.take<int>(n);
-    double* part = c.take<double>(4096 * 32);
-    size_t tb = sort_temp_bytes(n);
-    void* tmp = c.take<char>(tb);
-    if (!tmp) return APE_EWORKSPACE;
-    const int g = grid_for(n, 1024);
-    hipLaunchKernelGGL(bounds_stage1, dim3(g), dim3(kT), 0, st, pts, n, part);
-    hipLaunchKernelGGL(bounds_stage2, dim3(1), dim3(64), 0, st, part, g, part + 4096 * 16);
-    hipLaunchKernelGGL(keys_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pts, n, part + 4096 * 16, voxel, voxel * 0.5, k0, i0, (double*)nullptr);
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, k0, k1, i0, i1, n, 0, 63, st) != hipSuccess) return APE_ELAUNCH;
-    hipLaunchKernelGGL(heads_kernel, dim3(grid_for(n)), dim3(kT), 0, st, k1, n, head);
-    if (hipcub::DeviceScan::ExclusiveSum(tmp, tb, head, scan, n, st) != hipSuccess) return APE_ELAUNCH;
-    hipLaunchKernelGGL(voxel_mean_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pts, k1, i1, head, scan, n, out, n_out);
-    return ape::check_launch("ape_voxel_down_sample_f64");
-}
-
-/* Build the search grid of a cloud: sorted[n][3], keys[n], order[n], origin[3] (all caller-owned device buffers). */
-extern "C" int ape_grid_build_f64(const double* pts, int n, double cell, double* sorted, unsigned long long* keys, unsigned* order,
-                                  double* origin3, void* ws, size_t ws_bytes, void* stream)
-{
-    if (!pts || !sorted || !keys || !order || !origin3 || !ws || n < 1 || !(cell > 0)) return APE_EINVAL;
-    if (ws_bytes < ape_pc_workspace_bytes(n)) return APE_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    Carver c{(char*)ws, (char*)ws + ws_bytes};
-    u64* k0 = c.take<u64>(n); c.take<u64>(n);
-    unsigned* i0 = c.take<unsigned>(n); c.take<unsigned>(n);
-    c.take<int>(n); c.take<int>(n);
-    double* part = c.take<double>(4096 * 32);
-    size_t tb = sort_temp_bytes(n);
-    void* tmp = c.take<char>(tb);
-    if (!tmp) return APE_EWORKSPACE;
-    const int g = grid_for(n, 1024);
-    hipLaunchKernelGGL(bounds_stage1, dim3(g), dim3(kT), 0, st, pts, n, part);
-    hipLaunchKernelGGL(bounds_stage2, dim3(1), dim3(64), 0, st, part, g, part + 4096 * 16);
-    hipLaunchKernelGGL(keys_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pts, n, part + 4096 * 16, cell, cell, k0, i0, origin3);
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tb, k0, (u64*)keys, i0, order, n, 0, 63, st) != hipSuccess) return APE_ELAUNCH;
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pts, order, n, sorted);
-    return ape::check_launch("ape_grid_build_f64");
 }
 
 #define GRID_ARGS const double* sorted, const unsigned long long* keys, const unsigned* order, const double* origin3, int n, double cell
@@ -830,20 +693,6 @@ extern "C" int ape_mahalanobis_f64(const double* pts, int n, const double* mean_
     hipLaunchKernelGGL(mahalanobis_kernel, dim3(grid_for(n)), dim3(kT), 0, (hipStream_t)stream, pts, n, mc, out);
     return ape::check_launch("ape_mahalanobis_f64");
 }
-
-/* out[i] = pts[sel[i]] for the rows with keep[i] != 0, in order (capacity n); *n_out on the device */
-extern "C" int ape_select_points_f64(const double* pts, const uint8_t* keep, int n, double* out, int* sel_idx, int* n_out, void* ws,
-                                     size_t ws_bytes, void* stream)
-{
-    if (!pts || !keep || !out || !sel_idx || !n_out || !ws || n < 1) return APE_EINVAL;
-    size_t tb = sort_temp_bytes(n);
-    if (ws_bytes < tb) return APE_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    if (hipcub::DeviceSelect::Flagged(ws, tb, hipcub::CountingInputIterator<int>(0), keep, sel_idx, n_out, n, st) != hipSuccess) return APE_ELAUNCH;
-    hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for(n)), dim3(kT), 0, st, pts, sel_idx, n_out, out);
-    return ape::check_launch("ape_select_points_f64");
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // ICP iteration entirely on the device (open3d 0.9 RegistrationICP as called at pc_reconstruction/open3d_utils.py:96-117): the
@@ -1164,7 +1013,7 @@ struct BKeys { const double* pts; const double* bounds6; u64* keys; unsigned* id
 struct BVox { const double* pts; const u64* keys; const unsigned* order; int* head; int* scan; double* out; int* n_out; int n, gx; };
 struct BGather { const double* pts; const unsigned* order; double* out; int n, gx; };
 struct BGridQ { Grid g; const double* q; int nq, gx; double r2; int* count; double* normals; int max_nn; double* mean; int k; };
-struct BSel { const double* pts; const int* count; const double* mean; int* sel; int* n_out; double* out; int n, gx, thr_count; double thr_mean; int mode; };
+struct BSel { const double* pts; const int* count; const double* mean; int* sel; int* n_out; double* out; int n, gx, thr_count; double thr_mean; int mode; const uint8_t* keep; };
 struct BMom { const double* pts; double* part; double* out; int n, gx; };
 struct BMaha { const double* pts; double* out; int n, gx; Vec12 mc; };
 struct BXform { double* pts; double* normals; Mat4 T; int n, gx; };
@@ -1250,6 +1099,7 @@ __global__ __launch_bounds__(kCT) void select_compact_batch(const Batch<BSel> b)
     const BSel& a = b.t[blockIdx.y];
     if (a.n <= 0) return;
     if (a.mode == 0) compact_block(a.n, [&](int i) { return a.count[i] > a.thr_count; }, a.sel, a.n_out);
+    else if (a.mode == 2) compact_block(a.n, [&](int i) { return a.keep[i] != 0; }, a.sel, a.n_out);
     else compact_block(a.n, [&](int i) { const double m = a.mean[i]; return m > 0.0 && m < a.thr_mean; }, a.sel, a.n_out);
 }
 __global__ void select_rows_batch(const Batch<BSel> b)
@@ -1310,17 +1160,20 @@ __global__ __launch_bounds__(64) void icp_reduce_step_batch(const Batch<BIcp> b,
     icp_reduce_step_kernel_body(a.part, a.gx_sum, kind == 0 ? 17 : 29, a.sums, kind, a.st, a.ns, rel_fitness, rel_rmse, max_iteration, 0, 1);
 }
 
-// ---- one workgroup sorts one cloud's (cell key, original index) pairs: stable sort by key = sort by (key, index) -------------------------
-// hipCUB's radix sort walks all 64 key bits in 8 passes of several launches (its segmented form: 405 us per call for eight 5 k-point
-// segments -- half the label path's GPU time); the keys are cell coordinates of a compact cloud, so here (cx, cy, cz) is re-coded as the
-// lexicographic rank (cx * ny + cy) * nz + cz < 2^46 (ny, nz: 1 + the cloud's largest cell coordinate; same order as the packed 3 x 21-bit
-// key), packed with the 17-bit index into ONE 64-bit word, and runs of 16 k words (128 KB of LDS, one workgroup per run) are sorted by a
-// stable LSD radix sort over the rank's bits only (radix_lds: 4 bits per pass, 5 passes for a 10^6-cell grid; a first version used a
-// bitonic network in LDS -- ~78 trips of every word through LDS, LDS-bandwidth bound at 88 us per call against 52 now); a cloud of
-// several runs (a raw 640x480 surface: 20..60 k points) is then merged by rank (seg_merge_batch).  Clouds beyond 128 k points or 2^46
-// cells take a bitonic network over the global key / index arrays with the (key, index) compare.
+// ---- the sort of one cloud's (cell key, original index) pairs: stable sort by key = sort by (key, index) --------------------------------
+// A library radix sort walks all 64 key bits in 8 passes of several launches (hipCUB's segmented form: 405 us per call for eight 5 k-point
+// segments -- it was half the label path's GPU time); the keys are cell coordinates of a compact cloud, so here (cx, cy, cz) is re-coded
+// as the lexicographic rank (cx * ny + cy) * nz + cz (ny, nz: 1 + the cloud's largest cell coordinate; same order as the packed
+// 3 x 21-bit key), packed with the ceil(log2 n)-bit index into ONE 64-bit word, and runs of 16 k words (128 KB of LDS, one workgroup per
+// run) are sorted by a stable LSD radix sort over the rank's bits only (radix_lds: 4 bits per pass, 5 passes for a 10^6-cell grid; a
+// first version used a bitonic network in LDS -- ~78 trips of every word through LDS, LDS-bandwidth bound at 88 us per call against 43
+// now); a cloud of several runs (a raw 640x480 surface: 20..300 k points = 2..19 runs) is then merged by rank (seg_merge_batch).  Only a
+// cloud beyond kSortRuns runs (2^20 points) or whose rank and index do not fit 64 bits together (a grid of more than 2^(64 - index bits)
+// cells: stray points far from the object) takes the general form, a bitonic network over the global key / index arrays with the
+// (key, index) compare.
 struct BSort { const u64* k_in; const unsigned* i_in; u64* k_out; unsigned* i_out; u64* k_scratch; unsigned* i_scratch; int* flag; const double* bounds6; double h, shift; int n, gx; };
-constexpr int kSortLdsMax = 16384, kSortRuns = 8, kSortIdxBits = 17;       // runs of 16 k words (128 KB of LDS), 8 x 16 k = 2^17 indices
+constexpr int kSortLdsMax = 16384, kSortRuns = 64;                         // runs of 16 k words (128 KB of LDS), up to 64 x 16 k = 2^20 points
+__host__ __device__ __forceinline__ int sort_idx_bits(int n) { int b = 1; while ((1L << b) < (long)n) ++b; return b; }
 
 // positions >= n are +infinity and never touched; all block sizes are powers of two, so the pair -> (i, l) maps are shifts, and i grows
 // with p, so a thread stops at its first pair past the data
@@ -1450,7 +1303,7 @@ __global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
     const int n = a.n, run = blockIdx.x;
     const int nruns = (n + kSortLdsMax - 1) / kSortLdsMax;
     if (n <= 0 || (run > 0 && run >= nruns)) return;
-    // cells per axis: the cell of the cloud's upper bound (the expression of keys_kernel on the bound itself: (p - origin) / h is monotone in
+    // cells per axis: the cell of the cloud's upper bound (the expression of keys_kernel_body on the bound itself: (p - origin) / h is monotone in
     // p and the bound IS a point's coordinate, so this is the largest cell coordinate) + 1; walking the keys for their maxima cost a
     // global round trip and 3 k LDS atomics per call
     u64 dim[3];
@@ -1460,26 +1313,27 @@ __global__ __launch_bounds__(kCT) void seg_sort_batch(const Batch<BSort> b)
         v = v < 0 ? 0 : (v > 2097151 ? 2097151 : v);
         dim[d] = (u64)v + 1;
     }
-    const bool compact = nruns <= kSortRuns && (double)dim[0] * (double)dim[1] * (double)dim[2] <= 70368744177664.0;      // 2^46
+    const int ib = sort_idx_bits(n);
+    const bool compact = nruns <= kSortRuns && (double)dim[0] * (double)dim[1] * (double)dim[2] <= (double)(1ULL << (63 - ib));
     if (run == 0 && threadIdx.x == 0) *a.flag = compact ? 1 : 0;
     if (compact) {
         const int r0 = run * kSortLdsMax, len = n - r0 < kSortLdsMax ? n - r0 : kSortLdsMax;
         for (int i = threadIdx.x; i < len; i += blockDim.x) {
             const u64 key = a.k_in[r0 + i];
             const u64 cx = key >> 42, cy = (key >> 21) & 2097151ULL, cz = key & 2097151ULL;
-            sort_lds[sw(i)] = ((((cx * dim[1]) + cy) * dim[2] + cz) << kSortIdxBits) | (u64)(r0 + i);       // i_in[i] == i (keys_kernel)
+            sort_lds[sw(i)] = ((((cx * dim[1]) + cy) * dim[2] + cz) << ib) | (u64)(r0 + i);       // i_in[i] == i (keys_batch)
         }
         __syncthreads();
         {
-            const u64 cells = dim[0] * dim[1] * dim[2];                       // exact: <= 2^46
+            const u64 cells = dim[0] * dim[1] * dim[2];                       // exact: <= 2^(63 - ib)
             const int bits = cells > 1 ? 64 - __builtin_clzll(cells - 1) : 0;
-            radix_lds(sort_lds, len, kSortIdxBits, bits);
+            radix_lds(sort_lds, len, ib, bits);
         }
         if (nruns == 1) {
             for (int i = threadIdx.x; i < len; i += blockDim.x) {
                 const u64 word = sort_lds[sw(i)];
-                a.i_out[i] = (unsigned)(word & ((1ULL << kSortIdxBits) - 1));
-                const u64 code = word >> kSortIdxBits, cxy = code / dim[2];      // the key back from its rank (no dependent gather of k_in)
+                a.i_out[i] = (unsigned)(word & ((1ULL << ib) - 1));
+                const u64 code = word >> ib, cxy = code / dim[2];      // the key back from its rank (no dependent gather of k_in)
                 a.k_out[i] = pack_key((long)(cxy / dim[1]), (long)(cxy % dim[1]), (long)(code % dim[2]));
             }
         } else {
@@ -1511,6 +1365,7 @@ __global__ void seg_merge_batch(const Batch<BSort> b)
     const int n = a.n;
     const int nruns = (n + kSortLdsMax - 1) / kSortLdsMax;
     if (nruns < 2 || (int)blockIdx.x >= a.gx || !*a.flag) return;
+    const int ib = sort_idx_bits(n);
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += a.gx * blockDim.x) {
         const u64 w = a.k_scratch[g];
         const int r = g / kSortLdsMax;
@@ -1522,7 +1377,7 @@ __global__ void seg_merge_batch(const Batch<BSort> b)
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (run[mid] < w) lo = mid + 1; else hi = mid; }
             pos += lo;
         }
-        const unsigned src = (unsigned)(w & ((1ULL << kSortIdxBits) - 1));
+        const unsigned src = (unsigned)(w & ((1ULL << ib) - 1));
         a.i_out[pos] = src;
         a.k_out[pos] = a.k_in[src];
     }
@@ -1555,10 +1410,12 @@ int keys_and_sort(int nb, const double* const* pts, const int* n, const int* off
     launch_batch(bounds1_batch, bp, nb, mg1, kT, st);
     launch_batch(bounds2_batch, bp, nb, 1, 64, st);
     launch_batch(keys_batch, bk, nb, mg2, kT, st);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_devs{0};                   // the dynamic-LDS attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return APE_ELAUNCH;
+    if (!(attr_devs.load(std::memory_order_relaxed) >> dev & 1ULL)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(seg_sort_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (kSortLdsMax + kSortLdsMax / 16) * 8) != hipSuccess) return APE_ELAUNCH;
-        attr_set = true;
+        attr_devs.fetch_or(1ULL << dev, std::memory_order_relaxed);
     }
     const size_t lds_words = (size_t)(((nmax < kSortLdsMax ? nmax : kSortLdsMax) + 31) & ~31);
     const size_t lds = (lds_words + lds_words / 16) * 8;
@@ -1712,7 +1569,7 @@ extern "C" int ape_select_points_batch_f64(int mode, int nb, const double* const
     for (int c = 0; c < nb; ++c) {
         if (n[c] < 0) return APE_EINVAL;
         b.t[c] = BSel{pts[c], mode == 0 ? count[c] : nullptr, mode == 1 ? mean[c] : nullptr, sel_ws + off, n_out + c, out[c], n[c], n[c] > 0 ? grid_for(n[c]) : 0,
-                      thr_count, mode == 1 ? thr_mean_host[c] : 0.0, mode};
+                      thr_count, mode == 1 ? thr_mean_host[c] : 0.0, mode, nullptr};
         off += n[c];
         mg = b.t[c].gx > mg ? b.t[c].gx : mg;
     }
@@ -1827,4 +1684,54 @@ extern "C" int ape_icp_run_batch_f64(int kind, int nb, BGRID_ARGS, double* const
     if (first_call) block(0);
     for (int it = 0; it < n_iter; ++it) block(1);
     return ape::check_launch("ape_icp_run_batch_f64");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The one-cloud entry points: the batched ones above with one cloud (same kernels, same results as a batch slot)
+extern "C" size_t ape_pc_workspace_bytes(int n)
+{
+    if (n < 1) n = 1;
+    return ape_pc_batch_workspace_bytes(1, n) + align_up((size_t)n * 4);
+}
+
+/* label[H][W] u8, depth[H][W] u16 -> points[n][3] f64 in raster order (capacity H*W), *n_out on the device */
+extern "C" int ape_surface_points_f64(const uint8_t* label, const uint16_t* depth, int H, int W, double fx, double fy, double ppx,
+                                      double ppy, const double* T16_host, double* points, int* n_out, void* ws, size_t ws_bytes,
+                                      void* stream)
+{
+    if (!label || !depth || !T16_host || !points || !n_out || !ws || H < 1 || W < 1) return APE_EINVAL;
+    if (ws_bytes < (size_t)H * W * 4) return APE_EWORKSPACE;
+    const double intr[4] = {fx, fy, ppx, ppy};
+    return ape_surface_points_batch_f64(1, &label, &depth, H, W, intr, T16_host, &points, n_out, (int*)ws, stream);
+}
+
+/* out capacity n points; *n_out on the device */
+extern "C" int ape_voxel_down_sample_f64(const double* pts, int n, double voxel, double* out, int* n_out, void* ws, size_t ws_bytes,
+                                         void* stream)
+{
+    if (!pts || !out || !n_out || !ws || n < 1 || !(voxel > 0)) return APE_EINVAL;
+    return ape_voxel_down_sample_batch_f64(1, &pts, &n, voxel, &out, n_out, ws, ws_bytes, stream);
+}
+
+/* Build the search grid of a cloud: sorted[n][3], keys[n], order[n], origin[3] (all caller-owned device buffers). */
+extern "C" int ape_grid_build_f64(const double* pts, int n, double cell, double* sorted, unsigned long long* keys, unsigned* order,
+                                  double* origin3, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!pts || !sorted || !keys || !order || !origin3 || !ws || n < 1 || !(cell > 0)) return APE_EINVAL;
+    return ape_grid_build_batch_f64(1, &pts, &n, cell, &sorted, &keys, &order, &origin3, ws, ws_bytes, stream);
+}
+
+/* out[i] = pts[sel[i]] for the rows with keep[i] != 0, in order (capacity n); *n_out on the device */
+extern "C" int ape_select_points_f64(const double* pts, const uint8_t* keep, int n, double* out, int* sel_idx, int* n_out, void* ws,
+                                     size_t ws_bytes, void* stream)
+{
+    (void)ws; (void)ws_bytes;
+    if (!pts || !keep || !out || !sel_idx || !n_out || n < 1) return APE_EINVAL;
+    Batch<BSel> b{};
+    b.t[0] = BSel{pts, nullptr, nullptr, sel_idx, n_out, out, n, grid_for(n), 0, 0.0, 2, keep};
+    hipStream_t st = (hipStream_t)stream;
+    launch_batch(select_compact_batch, b, 1, 1, kCT, st);
+    launch_batch(select_rows_batch, b, 1, b.t[0].gx, kT, st);
+    return ape::check_launch("ape_select_points_f64");
 }
