@@ -66,14 +66,49 @@ class _HipModule(nn.Module):
     def _apply(self, fn, *a, **k):
         self._plan = None
         self._pcache = None
-        return super()._apply(fn, *a, **k)
+        r = super()._apply(fn, *a, **k)
+        self.invalidate_banks()
+        return r
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Parameter, nn.Module)):      # a replaced parameter / sub-module: cached look-ups and the plan are stale
+            self.__dict__["_pcache"] = None
+            self.__dict__["_plan"] = None
+        super().__setattr__(name, value)
+
+    def register_parameter(self, name, param):
+        self.__dict__["_pcache"] = None
+        self.__dict__["_plan"] = None
+        super().register_parameter(name, param)
+
+    def invalidate_banks(self):
+        """drop the packed conv operands kept on this module's parameters (autograd.WeightBank): they are rebuilt from the parameters on
+        the next training forward"""
+        from autoposeestimation_amd import autograd as A
+        A.invalidate_banks(self.parameters())
+
+    def sync_banks(self):
+        """Top of every training forward: re-pack the kept conv operands of ALL this module's parameters from the parameters' storage (one
+        launch).  A bank is keyed on the parameter's torch version counter, which writes through `.data`, raw pointers (the library's
+        Adam) or collectives on `.data` never move -- so the training forward does not trust it: whatever wrote the parameters since the last
+        forward, the convolutions below run on what is in memory now."""
+        from autoposeestimation_amd import autograd as A
+        A.refresh_banks(list(self.parameters()))
 
     def param(self, name):
-        """get_parameter(name) through a dict built once (the training forward looks ~75 parameters up per step)"""
+        """get_parameter(name) through a dict built once (the training forward looks ~75 parameters up per step); an entry is checked
+        against its owner's `_parameters` slot, so a parameter replaced by assignment -- on this module or on a holder below it -- is seen"""
         c = self.__dict__.get("_pcache")
         if c is None:
-            c = self.__dict__["_pcache"] = dict(self.named_parameters())
-        return c[name]
+            c = self.__dict__["_pcache"] = {}
+        hit = c.get(name)
+        if hit is not None and hit[0]._parameters.get(hit[1]) is hit[2]:
+            return hit[2]
+        path, _, leaf = name.rpartition(".")
+        owner = self.get_submodule(path) if path else self
+        p = owner._parameters[leaf]
+        c[name] = (owner, leaf, p)
+        return p
 
     def train(self, mode=True):
         """train(True): parameters become leaves of the tape (autoposeestimation_amd/autograd.py) and forward() runs the
@@ -82,6 +117,7 @@ class _HipModule(nn.Module):
         if mode:
             for p in self.parameters():
                 p.requires_grad_(True)
+        self.invalidate_banks()
         return super().train(mode)
 
     def set_dropout_masks(self, masks):
@@ -92,7 +128,9 @@ class _HipModule(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **k):
         self._plan = None
-        return super().load_state_dict(state_dict, strict=strict, **k)
+        r = super().load_state_dict(state_dict, strict=strict, **k)
+        self.invalidate_banks()
+        return r
 
     def _sd(self):
         return {k: v for k, v in self.state_dict().items()}
@@ -460,6 +498,7 @@ class PoseNet(_HipModule):
         img4 = torch.zeros(1, img.shape[2], img.shape[3], 4, dtype=torch.float32, device=img.device)
         img4[..., :3] = img.permute(0, 2, 3, 1)
         if self.training:
+            self.sync_banks()
             return self._forward_train(img4, E.pad3to4(x.float().contiguous()), choose.reshape(1, -1).contiguous(), o)
         heads, emb = self.forward_batch(img4, E.pad3to4(x.float().contiguous()), choose.reshape(1, -1).contiguous(),
                                         obj.reshape(1).contiguous())
@@ -534,6 +573,7 @@ class PoseRefineNet(_HipModule):
         if not 0 <= o < self.num_obj:
             raise IndexError("obj index %d out of range" % o)
         if self.training:
+            self.sync_banks()
             return self._forward_train(E.pad3to4(x.float().contiguous()), emb.transpose(1, 2).contiguous(), o)
         out = self.forward_batch(E.pad3to4(x.float().contiguous()), emb.transpose(1, 2).contiguous(), obj.reshape(1).contiguous())
         return out[:, 0:4].contiguous(), out[:, 4:7].contiguous()

@@ -31,7 +31,7 @@ def train_step(estimator, refiner, criterion, criterion_refine, data, opt, devic
     # the values are read only AFTER the backward launches are queued: a read straight behind the loss (as train.py:207-226 logs it) parks
     # the host until the forward has drained, and the step is bound by the host's launch rate
     loss_value, dis_value = float(loss.detach()), float(dis.detach())
-    return loss_value, (dis_value if opt.refine_start else 0.0), dis_value
+    return loss_value, (dis_value if opt.refine_start and opt.iteration > 0 else 0.0), dis_value      # no refiner pass ran: no refiner loss
 
 
 def train_epoch(estimator, refiner, optimizer, criterion, criterion_refine, dataloader, opt, device="cuda:0"):

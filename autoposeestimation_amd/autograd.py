@@ -76,8 +76,12 @@ class WeightBank:
     """The conv kernels' operands of ONE parameter, kept while the parameter does not change ("keep packed weights
     until optimizer.step()"): the forward form ([Cout,KH,KW,Cin4] f32 + split-bf16 planes) and the input-gradient form (flipped taps,
     channels transposed).  Both are written by ONE launch of ape_pack_train_weights from the parameter's own storage; `Adam.step()`
-    re-packs the banks of all its parameters in one further launch right after the update.  A bank is stale when the parameter's
-    torch version counter moved (load_state_dict, a torch optimizer, any in-place op) -- it is then rebuilt on the next use."""
+    re-packs the banks of all its parameters in one further launch right after the update.  A bank is rebuilt on the next use when the
+    parameter's torch version counter moved (a torch optimizer, any in-place op on the parameter itself).  Writes the counter does not see
+    -- `p.data.mul_()`, `dist.broadcast(p.data)`, a raw-pointer kernel -- are covered one level up: the modules' training forward re-packs
+    every bank of the module first (`_HipModule.sync_banks`, one launch), and load_state_dict / .to() / train() drop the banks
+    (`invalidate_banks`).  Code that calls the tape's conv functions directly after such a write calls `refresh_banks` / `invalidate_banks`
+    itself."""
 
     def __init__(self, weight, precision):
         w = weight.detach()
@@ -146,6 +150,18 @@ def weight_bank(weight, precision):
         except AttributeError:
             pass
     return bank
+
+
+def invalidate_banks(params):
+    """forget the kept operands of `params` (and of their row / column blocks): the next use packs them again from the parameter"""
+    for p in params:
+        for name in ("_ape_bank", "_ape_slices"):
+            if getattr(p, name, None) is not None:
+                try:
+                    delattr(p, name)
+                except AttributeError:
+                    pass
+    refresh_banks.cache.clear()
 
 
 def refresh_banks(params):

@@ -4,7 +4,8 @@ symmetric objects) -> `dis < 0.02 m` bucket per class.  Everything after the PNG
 
 Multi-GPU: the samples are independent, so with `dist=` (an initialised torch.distributed) every rank evaluates
 its contiguous `shard_range` of the test set and ONE all-reduce of the per-class `(sum of dis, count < 2 cm, count)` table (float64)
-plus one gather of the per-sample distances gives every rank the reference's result dict -- the same numbers as the single-rank
+plus one gather of the per-sample distances gives every rank the reference's result dict (a rank that raises inside its shard makes
+every rank raise: `sharding.guarded`) -- the same numbers as the single-rank
 loop up to the float64 summation order of `dis` (the counts are exact)."""
 import numpy as np
 import torch
@@ -25,22 +26,32 @@ def eval(num_points, refine_start, data_set_name, show_sample, label_mode, p_ext
     dists = []
     sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     lo, hi = shard_range(len(dataset), dist.get_rank(), dist.get_world_size()) if sharded else (0, len(dataset))
-    for j in range(lo, hi):
-        points, choose, img, target, model_points, idx, intr, np_img = dataset[j]
-        cls_key = classes[int(idx[0])]
-        points, choose, img = points.unsqueeze(0).cuda(), choose.unsqueeze(0).cuda(), img.unsqueeze(0).cuda()
-        target, model_points, idx = target.unsqueeze(0).cuda(), model_points.unsqueeze(0).cuda(), idx.cuda()
-        pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx.view(1, 1))
-        _, dis, new_points, new_target, _ = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, w, refine_start)
-        if refine_start:
-            for _ in range(iteration):
-                pred_r, pred_t = refiner(new_points, emb, idx.view(1, 1))
-                dis, new_points, new_target, _ = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
-        dists.append(float(dis.reshape(-1)[0].item()))
-        results[cls_key]["<2" if dists[-1] < 0.02 else ">=2"] += 1
-        results[cls_key]["dis"].append(dists[-1])
-        if verbose:
-            print("sample {}/{}| dis: {}, average ADD-s: {}".format(j, len(dataset), np.round(dists[-1], 5), np.round(np.mean(dists), 5)))
+
+    def shard():
+        for j in range(lo, hi):
+            points, choose, img, target, model_points, idx, intr, np_img = dataset[j]
+            cls_key = classes[int(idx[0])]
+            points, choose, img = points.unsqueeze(0).cuda(), choose.unsqueeze(0).cuda(), img.unsqueeze(0).cuda()
+            target, model_points, idx = target.unsqueeze(0).cuda(), model_points.unsqueeze(0).cuda(), idx.cuda()
+            pred_r, pred_t, pred_c, emb = estimator(img, points, choose, idx.view(1, 1))
+            _, dis, new_points, new_target, _ = criterion(pred_r, pred_t, pred_c, target, model_points, idx, points, w, refine_start)
+            if refine_start:
+                for _ in range(iteration):
+                    pred_r, pred_t = refiner(new_points, emb, idx.view(1, 1))
+                    dis, new_points, new_target, _ = criterion_refine(pred_r, pred_t, new_target, model_points, idx, new_points)
+            dists.append(float(dis.reshape(-1)[0].item()))
+            results[cls_key]["<2" if dists[-1] < 0.02 else ">=2"] += 1
+            results[cls_key]["dis"].append(dists[-1])
+            if verbose:
+                print("sample {}/{}| dis: {}, average ADD-s: {}".format(j, len(dataset), np.round(dists[-1], 5), np.round(np.mean(dists), 5)))
+
+    # a rank that fails inside its shard (a corrupt sample, a library error) must not leave the others waiting in merge_results' collectives:
+    # every rank learns of it and raises (sharding.all_ranks_ok)
+    if sharded:
+        from autoposeestimation_amd.sharding import guarded
+        guarded(dist, shard, "experiments/eval.py: this rank's shard of the test set")
+    else:
+        shard()
     return merge_results(results, classes, dist if sharded else None)
 
 

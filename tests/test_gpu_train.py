@@ -555,6 +555,54 @@ def test_weight_bank_of_a_column_block_packs_in_place_and_follows_the_optimizer(
     check()
 
 
+def test_training_forward_follows_writes_the_version_counter_does_not_see():
+    """the kept conv operands (autograd.WeightBank) are keyed on the parameter's version counter; `p.data.mul_()`, a copy through `.data`
+    or a replaced parameter do not move it: the training forward re-packs the module's banks first (sync_banks), so the outputs follow
+    the parameters -- checked against a freshly built module holding the same values"""
+    from autoposeestimation_amd import synthetic as S
+    from autoposeestimation_amd.DenseFusion.lib.network import PoseRefineNet
+    n, num_obj = 200, 4
+    sd = S.refiner_state_dict(num_obj, seed=9)
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(1, 32, n, generator=g).to(DEV)
+    pts = (torch.randn(1, n, 3, generator=g) * 0.05).to(DEV)
+    obj = torch.tensor([[2]]).to(DEV)
+
+    def fresh(state):
+        m = PoseRefineNet(n, num_obj)
+        m.load_state_dict(state)
+        return m.to(DEV).train()
+
+    net = fresh(sd)
+    out0 = [t.detach().clone() for t in net(pts, emb, obj)]
+    # (1) in-place through .data on every parameter
+    with torch.no_grad():
+        for p in net.parameters():
+            v = p._version
+            p.data.mul_(1.25)
+            assert p._version == v                                    # the write is invisible to the counter
+    out1 = [t.detach().clone() for t in net(pts, emb, obj)]
+    want1 = [t.detach() for t in fresh({k: v * 1.25 for k, v in sd.items()})(pts, emb, obj)]
+    assert all(torch.equal(a, b) for a, b in zip(out1, want1))
+    assert not torch.equal(out1[0], out0[0])
+    # (2) a copy through .data (what dist.broadcast(p.data) does)
+    for k, p in net.named_parameters():
+        p.data.copy_(sd[k].to(DEV))
+    out2 = [t.detach() for t in net(pts, emb, obj)]
+    assert all(torch.equal(a, b) for a, b in zip(out2, out0))
+    # (3) a parameter replaced by assignment: the name -> parameter cache is dropped
+    name, old = next((k, p) for k, p in net.named_parameters() if k.endswith("conv1_r.weight"))
+    mod = net
+    for part in name.split(".")[:-1]:
+        mod = getattr(mod, part)
+    setattr(mod, name.split(".")[-1], torch.nn.Parameter(old.detach() * 0.5))
+    out3 = [t.detach() for t in net(pts, emb, obj)]
+    sd3 = dict(sd)
+    sd3[name] = sd[name] * 0.5
+    want3 = [t.detach() for t in fresh(sd3)(pts, emb, obj)]
+    assert all(torch.equal(a, b) for a, b in zip(out3, want3))
+
+
 def test_multi_tensor_adam_equals_the_one_buffer_kernel_bitwise():
     """ape_adam_step_multi_f32 (all parameters in one launch, 64 per launch: 150 buffers = 3 launches) against ape_adam_step_f32 buffer by
     buffer, three steps, buffers of 1 .. 3 M elements, one without a gradient"""

@@ -305,3 +305,47 @@ def test_a_failure_on_one_rank_is_raised_on_every_rank():
     assert got[1] == "own error"
     for r in (0, 2):
         assert got[r].startswith("told:") and "rank(s) [1]" in got[r]
+
+
+def _failing_eval_worker(rank, world, port, q):
+    from autoposeestimation_amd.experiments import eval as EV
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class OneBadSample:                  # stands in for PoseDataset("test", ...): one sample, unreadable
+        def __init__(self, *a, **k):
+            pass
+
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, j):
+            raise KeyError("corrupt sample %d" % j)
+
+        def get_num_points_mesh(self):
+            return 500
+
+        def get_sym_list(self):
+            return []
+
+    EV.PoseDataset = OneBadSample
+    try:
+        EV.eval(500, False, "set", False, "auto", 0.0, 0.0, None, 0.015, None, 0, 0, ["a"], dist=dist)
+        outcome = "returned"
+    except KeyError:
+        outcome = "own error"
+    except RuntimeError as e:
+        outcome = "told: " + str(e)
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_eval_shard_is_raised_on_every_rank():
+    """experiments/eval.py: the rank holding the unreadable sample raises its own error, the rank with an empty shard is told instead of
+    waiting in merge_results' all_reduce"""
+    got = _spawn(_failing_eval_worker, 2, 30700)
+    owner = 0 if shard_range(1, 0, 2) == (0, 1) else 1
+    assert got[owner] == "own error"
+    assert got[1 - owner].startswith("told:") and "rank(s) [%d]" % owner in got[1 - owner]
