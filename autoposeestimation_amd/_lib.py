@@ -70,11 +70,6 @@ SIGNATURES = {
     "ape_seg_components_workspace_bytes": [_I, _I, _I, _I],
     "ape_seg_components": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_conv3x3_halo_seghead_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
-    "ape_up3_seghead_ws_supported": [_P, _I],
-    "ape_up3_seghead_ws_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
-    "ape_up3_seghead_debug": [_I],
-    "ape_up3_seghead_debug_get": [],
-    "ape_up3_seghead_stamps": [_P],
     "ape_seg_components_scored": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_bgsub_features_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "ape_conv2d_wgrad_workspace_bytes": [_P],

@@ -604,12 +604,6 @@ extern "C" int ape_conv3x3_halo_bf16(const float* x, const void* w_packed, const
 #undef HALO_DISPATCH
 }
 
-extern "C" int ape_up3_seghead_ws_supported(const ape_conv_params* params, int nsplit);
-extern "C" int ape_up3_seghead_debug_get(void);
-extern "C" int ape_up3_seghead_ws_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params, int nsplit,
-                                       const float* head_w, const float* head_b, int C, uint8_t* label, float* score, int double_softmax,
-                                       void* stream);
-
 /* Same convolution (Cout must be 64, no residual) with the segmentation head fused into its epilogue: see include/ape_hip.h */
 extern "C" int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params,
                                              int nsplit, const float* head_w, const float* head_b, int C, uint8_t* label, float* score,
@@ -623,10 +617,6 @@ extern "C" int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packe
     if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID || (p.ups != 0 && p.ups != 1)) return APE_EINVAL;
     if (p.ups && ((p.H & 1) || (p.W & 1))) return APE_EINVAL;
     if (p.B == 0) return APE_OK;
-    // opt-in (ape_up3_seghead_debug bit 1): the wave-specialised persistent kernel (up3_head_ws.hip), bit-identical labels and scores,
-    // measured at the same speed as the kernel below
-    if ((ape_up3_seghead_debug_get() & 2) && ape_up3_seghead_ws_supported(params, nsplit) && (!bias || ((size_t)bias % 16 == 0 && p.bias_bstride % 4 == 0)))
-        return ape_up3_seghead_ws_bf16(x, w_packed, bias, params, nsplit, head_w, head_b, C, label, score, double_softmax, stream);
     const long K = 9L * p.Cin, Kp = (K + 7) / 8 * 8;
     if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.Cout * Kp >= (1L << 31)) return APE_EINVAL;
     HaloArgs a;

@@ -123,109 +123,4 @@ __device__ __forceinline__ void seg_head_group(const float4 (&x)[4], const float
     seg_head_finish(acc, C, lane, double_softmax, am_out, pm_out);
 }
 
-
-// The same head for G groups of 16 pixels at once, written step by step ACROSS the groups so that their G independent dependency
-// chains (16 dependent f32 MFMAs, the arg-max exchange, exp -> sum -> reciprocal, twice) interleave: one wave per SIMD running the
-// groups one after the other pays every instruction's latency (measured in up3_head_ws.hip: 14 k cycles per 4 groups).
-// Per group exactly the operations of seg_head_group, in the same order: bit-identical labels and scores.
-template <int G>
-__device__ __forceinline__ void seg_head_groups(const float4 (&x)[G][4], const float (&wreg)[16], const float (&breg)[4], int C, int lane,
-                                                int double_softmax, int (&am_out)[G], float (&pm_out)[G])
-{
-    const int kq = lane >> 4;
-    f32x4h acc[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = f32x4h{breg[0], breg[1], breg[2], breg[3]};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 0], x[g][j].x, acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 1], x[g][j].y, acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 2], x[g][j].z, acc[g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j * 4 + 3], x[g][j].w, acc[g], 0, 0, 0);
-    }
-    float m[G];
-    int am[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        m[g] = -__builtin_inff();
-        am[g] = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = kq * 4 + r;
-            if (c < C && acc[g][r] > m[g]) { m[g] = acc[g][r]; am[g] = c; }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const float om = lane_xor16(m[g], lane);
-        const int oa = (int)lane_xor16_u((unsigned)am[g], lane);
-        if (om > m[g] || (om == m[g] && oa < am[g])) { m[g] = om; am[g] = oa; }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const float om = lane_xor32(m[g], lane);
-        const int oa = (int)lane_xor32_u((unsigned)am[g], lane);
-        if (om > m[g] || (om == m[g] && oa < am[g])) { m[g] = om; am[g] = oa; }
-    }
-    float e[G][4], s[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        s[g] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { e[g][r] = (kq * 4 + r < C) ? __expf(acc[g][r] - m[g]) : 0.f; s[g] += e[g][r]; }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) s[g] += lane_xor16(s[g], lane);
-#pragma unroll
-    for (int g = 0; g < G; ++g) s[g] += lane_xor32(s[g], lane);
-    float pm[G], t[G][4];
-#pragma unroll
-    for (int g = 0; g < G; ++g) pm[g] = __builtin_amdgcn_rcpf(s[g]);
-    if (double_softmax) {
-        float s2[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float inv = pm[g];
-            s2[g] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { t[g][r] = (kq * 4 + r < C) ? __expf(e[g][r] * inv - pm[g]) : 0.f; s2[g] += t[g][r]; }
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) s2[g] += lane_xor16(s2[g], lane);
-#pragma unroll
-        for (int g = 0; g < G; ++g) s2[g] += lane_xor32(s2[g], lane);
-#pragma unroll
-        for (int g = 0; g < G; ++g) pm[g] = __builtin_amdgcn_rcpf(s2[g]);
-    } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[g][r] = e[g][r];
-    }
-    int tmin[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        tmin[g] = am[g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (t[g][r] == 1.f && kq * 4 + r < tmin[g]) tmin[g] = kq * 4 + r;
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int o16 = (int)lane_xor16_u((unsigned)tmin[g], lane);
-        tmin[g] = o16 < tmin[g] ? o16 : tmin[g];
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int o32 = (int)lane_xor32_u((unsigned)tmin[g], lane);
-        am[g] = o32 < tmin[g] ? o32 : tmin[g];
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) { am_out[g] = am[g]; pm_out[g] = pm[g]; }
-}
-
 }  // namespace ape_seg

@@ -406,22 +406,6 @@ int ape_conv3x3_halo_seghead_bf16(const float* x, const void* w_packed, const fl
                                   const float* head_w, const float* head_b, int C, uint8_t* label, float* score, int double_softmax,
                                   void* stream);
 
-/* The same operator for the segmentor's own up_3 (DenseFusion/lib/pspnet.py:51,53-55: nsplit 3, Cin = Cout = 64, params->ups = 1) as a
- * wave-specialised persistent kernel (four matrix waves + four producer waves per CU, csrc/up3_head_ws.hip); labels and scores are
- * bit-identical to ape_conv3x3_halo_seghead_bf16's.  Measured at the SAME speed as the one-role kernel, so it is opt-in:
- * ape_conv3x3_halo_seghead_bf16 dispatches here only when ape_up3_seghead_debug bit 1 is set.  bias (if given) must be 16-byte
- * aligned.  ape_up3_seghead_debug bits: 0 = matrix waves at static priority 1, 1 = route ape_conv3x3_halo_seghead_bf16 here,
- * 5 = producer waves at priority 3 (results unchanged by these); 2, 3, 4 = timing-only ablations (no halo building / no MFMAs / no
- * head: WRONG results, for tools/ab_up3.py only). */
-int ape_up3_seghead_ws_supported(const ape_conv_params* params, int nsplit);
-int ape_up3_seghead_ws_bf16(const float* x, const void* w_packed, const float* bias, const ape_conv_params* params, int nsplit,
-                            const float* head_w, const float* head_b, int C, uint8_t* label, float* score, int double_softmax,
-                            void* stream);
-int ape_up3_seghead_debug(int bits);
-int ape_up3_seghead_debug_get(void);
-/* diagnostic: device buffer of 256 x 4 x 4 uint64 -> the following launches run a stamped build (s_memtime sums per matrix wave: burst,
- * wait + barrier, head epilogue, tiles); NULL switches it off */
-int ape_up3_seghead_stamps(void* device_buffer);
 
 /* ---- training step: the backward kernels behind DenseFusion/tools/train.py:205-238 -------------------
  * `loss.backward()` / `dis.backward()` there run torch autograd over cuDNN; each entry below is one backward rule of the ops

@@ -179,25 +179,3 @@ def test_halo_conv_with_fused_seg_head_is_bit_identical_to_the_unfused_pair(prec
     assert len(torch.unique(label)) > 1
 
 
-@pytest.mark.parametrize("b,h,w", [(3, 24, 40), (2, 21, 33), (3, 120, 160), (5, 136, 104)])
-def test_wave_specialised_up3_head_equals_the_one_role_kernel_bitwise(b, h, w):
-    """csrc/up3_head_ws.hip (four matrix waves + four producer waves per CU, persistent over the tiles; opt-in through
-    ape_up3_seghead_debug bit 1) == conv3x3_halo_kernel<3,1,64,true,true>: labels and scores bit for bit, one tile per workgroup
-    (45 / 18 tiles), several tiles per workgroup with ragged tile counts (900 and 1105 tiles over 256 workgroups)"""
-    from autoposeestimation_amd import _lib, engine as E
-    g = torch.Generator().manual_seed(b * 1000 + h + w)
-    x = torch.randn(b, h, w, 64, generator=g).to("cuda")
-    wt = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to("cuda")
-    bias = (torch.randn(64, generator=g) * 0.1).to("cuda")
-    hw = (torch.randn(13, 64, generator=g) * 0.3).to("cuda").contiguous()
-    hb = (torch.randn(13, generator=g) * 0.1).to("cuda")
-    conv = E.Conv(wt, bias, 1, 1, 1, E.ACT_PRELU, alpha=0.25, device="cuda", precision="bf16x3")
-    want = E.conv_seg_head(conv, x, hw, hb, True, upsample2x=True)
-    _lib.lib().ape_up3_seghead_debug(2)
-    try:
-        got = E.conv_seg_head(conv, x, hw, hb, True, upsample2x=True)
-        again = E.conv_seg_head(conv, x, hw, hb, True, upsample2x=True)
-    finally:
-        _lib.lib().ape_up3_seghead_debug(0)
-    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
-    assert torch.equal(again[0], want[0]) and torch.equal(again[1], want[1])
