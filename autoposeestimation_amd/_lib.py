@@ -36,6 +36,7 @@ SIGNATURES = {
     "ape_adaptive_avgpool_multi_nhwc_fmt": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_upconv3x3_gather_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "ape_upconv3x3_gather_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ape_upconv3x3_gather_strip_rows": [_I],
     "ape_upconv3x3_fused_supported": [_I, _I, _I, _I],
     "ape_upconv3x3_fused_debug": [_I],
     "ape_upconv3x3_fused_stamps": [_P],

@@ -487,6 +487,154 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
     }
 }
 
+// The same operator for channel counts that are multiples of 64, as a walk DOWN the image: one workgroup = a strip of `rows` output rows x
+// 16 output columns x 64 channels (256-byte runs of z and of the output).  The row kernel above re-reads z for every output row -- each z
+// element is wanted by ~4 output rows (2 as the upper, 2 as the lower row of the y interpolation), 6 row loads per output row and S value --
+// and is bound by that L2 -> L1 traffic (~5x the tensor per launch), not by HBM.  Here a thread keeps the two z rows of each of its 9 taps in
+// registers while the strip moves down: going from output row Y to Y + 1 a tap's row pair (iy0, iy1) either stays or becomes (iy1, iy1 + 1)
+// -- one new row load, on average 1.5 per output row instead of 6 -- and the loads for row Y + 1 are issued before row Y's x interpolation,
+// so they fly during it.  The arithmetic per output is the row kernel's, operation for operation (same S_kx, same x interpolation, same
+// epilogue): bit-identical outputs.
+template <bool S32OUT, bool FMA>
+__global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* __restrict__ z, const float* __restrict__ bias,
+                                                                  float4* __restrict__ out, int B, int h, int w, int C4, float sh, float sw,
+                                                                  int act, float alpha, int rows)
+{
+    const int Ho = 2 * h, Wo = 2 * w;
+    const int xt_n = (Wo + 15) / 16, ns = (Ho + rows - 1) / rows, nslab = C4 / 16;
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;      // neighbours in x (shared halo columns) on one XCD
+    const int slab = logical % nslab; logical /= nslab;
+    const int xt = logical % xt_n; logical /= xt_n;
+    const int strip = logical % ns;
+    const int b = logical / ns;
+    const int Ys = strip * rows, Ye = Ys + rows < Ho ? Ys + rows : Ho;
+    __shared__ float4 S[2][3 * kUpCols * 16];
+    const int X0 = xt * 16;
+    const int qx_lo = X0 - 1 < 0 ? 0 : X0 - 1, qx_hi = X0 + 16 > Wo - 1 ? Wo - 1 : X0 + 16;
+    const int ix_lo = (int)(sw * (float)qx_lo);
+    int ix_hi = (int)(sw * (float)qx_hi);
+    ix_hi = ix_hi + (ix_hi < w - 1 ? 1 : 0);
+    const int ni = ix_hi - ix_lo + 1;                   // <= kUpCols (host checks)
+    const int c4 = threadIdx.x & 15, hi4 = threadIdx.x >> 4;
+    const int c = slab * 16 + c4;
+    // phase 1 role: low-resolution column ix_lo + hi4 (idle beyond ni), all 9 taps
+    const bool p1 = hi4 < ni;
+    const long rs = (long)w * 9 * C4;                   // float4 per low-resolution row of z
+    const float4* zc = z + (long)b * h * rs + (long)(ix_lo + (p1 ? hi4 : 0)) * 9 * C4 + c;
+    float4 v0[3][3], v1[3][3];                          // [ky][kx]: the held row pair of every tap
+    int hy0[3] = {-1, -1, -1}, hy1[3] = {-1, -1, -1};
+    // phase 2 role: output column X0 + hi4
+    const int X = X0 + hi4;
+    const bool p2 = X < Wo;
+    int so0[3], so1[3];
+    float lx0[3], lx1[3];
+    bool xok[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int qx = X + kx - 1;
+        xok[kx] = p2 && (unsigned)qx < (unsigned)Wo;
+        const float fx = sw * (float)(xok[kx] ? qx : 0);
+        const int ix0 = (int)fx, ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+        lx1[kx] = fx - (float)ix0;
+        lx0[kx] = 1.f - lx1[kx];
+        so0[kx] = xok[kx] ? (kx * kUpCols + ix0 - ix_lo) * 16 + c4 : c4;
+        so1[kx] = xok[kx] ? (kx * kUpCols + ix1 - ix_lo) * 16 + c4 : c4;
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = make_float4(bias[c * 4], bias[c * 4 + 1], bias[c * 4 + 2], bias[c * 4 + 3]);
+
+    auto window = [&](int Y) {                          // make the registers hold the row pairs of output row Y
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = Y + ky - 1;
+            const float fy = sh * (float)((unsigned)qy < (unsigned)Ho ? qy : 0);
+            const int iy0 = (int)fy, iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
+            if (iy0 == hy0[ky]) continue;
+            if (p1) {
+                if (iy0 == hy1[ky]) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) v0[ky][kx] = v1[ky][kx];
+                } else {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) v0[ky][kx] = zc[(long)iy0 * rs + (ky * 3 + kx) * C4];
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) v1[ky][kx] = zc[(long)iy1 * rs + (ky * 3 + kx) * C4];
+            }
+            hy0[ky] = iy0; hy1[ky] = iy1;
+        }
+    };
+    window(Ys);
+    for (int Y = Ys; Y < Ye; ++Y) {
+        float4* Sb = S[Y & 1];
+        if (p1) {
+            float ly0[3], ly1[3];
+            bool yok[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int qy = Y + ky - 1;
+                yok[ky] = (unsigned)qy < (unsigned)Ho;
+                const float fy = sh * (float)(yok[ky] ? qy : 0);
+                ly1[ky] = fy - (float)(int)fy;
+                ly0[ky] = 1.f - ly1[ky];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (!yok[ky]) continue;
+                    const float4 a0 = v0[ky][kx], a1 = v1[ky][kx];
+                    if (FMA) {
+                        acc.x = fmaf(ly1[ky], a1.x, fmaf(ly0[ky], a0.x, acc.x));
+                        acc.y = fmaf(ly1[ky], a1.y, fmaf(ly0[ky], a0.y, acc.y));
+                        acc.z = fmaf(ly1[ky], a1.z, fmaf(ly0[ky], a0.z, acc.z));
+                        acc.w = fmaf(ly1[ky], a1.w, fmaf(ly0[ky], a0.w, acc.w));
+                        continue;
+                    }
+                    acc.x += ly0[ky] * a0.x + ly1[ky] * a1.x;
+                    acc.y += ly0[ky] * a0.y + ly1[ky] * a1.y;
+                    acc.z += ly0[ky] * a0.z + ly1[ky] * a1.z;
+                    acc.w += ly0[ky] * a0.w + ly1[ky] * a1.w;
+                }
+                Sb[(kx * kUpCols + hi4) * 16 + c4] = acc;
+            }
+        }
+        if (Y + 1 < Ye) window(Y + 1);                  // the next row's new z rows: in flight during the x interpolation below
+        __syncthreads();
+        if (p2) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                if (!xok[kx]) continue;
+                const float4 s0 = Sb[so0[kx]], s1 = Sb[so1[kx]];
+                if (FMA) {
+                    acc.x = fmaf(lx1[kx], s1.x, fmaf(lx0[kx], s0.x, acc.x));
+                    acc.y = fmaf(lx1[kx], s1.y, fmaf(lx0[kx], s0.y, acc.y));
+                    acc.z = fmaf(lx1[kx], s1.z, fmaf(lx0[kx], s0.z, acc.z));
+                    acc.w = fmaf(lx1[kx], s1.w, fmaf(lx0[kx], s0.w, acc.w));
+                    continue;
+                }
+                acc.x += lx0[kx] * s0.x + lx1[kx] * s1.x;
+                acc.y += lx0[kx] * s0.y + lx1[kx] * s1.y;
+                acc.z += lx0[kx] * s0.z + lx1[kx] * s1.z;
+                acc.w += lx0[kx] * s0.w + lx1[kx] * s1.w;
+            }
+            if (bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
+            if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+            else if (act == APE_ACT_PRELU) {
+                acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;
+                acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
+            }
+            if (S32OUT) ape::s32_store4(out, (long)(b * Ho + Y) * Wo + X, C4, c, acc);
+            else out[((long)(b * Ho + Y) * Wo + X) * C4 + c] = acc;
+        }
+    }
+}
+
 // sum of the four PSP priors, each up-sampled bilinearly (align_corners=False) from its s x s map (s = 1,2,3,6) to h x w:
 // one pass writing the result once, instead of four read-modify-write passes over the [B,h,w,C] accumulator (pspnet.py:22).
 // One thread owns a column (b, ox, 4 channels) and walks down the h rows: the x-interpolated values  tx = lx0 * z[iy][ix0] +
@@ -745,6 +893,15 @@ extern "C" int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void*
     return ape_upconv3x3_gather_ex(z, bias, out, out_fmt, B, h, w, C, act, alpha, 0, stream);
 }
 
+static int g_upg_strip_rows = 30;       // output rows per workgroup of the strip walk; 0 = the row kernel for every channel count
+/* tuning / test hook: rows per strip (>= 1), 0 switches the strip walk off; returns the previous value */
+extern "C" int ape_upconv3x3_gather_strip_rows(int rows)
+{
+    const int old = g_upg_strip_rows;
+    if (rows >= 0) g_upg_strip_rows = rows;
+    return old;
+}
+
 /* ... and with the choice of the interpolation arithmetic: fma = 0 the separately rounded products of ape_bilinear_nhwc_f32, fma = 1 chained
  * fused multiply-adds (the unfused twin of ape_upconv3x3_fused_* built with fma = 1) */
 extern "C" int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act,
@@ -756,6 +913,18 @@ extern "C" int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* 
     if (total == 0) return APE_OK;
     const float sh = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sw = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    if (C % 64 == 0 && g_upg_strip_rows > 0) {          // the strip walk (256-byte channel slabs)
+        const int rows = g_upg_strip_rows;
+        const long gs = (long)B * ((2 * h + rows - 1) / rows) * ((2 * w + 15) / 16) * (C / 64);
+        if (gs >= (1L << 31)) return APE_EINVAL;
+#define APE_UPS_LAUNCH(S32O, FM)                                                                                                           \
+    hipLaunchKernelGGL((upconv_gather_strip_kernel<S32O, FM>), dim3((unsigned)gs), dim3(256), 0, (hipStream_t)stream, (const float4*)z,    \
+                       bias, (float4*)out, B, h, w, C / 4, sh, sw, act, alpha, rows)
+        if (out_fmt == APE_FMT_S32) { if (fma) APE_UPS_LAUNCH(true, true); else APE_UPS_LAUNCH(true, false); }
+        else { if (fma) APE_UPS_LAUNCH(false, true); else APE_UPS_LAUNCH(false, false); }
+#undef APE_UPS_LAUNCH
+        return ape::check_launch("ape_upconv3x3_gather_f32");
+    }
     const long g = (long)B * 2 * h * ((2 * w + 15) / 16);
     if (g >= (1L << 31)) return APE_EINVAL;
     const size_t lds = (size_t)3 * kUpCols * (C / 4) * sizeof(float4);

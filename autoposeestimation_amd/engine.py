@@ -498,7 +498,8 @@ class UpConv:
     def _gather(self, z, out_fmt):
         b, h, w, _ = z.shape
         out = torch.empty(b, 2 * h, 2 * w, self.cout, dtype=torch.float32, device=z.device)
-        glabel = "upconv_gather_kernel<%s,%s>" % ("true" if out_fmt == FMT_S32 else "false", "true" if self.fma else "false")
+        strip = self.cout % 64 == 0 and _lib.lib().ape_upconv3x3_gather_strip_rows(-1) > 0      # the library's own routing rule
+        glabel = "upconv_gather_%skernel<%s,%s>" % ("strip_" if strip else "", "true" if out_fmt == FMT_S32 else "false", "true" if self.fma else "false")
         e0 = _prof_begin(glabel)
         rc = _lib.lib().ape_upconv3x3_gather_ex(_lib.dptr(z, torch.float32), _lib.dptr(self.bias), _lib.dptr(out), out_fmt, b, h, w,
                                                 self.cout, ACT_PRELU, self.alpha, int(self.fma), _st())

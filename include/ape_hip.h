@@ -127,6 +127,11 @@ int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int o
  * ape_upconv3x3_fused_* called with fma = 1 */
 int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act, float alpha,
                             int fma, void* stream);
+/* Channel counts that are multiples of 64 take a second kernel with the same arithmetic (bit-identical outputs): strips of `rows` output
+ * rows per workgroup, the z rows of every tap held in registers while the strip moves down (each z element is loaded ~1.2x instead of
+ * ~5x).  rows >= 1 sets the strip height (default 30), 0 routes every call to the one-row kernel, < 0 only queries; returns the
+ * previous value.  A process-wide tuning / test switch, not per stream. */
+int ape_upconv3x3_gather_strip_rows(int rows);
 /* PSPUpsample with 64 output channels (DenseFusion/lib/pspnet.py:27-37: nn.Upsample x2 align_corners=True -> Conv2d 3x3 pad 1 -> PReLU;
  * up_2 and up_3 of pspnet.py:50-51) as ONE kernel on an S32 input x[B][h][w][Cin] (Cin = 64): the low-resolution channel mixing
  * z = W9 . x (W9 S32K [9*64][Cin], row = tap*64 + co, as ape_upconv3x3_gather_f32 expects) runs on the matrix cores for the 10 x 16

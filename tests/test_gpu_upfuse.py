@@ -118,3 +118,34 @@ def test_unsupported_geometries_are_refused():
         up(x, fused=True)
     assert up(x).shape == (1, 16, 16, 64)
     assert E.UpConv(torch.randn(64, 64, 3, 3), torch.zeros(64), 0.1, precision="f32").fusable(E.S32.from_f32(x)) is False
+
+
+@pytest.mark.parametrize("b,h,w,c", [(1, 1, 1, 64), (2, 5, 7, 64), (1, 8, 8, 128), (2, 17, 9, 64), (1, 33, 61, 256), (3, 24, 40, 64), (1, 60, 80, 256)])
+@pytest.mark.parametrize("fma", [0, 1])
+@pytest.mark.parametrize("out_s32", [False, True])
+def test_strip_gather_equals_the_row_gather_bitwise(b, h, w, c, fma, out_s32):
+    """ape_upconv3x3_gather_ex's two kernels (csrc/ops.hip): the strip walk (C % 64 == 0: z rows held in registers while a workgroup moves
+    down the image) against the one-row kernel, bit for bit -- both arithmetics, both output formats, strips of 1, 2, 7 and 30 rows and one
+    strip taller than the image (the row-pair hand-over at every parity, the first / last rows' clamps, ragged last strips and columns)"""
+    from autoposeestimation_amd import _lib, engine as E
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(7 * h + w + c)
+    z = torch.randn(b, h, w, 9 * c, generator=g).cuda()
+    bias = torch.randn(c, generator=g).cuda()
+    fmt = E.FMT_S32 if out_s32 else E.FMT_F32
+
+    def run(rows):
+        old = lib.ape_upconv3x3_gather_strip_rows(rows)
+        try:
+            out = torch.full((b, 2 * h, 2 * w, c), float("nan"), dtype=torch.float32, device="cuda")
+            rc = lib.ape_upconv3x3_gather_ex(_lib.dptr(z), _lib.dptr(bias), _lib.dptr(out), fmt, b, h, w, c, E.ACT_PRELU, 0.25, fma, _lib.stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            return out.view(torch.int32)
+        finally:
+            lib.ape_upconv3x3_gather_strip_rows(old)
+
+    want = run(0)
+    for rows in (1, 2, 7, 30, 1000):
+        assert torch.equal(run(rows), want), rows
+    assert lib.ape_upconv3x3_gather_strip_rows(-1) == 30            # the default is back
