@@ -10,6 +10,8 @@
 // Each is one pass over its input (algorithmic bytes = bytes read + bytes written once); grids are sized to
 // >= 2048 workgroups-worth of work and grid-stride the rest.
 #include "common.h"
+#include <map>
+#include <mutex>
 #include "s32.h"
 
 namespace {
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
     const long rs = (long)w * 9 * C4;                   // float4 per low-resolution row of z
     const float4* zc = z + (long)b * h * rs + (long)(ix_lo + (p1 ? hi4 : 0)) * 9 * C4 + c;
     float4 v0[3][3], v1[3][3];                          // [ky][kx]: the held row pair of every tap
-    int hy0[3] = {-1, -1, -1}, hy1[3] = {-1, -1, -1};
+    int hy0[3];
     // phase 2 role: output column X0 + hi4
     const int X = X0 + hi4;
     const bool p2 = X < Wo;
@@ -546,93 +548,114 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = make_float4(bias[c * 4], bias[c * 4 + 1], bias[c * 4 + 2], bias[c * 4 + 3]);
 
-    auto window = [&](int Y) {                          // make the registers hold the row pairs of output row Y
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int qy = Y + ky - 1;
-            const float fy = sh * (float)((unsigned)qy < (unsigned)Ho ? qy : 0);
-            const int iy0 = (int)fy, iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
-            if (iy0 == hy0[ky]) continue;
-            if (p1) {
-                if (iy0 == hy1[ky]) {
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) v0[ky][kx] = v1[ky][kx];
-                } else {
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) v0[ky][kx] = zc[(long)iy0 * rs + (ky * 3 + kx) * C4];
-                }
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) v1[ky][kx] = zc[(long)iy1 * rs + (ky * 3 + kx) * C4];
-            }
-            hy0[ky] = iy0; hy1[ky] = iy1;
-        }
-    };
-    window(Ys);
-    for (int Y = Ys; Y < Ye; ++Y) {
-        float4* Sb = S[Y & 1];
-        if (p1) {
-            float ly0[3], ly1[3];
-            bool yok[3];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int qy = Y + ky - 1;
-                yok[ky] = (unsigned)qy < (unsigned)Ho;
-                const float fy = sh * (float)(yok[ky] ? qy : 0);
-                ly1[ky] = fy - (float)(int)fy;
-                ly0[ky] = 1.f - ly1[ky];
-            }
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    if (!yok[ky]) continue;
-                    const float4 a0 = v0[ky][kx], a1 = v1[ky][kx];
-                    if (FMA) {
-                        acc.x = fmaf(ly1[ky], a1.x, fmaf(ly0[ky], a0.x, acc.x));
-                        acc.y = fmaf(ly1[ky], a1.y, fmaf(ly0[ky], a0.y, acc.y));
-                        acc.z = fmaf(ly1[ky], a1.z, fmaf(ly0[ky], a0.z, acc.z));
-                        acc.w = fmaf(ly1[ky], a1.w, fmaf(ly0[ky], a0.w, acc.w));
-                        continue;
-                    }
-                    acc.x += ly0[ky] * a0.x + ly1[ky] * a1.x;
-                    acc.y += ly0[ky] * a0.y + ly1[ky] * a1.y;
-                    acc.z += ly0[ky] * a0.z + ly1[ky] * a1.z;
-                    acc.w += ly0[ky] * a0.w + ly1[ky] * a1.w;
-                }
-                Sb[(kx * kUpCols + hi4) * 16 + c4] = acc;
-            }
-        }
-        if (Y + 1 < Ye) window(Y + 1);                  // the next row's new z rows: in flight during the x interpolation below
-        __syncthreads();
-        if (p2) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                if (!xok[kx]) continue;
-                const float4 s0 = Sb[so0[kx]], s1 = Sb[so1[kx]];
-                if (FMA) {
-                    acc.x = fmaf(lx1[kx], s1.x, fmaf(lx0[kx], s0.x, acc.x));
-                    acc.y = fmaf(lx1[kx], s1.y, fmaf(lx0[kx], s0.y, acc.y));
-                    acc.z = fmaf(lx1[kx], s1.z, fmaf(lx0[kx], s0.z, acc.z));
-                    acc.w = fmaf(lx1[kx], s1.w, fmaf(lx0[kx], s0.w, acc.w));
-                    continue;
-                }
-                acc.x += lx0[kx] * s0.x + lx1[kx] * s1.x;
-                acc.y += lx0[kx] * s0.y + lx1[kx] * s1.y;
-                acc.z += lx0[kx] * s0.z + lx1[kx] * s1.z;
-                acc.w += lx0[kx] * s0.w + lx1[kx] * s1.w;
-            }
-            if (bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
-            if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-            else if (act == APE_ACT_PRELU) {
-                acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;
-                acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;
-            }
-            if (S32OUT) ape::s32_store4(out, (long)(b * Ho + Y) * Wo + X, C4, c, acc);
-            else out[((long)(b * Ho + Y) * Wo + X) * C4 + c] = acc;
-        }
+    // ---- the window of z rows ------------------------------------------------------------------------------------------------------
+    // hy0[ky]: the upper row of the pair tap row ky holds.  ADVANCE(ky, YY): make the pair fit output row YY, assuming (host-checked floor
+    // pattern, ape_upconv3x3_gather_ex) it either stays or moves down by one: v0 <- keep ? v0 : v1 (a select on a scalar condition, no
+    // branch), v1 <- the pair's lower row, loaded unconditionally (the same row again when the pair stays: first rows of the image, last
+    // row's clamp).  Which tap row advances when is static: q = Y + ky - 1 and the upper row changes when q turns odd, so ky = 1 advances
+    // on the way to an odd Y, ky = 0 and 2 on the way to an even one -- strips start on even rows.
+#define APE_UPS_ROWS(YY, ky, iy0, iy1)                                                                                                     \
+    const int qy_##ky = (YY) + (ky) - 1;                                                                                                   \
+    const int iy0 = __builtin_amdgcn_readfirstlane((int)(sh * (float)((unsigned)qy_##ky < (unsigned)Ho ? qy_##ky : 0)));                   \
+    const int iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
+#define APE_UPS_ADVANCE(YY, ky)                                                                                                            \
+    {                                                                                                                                      \
+        APE_UPS_ROWS(YY, ky, iy0, iy1)                                                                                                     \
+        const bool keep = iy0 == hy0[ky];                                                                                                  \
+        const float4* zr1 = zc + (long)iy1 * rs + (ky) * 3 * C4;                                                                           \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                                                 \
+            v0[ky][kx].x = keep ? v0[ky][kx].x : v1[ky][kx].x; v0[ky][kx].y = keep ? v0[ky][kx].y : v1[ky][kx].y;                          \
+            v0[ky][kx].z = keep ? v0[ky][kx].z : v1[ky][kx].z; v0[ky][kx].w = keep ? v0[ky][kx].w : v1[ky][kx].w;                          \
+            v1[ky][kx] = zr1[kx * C4];                                                                                                     \
+        }                                                                                                                                  \
+        hy0[ky] = iy0;                                                                                                                     \
     }
+#define APE_UPS_INIT(YY, ky)                                                                                                               \
+    {                                                                                                                                      \
+        APE_UPS_ROWS(YY, ky, iy0, iy1)                                                                                                     \
+        const float4* zr0 = zc + (long)iy0 * rs + (ky) * 3 * C4;                                                                           \
+        const float4* zr1 = zc + (long)iy1 * rs + (ky) * 3 * C4;                                                                           \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) { v0[ky][kx] = zr0[kx * C4]; v1[ky][kx] = zr1[kx * C4]; }                         \
+        hy0[ky] = iy0;                                                                                                                     \
+    }
+    // S_kx of output row YY from the window -> LDS buffer Sb
+#define APE_UPS_PHASE1(YY, Sb)                                                                                                             \
+    {                                                                                                                                      \
+        float ly0[3], ly1[3];                                                                                                              \
+        bool yok[3];                                                                                                                       \
+        _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                                                 \
+            const int qy = (YY) + ky - 1;                                                                                                  \
+            yok[ky] = (unsigned)qy < (unsigned)Ho;                                                                                         \
+            const float fy = sh * (float)(yok[ky] ? qy : 0);                                                                               \
+            ly1[ky] = fy - (float)(int)fy;                                                                                                 \
+            ly0[ky] = 1.f - ly1[ky];                                                                                                       \
+        }                                                                                                                                  \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                                                 \
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                                                  \
+            _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                                             \
+                if (!yok[ky]) continue;                                                                                                    \
+                const float4 a0 = v0[ky][kx], a1 = v1[ky][kx];                                                                             \
+                if (FMA) {                                                                                                                 \
+                    acc.x = fmaf(ly1[ky], a1.x, fmaf(ly0[ky], a0.x, acc.x));                                                               \
+                    acc.y = fmaf(ly1[ky], a1.y, fmaf(ly0[ky], a0.y, acc.y));                                                               \
+                    acc.z = fmaf(ly1[ky], a1.z, fmaf(ly0[ky], a0.z, acc.z));                                                               \
+                    acc.w = fmaf(ly1[ky], a1.w, fmaf(ly0[ky], a0.w, acc.w));                                                               \
+                    continue;                                                                                                              \
+                }                                                                                                                          \
+                acc.x += ly0[ky] * a0.x + ly1[ky] * a1.x;                                                                                  \
+                acc.y += ly0[ky] * a0.y + ly1[ky] * a1.y;                                                                                  \
+                acc.z += ly0[ky] * a0.z + ly1[ky] * a1.z;                                                                                  \
+                acc.w += ly0[ky] * a0.w + ly1[ky] * a1.w;                                                                                  \
+            }                                                                                                                              \
+            if (p1) (Sb)[(kx * kUpCols + hi4) * 16 + c4] = acc;                                                                            \
+        }                                                                                                                                  \
+    }
+    // the x interpolation, epilogue and store of output row YY from LDS buffer Sb
+#define APE_UPS_PHASE2(YY, Sb)                                                                                                             \
+    if (p2) {                                                                                                                              \
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                                                      \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                                                 \
+            if (!xok[kx]) continue;                                                                                                        \
+            const float4 s0 = (Sb)[so0[kx]], s1 = (Sb)[so1[kx]];                                                                           \
+            if (FMA) {                                                                                                                     \
+                acc.x = fmaf(lx1[kx], s1.x, fmaf(lx0[kx], s0.x, acc.x));                                                                   \
+                acc.y = fmaf(lx1[kx], s1.y, fmaf(lx0[kx], s0.y, acc.y));                                                                   \
+                acc.z = fmaf(lx1[kx], s1.z, fmaf(lx0[kx], s0.z, acc.z));                                                                   \
+                acc.w = fmaf(lx1[kx], s1.w, fmaf(lx0[kx], s0.w, acc.w));                                                                   \
+                continue;                                                                                                                  \
+            }                                                                                                                              \
+            acc.x += lx0[kx] * s0.x + lx1[kx] * s1.x;                                                                                      \
+            acc.y += lx0[kx] * s0.y + lx1[kx] * s1.y;                                                                                      \
+            acc.z += lx0[kx] * s0.z + lx1[kx] * s1.z;                                                                                      \
+            acc.w += lx0[kx] * s0.w + lx1[kx] * s1.w;                                                                                      \
+        }                                                                                                                                  \
+        if (bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }                                                          \
+        if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); } \
+        else if (act == APE_ACT_PRELU) {                                                                                                   \
+            acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;                                      \
+            acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;                                      \
+        }                                                                                                                                  \
+        if (S32OUT) ape::s32_store4(out, (long)(b * Ho + (YY)) * Wo + X, C4, c, acc);                                                      \
+        else out[((long)(b * Ho + (YY)) * Wo + X) * C4 + c] = acc;                                                                         \
+    }
+
+    APE_UPS_INIT(Ys, 0) APE_UPS_INIT(Ys, 1) APE_UPS_INIT(Ys, 2)
+    for (int Y = Ys; Y < Ye; Y += 2) {                  // Ys even, rows even, Ho even: whole pairs
+        APE_UPS_PHASE1(Y, S[0])
+        APE_UPS_ADVANCE(Y + 1, 1)                       // the odd row's new z row: in flight during the x interpolation below
+        __syncthreads();
+        APE_UPS_PHASE2(Y, S[0])
+        APE_UPS_PHASE1(Y + 1, S[1])
+        APE_UPS_ADVANCE(Y + 2, 0)
+        APE_UPS_ADVANCE(Y + 2, 2)
+        __syncthreads();
+        APE_UPS_PHASE2(Y + 1, S[1])
+    }
+#undef APE_UPS_ROWS
+#undef APE_UPS_ADVANCE
+#undef APE_UPS_INIT
+#undef APE_UPS_PHASE1
+#undef APE_UPS_PHASE2
 }
 
 // sum of the four PSP priors, each up-sampled bilinearly (align_corners=False) from its s x s map (s = 1,2,3,6) to h x w:
@@ -893,6 +916,27 @@ extern "C" int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void*
     return ape_upconv3x3_gather_ex(z, bias, out, out_fmt, B, h, w, C, act, alpha, 0, stream);
 }
 
+// The strip kernel advances a tap's z row pair on a fixed schedule: the upper source row floor(sh * q) of up-sampled row q may change
+// only when q turns odd, and then by one.  True for the x2 align_corners scale in exact arithmetic; checked here in the kernel's own
+// float expression (cached per height).
+static bool strip_schedule_ok(int h, float sh)
+{
+    static std::mutex mu;
+    static std::map<int, bool> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(h);
+    if (it != seen.end()) return it->second;
+    bool ok = true;
+    int prev = (int)(sh * 0.f);
+    for (int q = 1; q < 2 * h && ok; ++q) {
+        const int cur = (int)(sh * (float)q);
+        ok = (q & 1) ? (cur == prev || cur == prev + 1) : cur == prev;
+        prev = cur;
+    }
+    seen[h] = ok;
+    return ok;
+}
+
 static int g_upg_strip_rows = 30;       // output rows per workgroup of the strip walk; 0 = the row kernel for every channel count
 /* tuning / test hook: rows per strip (>= 1), 0 switches the strip walk off; returns the previous value */
 extern "C" int ape_upconv3x3_gather_strip_rows(int rows)
@@ -913,8 +957,8 @@ extern "C" int ape_upconv3x3_gather_ex(const float* z, const float* bias, void* 
     if (total == 0) return APE_OK;
     const float sh = 2 * h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sw = 2 * w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    if (C % 64 == 0 && g_upg_strip_rows > 0) {          // the strip walk (256-byte channel slabs)
-        const int rows = g_upg_strip_rows;
+    if (C % 64 == 0 && g_upg_strip_rows > 0 && strip_schedule_ok(h, sh)) {          // the strip walk (256-byte channel slabs)
+        const int rows = (g_upg_strip_rows + 1) & ~1;   // whole row pairs
         const long gs = (long)B * ((2 * h + rows - 1) / rows) * ((2 * w + 15) / 16) * (C / 64);
         if (gs >= (1L << 31)) return APE_EINVAL;
 #define APE_UPS_LAUNCH(S32O, FM)                                                                                                           \
