@@ -151,21 +151,55 @@ def synthetic_frame(frame_id, cls=1, box=(150, 250), size=(150, 150), h=480, w=6
     Background: uniform noise in [96,160); depth: plane at 600 mm, object 80 mm closer with a
     smooth bump, 2 % of all pixels invalid (0).
     """
+    return synthetic_frame_multi(frame_id, [(cls, box, size)], h, w)
+
+
+def synthetic_frame_multi(frame_id, objects, h=480, w=640):
+    """synthetic_frame with several painted boxes: objects = [(cls, (r0, c0), (rh, rw)), ...] (non-overlapping, distinct classes -- the
+    live path keeps one detection per class and frame, pipeline/utils.py:444-470).  One object gives exactly synthetic_frame's arrays
+    (same generator, same draw order: background, per object its colour jitter, then the invalid-depth mask)."""
     rng = np.random.default_rng(int(frame_id))
     rgb = rng.integers(96, 160, size=(h, w, 3), dtype=np.uint8)
-    r0, c0 = box
-    rh, rw = size
     label = np.zeros((h, w), np.uint8)
-    label[r0:r0 + rh, c0:c0 + rw] = cls
-    col = CLASS_COLOURS[(cls - 1) % len(CLASS_COLOURS)].astype(np.int16)
-    jitter = rng.integers(-12, 13, size=(rh, rw, 3), dtype=np.int16)
-    rgb[r0:r0 + rh, c0:c0 + rw] = np.clip(col + jitter, 0, 255).astype(np.uint8)
     depth = np.full((h, w), 600, np.uint16)
-    yy, xx = np.mgrid[0:rh, 0:rw]
-    bump = 40.0 * np.exp(-(((yy - rh / 2) / (rh / 3)) ** 2 + ((xx - rw / 2) / (rw / 3)) ** 2))
-    depth[r0:r0 + rh, c0:c0 + rw] = (520 - bump).astype(np.uint16)
+    for cls, (r0, c0), (rh, rw) in objects:
+        label[r0:r0 + rh, c0:c0 + rw] = cls
+        col = CLASS_COLOURS[(cls - 1) % len(CLASS_COLOURS)].astype(np.int16)
+        jitter = rng.integers(-12, 13, size=(rh, rw, 3), dtype=np.int16)
+        rgb[r0:r0 + rh, c0:c0 + rw] = np.clip(col + jitter, 0, 255).astype(np.uint8)
+        yy, xx = np.mgrid[0:rh, 0:rw]
+        bump = 40.0 * np.exp(-(((yy - rh / 2) / (rh / 3)) ** 2 + ((xx - rw / 2) / (rw / 3)) ** 2))
+        depth[r0:r0 + rh, c0:c0 + rw] = (520 - bump).astype(np.uint16)
     depth[rng.random((h, w)) < 0.02] = 0
     return rgb, depth, label
+
+
+# SURVEY.md 8d's crop sweep {80^2, 120x160, 160^2, 240^2, 320x400}: painted sizes that get_bbox (myDatasetAugmented/dataset.py:342-380) rounds
+# up to those crops
+MIXED_SIZES = ((70, 70), (110, 150), (150, 150), (230, 230), (310, 390))
+
+
+def mixed_frame(frame_id, h=480, w=640, margin=24):
+    """A frame of the `bench.py --mixed` sweep: 1-3 objects of distinct classes (1..3), sizes drawn from MIXED_SIZES, placed at random
+    without overlap (a draw that does not fit after 40 tries is dropped, so a frame holds at least its first object).  Seeded by
+    frame_id alone.  Returns (rgb, depth, label, objects)."""
+    rng = np.random.default_rng([4242, int(frame_id)])
+    n_obj = int(rng.integers(1, 4))
+    classes = rng.permutation(3)[:n_obj] + 1
+    placed = []
+    for cls in classes.tolist():
+        for _ in range(40):
+            rh, rw = MIXED_SIZES[int(rng.integers(0, len(MIXED_SIZES)))]
+            r0 = int(rng.integers(margin, h - margin - rh + 1)) if h - 2 * margin - rh >= 0 else -1
+            c0 = int(rng.integers(margin, w - margin - rw + 1)) if w - 2 * margin - rw >= 0 else -1
+            if r0 < 0 or c0 < 0:
+                continue
+            if all(r0 + rh + margin <= pr or pr + ph + margin <= r0 or c0 + rw + margin <= pc or pc + pw + margin <= c0
+                   for _, (pr, pc), (ph, pw) in placed):
+                placed.append((cls, (r0, c0), (rh, rw)))
+                break
+    rgb, depth, label = synthetic_frame_multi(900000 + int(frame_id), placed, h, w)
+    return rgb, depth, label, placed
 
 
 def model_cloud(cls, m=1000, seed=1234):

@@ -295,6 +295,102 @@ def parity_block(out, oracle_results, frames, seg_sd):
                     "ground-truth placement of the 1000-point 0.1 m-cube model cloud (eval_linemod.py:118-130), bar 1e-4 m"}
 
 
+def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence):
+    """`bench.py --mixed`: --batch frames per rank of synthetic.mixed_frame (1-3 objects, five painted sizes) through FramePipeline --
+    segmentation, components, then ONE pose-stage pass per distinct crop size of the batch (FramePipeline.poses' buckets) -- and one
+    all_gather of a [frames, 3, 8] result block per step.  Returns the `sweep` object (rank 0; None elsewhere)."""
+    from autoposeestimation_amd.pipeline.utils import FramePipeline
+    from autoposeestimation_amd.sharding import gather_results
+    n = args.batch
+    mframes = [S.mixed_frame(rank * 100003 + i) for i in range(n)]
+    rgb = torch.from_numpy(np.stack([f[0] for f in mframes])).to(device)
+    depth = torch.from_numpy(np.stack([f[1] for f in mframes])).to(device)
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap)
+
+    def tail(out):
+        with torch.cuda.stream(out.get("stream") or torch.cuda.current_stream()):
+            block = torch.zeros(n, 3, 8, dtype=torch.float32, device=device)
+            if out["objects"]:
+                o = np.asarray(out["objects"], dtype=np.int64)
+                first = np.searchsorted(o[:, 0], o[:, 0], side="left")          # objects are frame-major: slot = position within the frame
+                slot = np.arange(len(o)) - first
+                t = torch.from_numpy(np.stack([o[:, 0], slot, o[:, 1]])).pin_memory().to(device, non_blocking=True)
+                block[t[0], t[1], 0] = t[2].float()
+                block[t[0], t[1], 1:] = out["pose"].float()
+            out["gathered"] = gather_results(block, dist)
+        return out
+
+    def run(count, seed0):
+        out = None
+        n_obj = 0
+        if not args.overlap:
+            for i in range(count):
+                out = tail(pipe.run(rgb, depth, S.REALSENSE_META, seed=seed0 + i))
+                n_obj += len(out["objects"])
+            return out, n_obj
+        h = pipe.begin(rgb)
+        for i in range(count):
+            h_next = pipe.begin(rgb) if i + 1 < count else None
+            out = tail(pipe.finish(h, rgb, depth, S.REALSENSE_META, seed=seed0 + i))
+            n_obj += len(out["objects"])
+            h = h_next
+        return out, n_obj
+
+    run(2, 0)
+    fence()
+    t0 = time.perf_counter()
+    out, n_obj = run(args.mixed_steps, 2)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt, float(n_obj)], dtype=torch.float64, device=device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, n_obj = float(tmax[0]), int(round(float(t[1])))
+    if rank != 0:
+        return None
+    buckets, painted = {}, {}
+    for o in out["objects"]:
+        k = "%dx%d" % (o[3] - o[2], o[5] - o[4])
+        buckets[k] = buckets.get(k, 0) + 1
+    for f in mframes:
+        for _, _, (rh, rw) in f[3]:
+            painted["%dx%d" % (rh, rw)] = painted.get("%dx%d" % (rh, rw), 0) + 1
+    sweep = {"value": round(n * world * args.mixed_steps / dt, 2), "unit": "frames/s", "objects_per_s": round(n_obj / dt, 2),
+             "ms_per_step": round(dt / args.mixed_steps * 1e3, 3), "steps": args.mixed_steps, "frames_per_gpu_per_step": n,
+             "objects_per_step_rank0": len(out["objects"]), "objects_painted_rank0": sum(len(f[3]) for f in mframes),
+             "crop_buckets_last_step": dict(sorted(buckets.items())), "painted_sizes_rank0": dict(sorted(painted.items())),
+             "overlap": bool(args.overlap),
+             "note": "synthetic.mixed_frame: 1-3 painted objects of distinct classes per 640x480 frame, sizes drawn from {70x70, 110x150, 150x150, "
+                     "230x230, 310x390} (crops 80x80 .. 320x400, SURVEY.md 8d); one pose-stage pass per distinct crop size of the batch; run after "
+                     "the timed region, never part of `value`"}
+    if not args.no_cpu_baseline and world == 1:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import densefusion_oracle as O
+        if out.get("stream") is not None:
+            out["stream"].synchronize()
+        choose_h = out["choose"].cpu().numpy()
+        by_frame = {(o[0], CLASSES[o[1] - 1]): k for k, o in enumerate(out["objects"])}
+
+        def gpu_choose(fi, name, nz, cnt):
+            k = by_frame.get((fi, name))
+            if k is None:
+                return nz[(np.arange(cnt) * len(nz)) // cnt] if len(nz) > cnt else np.pad(nz, (0, cnt - len(nz)), "wrap")
+            return choose_h[k]
+
+        sample = list(range(min(8, n)))
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        with ThreadPoolExecutor(max_workers=min(8, len(sample))) as ex:
+            res = dict(zip(sample, ex.map(lambda i: O.full_prediction(mframes[i][0], mframes[i][1], S.REALSENSE_META, seg_sd, est_sd, ref_sd, CLASSES,
+                                                                       choose_fn=lambda name, nz, cnt: gpu_choose(i, name, nz, cnt)), sample)))
+        torch.set_num_threads(old_threads)
+        sweep["parity"] = parity_block(out, res, mframes, seg_sd)
+        sweep["parity"]["objects_checked"] = sum(len(r) for r in res.values())
+    return sweep
+
+
 def kernel_peak(label):
     """(bound, peak, unit) for a profiled kernel label"""
     if "upconv_gather" in label:
@@ -462,6 +558,11 @@ def main():
     ap.add_argument("--dump-launches", default="", help="write [[kernel label, layer shape], ...] of ONE step's profiled launches in launch order "
                     "(for tools/pmc_summary.py --shapes: per-shape HBM traffic from the rocprofv3 PMC passes; use with --no-overlap)")
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary `modes` leg (two steps of the exact-fp32 operand mode after the timed region)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="add a secondary `sweep` object to the line: --batch frames with 1-3 painted objects each, sizes drawn from SURVEY.md 8d's crop "
+                         "sweep {80x80, 120x160, 160x160, 240x240, 320x400}, through the same path (several crop-size buckets per step); run after the "
+                         "timed region, never part of `value`")
+    ap.add_argument("--mixed-steps", type=int, default=5)
     ap.add_argument("--seg-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--pose-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
@@ -663,6 +764,12 @@ def main():
         ref.set_precision(args.pose_precision)
         del pipe_f
 
+    # Secondary, AFTER the timed region (not part of `value`): what real frames look like (pipeline/utils.py:444-470, 522-561: every detected
+    # class of a frame gets its own crop, crops of one size go through the pose stage together) -- 1-3 objects per frame, five crop sizes.
+    sweep = None
+    if args.mixed:
+        sweep = mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence)
+
     if rank == 0:
         summ = prof.summary()
         by_shape = prof.summary(by_shape=True)
@@ -776,6 +883,8 @@ def main():
             "roofline": roofline,
             "modes": modes,
         }
+        if sweep is not None:
+            line["sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             if out.get("stream") is not None:
                 out["stream"].synchronize()

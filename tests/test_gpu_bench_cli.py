@@ -77,6 +77,25 @@ def test_frames_1024_line():
     assert p["adds_delta_m"] <= 1e-4
 
 
+def test_mixed_sweep_line():
+    """`--mixed`: frames with 1-3 objects and five crop sizes through the bucketed pose stage, as a secondary `sweep` object with its own
+    parity block; the primary fields stay what the default command prints"""
+    d = _run("--mixed", "--mixed-steps", "2", "--steps", "2", "--warmup", "2", "--baseline-frames", "16", "--no-modes")
+    _common(d, 2, 2)
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["crop_buckets_last_step"] == {"160x160": 64}
+    s = d["sweep"]
+    assert s["unit"] == "frames/s" and 0 < s["value"] < d["value"] * 1.2 and s["steps"] == 2 and s["frames_per_gpu_per_step"] == 64
+    assert s["objects_per_s"] >= s["value"]                           # at least one object per frame
+    painted = s["objects_painted_rank0"]
+    assert 64 <= painted <= 192 and abs(s["objects_per_step_rank0"] - painted) <= 0.1 * painted
+    assert len(s["crop_buckets_last_step"]) >= 4                     # several crop sizes in one step
+    assert sum(s["crop_buckets_last_step"].values()) == s["objects_per_step_rank0"]
+    p = s["parity"]
+    assert p["frames"] == 8 and p["objects_checked"] >= 8
+    assert p["max_dq"] <= 1e-4 and p["max_dt"] <= 1e-4 and p["mask_diff_px_outside_tie_band"] == 0 and p["objects_not_matched"] == 0
+    assert p["adds_delta_m"] <= 1e-4
+
+
 def test_label_line():
     d = _run("--workload", "label", "--steps", "1", "--warmup", "1")
     _common(d, 1, 1)
