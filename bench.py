@@ -391,6 +391,34 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
     return sweep
 
 
+def latency_leg(args, device, seg, est, ref, frame):
+    """`bench.py --latency`: the batch-1 live loop (main.py:517-553 -> pipeline/utils.py full_prediction): ONE frame already in HBM, one painted
+    object; per run the host clock from FramePipeline.run(...) to the pose in host memory (segmentation, components, the one D2H of the
+    detections, crop, PoseNet, 2 x refiner, pose D2H: ~140 dependent launches on one stream).  p50 / p99 / min over --latency-runs runs
+    behind 10 warm-up runs.  Rank 0 only (a latency, not a throughput: it does not aggregate over ranks)."""
+    from autoposeestimation_amd.pipeline.utils import FramePipeline
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
+    rgb = torch.from_numpy(frame[0][None]).to(device)
+    depth = torch.from_numpy(frame[1][None]).to(device)
+    for i in range(10):
+        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+        out["pose"].cpu()
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(args.latency_runs):
+        t0 = time.perf_counter()
+        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+        out["pose"].cpu()
+        ts.append(time.perf_counter() - t0)
+    ts = np.sort(np.asarray(ts)) * 1e3
+    pick = lambda q: float(ts[min(len(ts) - 1, int(np.ceil(q * len(ts))) - 1)])  # noqa: E731
+    return {"p50_ms": round(pick(0.50), 3), "p99_ms": round(pick(0.99), 3), "min_ms": round(float(ts[0]), 3), "mean_ms": round(float(ts.mean()), 3),
+            "runs": int(len(ts)), "objects": len(out["objects"]), "frames": 1,
+            "note": "one resident 640x480 frame, one object, batch 1, one stream, eager launches; host wall clock from FramePipeline.run() to the pose "
+                    "on the host (includes the detections' D2H sync in the middle and the pose D2H at the end); after the timed region, never part "
+                    "of `value`"}
+
+
 def kernel_peak(label):
     """(bound, peak, unit) for a profiled kernel label"""
     if "upconv_gather" in label:
@@ -563,6 +591,11 @@ def main():
                          "sweep {80x80, 120x160, 160x160, 240x240, 320x400}, through the same path (several crop-size buckets per step); run after the "
                          "timed region, never part of `value`")
     ap.add_argument("--mixed-steps", type=int, default=5)
+    ap.add_argument("--latency", action="store_true",
+                    help="add a secondary `latency` object: ONE resident 640x480 frame with one object through the whole path (what the reference's live "
+                         "loop does per frame, main.py:517-553), host wall clock from the call to the pose on the host, p50 / p99 over --latency-runs "
+                         "runs; after the timed region, never part of `value`")
+    ap.add_argument("--latency-runs", type=int, default=200)
     ap.add_argument("--seg-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--pose-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"])
     args = ap.parse_args()
@@ -770,6 +803,12 @@ def main():
     if args.mixed:
         sweep = mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence)
 
+    latency = None
+    if args.latency and rank == 0:
+        latency = latency_leg(args, device, seg, est, ref, frames[0])
+    if dist and args.latency:
+        dist.barrier()
+
     if rank == 0:
         summ = prof.summary()
         by_shape = prof.summary(by_shape=True)
@@ -885,6 +924,8 @@ def main():
         }
         if sweep is not None:
             line["sweep"] = sweep
+        if latency is not None:
+            line["latency"] = latency
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would idle at the barrier)
             if out.get("stream") is not None:
                 out["stream"].synchronize()

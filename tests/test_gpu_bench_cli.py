@@ -77,10 +77,12 @@ def test_frames_1024_line():
     assert p["adds_delta_m"] <= 1e-4
 
 
-def test_mixed_sweep_line():
-    """`--mixed`: frames with 1-3 objects and five crop sizes through the bucketed pose stage, as a secondary `sweep` object with its own
+def test_mixed_sweep_and_latency_line():
+    """`--latency`: one resident frame through the whole path, p50 / p99 of the host clock.  `--mixed`: frames with 1-3 objects and five crop sizes through the bucketed pose stage, as a secondary `sweep` object with its own
     parity block; the primary fields stay what the default command prints"""
-    d = _run("--mixed", "--mixed-steps", "2", "--steps", "2", "--warmup", "2", "--baseline-frames", "16", "--no-modes")
+    d = _run("--mixed", "--mixed-steps", "2", "--latency", "--latency-runs", "50", "--steps", "2", "--warmup", "2", "--baseline-frames", "16", "--no-modes")
+    lat = d["latency"]
+    assert lat["runs"] == 50 and lat["objects"] == 1 and 0 < lat["min_ms"] <= lat["p50_ms"] <= lat["p99_ms"] < 50
     _common(d, 2, 2)
     assert "configs[2]" in d["config"]["workload"] and d["config"]["crop_buckets_last_step"] == {"160x160": 64}
     s = d["sweep"]
