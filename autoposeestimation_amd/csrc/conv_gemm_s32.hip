@@ -456,7 +456,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vv[e] = sigm ? act_fn(vv[e], a.act, a.alpha) : ape::act_fast(vv[e], af);
-                if (ABL(64)) continue;               // (timing only: no stores)
+                if (ABL(256)) continue;              // (timing only: no stores)
                 if (a.out_fmt == APE_FMT_S32) {
                     const int cy = a.yoff + n;
                     char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;

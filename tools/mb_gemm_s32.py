@@ -23,7 +23,7 @@ for name, b, h, w, cin, cout in shapes:
     arms = {"conv_gemm (fp32 in)": lambda: conv(x, out=out), "gemm_s32 -> f32": lambda: conv(xs, out=out),
             "gemm_s32 -> s32": lambda: conv(xs, out=out, out_fmt=E.FMT_S32),
             "  k-rotation": dbg(16), "  no static priority": dbg(32), "  ablate: no DMA": dbg(1), "  ablate: no barrier": dbg(2), "  ablate: no DMA+bar": dbg(3), "  ablate: no MFMA": dbg(4),
-            "  ablate: no reads": dbg(8), "  ablate: no stores": dbg(64), "  ablate: MFMA only": dbg(1 | 2 | 8), "  ablate: no MFMA/reads": dbg(4 | 8)}
+            "  ablate: no reads": dbg(8), "  ablate: no stores": dbg(256), "  ablate: MFMA only": dbg(1 | 2 | 8), "  ablate: no MFMA/reads": dbg(4 | 8)}
     for f in arms.values():
         f()
     torch.cuda.synchronize()
