@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/ape_hip.h"
 
 namespace ape {
@@ -20,6 +21,31 @@ static inline int check_launch(const char* what)
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Per-(kernel, device) set-up of the kernels with more than 64 KB of dynamic LDS: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a
+// per-DEVICE property and so is the compute-unit count the persistent grids are sized from -- a process may drive several devices
+// (one `static DeviceOnce` per kernel instantiation; devices 0..63).  Returns APE_OK and the current device's CU count (256 if unknown).
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    int ncu[64];
+};
+static inline int device_once(DeviceOnce& s, const void* kernel, int lds_bytes, int* ncu_out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { set_last_error("hipGetDevice"); return APE_ELAUNCH; }
+    if (!((s.done.load(std::memory_order_acquire) >> dev) & 1ULL)) {
+        if (lds_bytes > 0 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+            set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            return APE_ELAUNCH;
+        }
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        s.ncu[dev] = n;
+        s.done.fetch_or(1ULL << dev, std::memory_order_release);
+    }
+    if (ncu_out) *ncu_out = s.ncu[dev];
+    return APE_OK;
+}
 
 #if defined(__HIPCC__)
 // APE_ACT_NONE / RELU / PRELU without control flow: v > 0 ? v : (slope * v) & keep, slope = 1 / 1 / alpha, keep = ~0 / 0 / ~0 (RELU's

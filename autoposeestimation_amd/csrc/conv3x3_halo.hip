@@ -539,14 +539,8 @@ int launch_halo(const HaloArgs& a, hipStream_t st)
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!UPS || D == 1, "fused up-sampling is built for the d = 1 kernel");
     auto kern = conv3x3_halo_kernel<NSPLIT, D, BNH, UPS, HEAD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-            return APE_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static ape::DeviceOnce once;       // (per kernel instantiation)
+    if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), (int)lds, nullptr)) return rc;
     const int grid = a.p.B * a.tiles_x * a.tiles_y * a.n_tiles;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(halo_threads(BNH)), lds, st, a);
     return ape::check_launch("ape_conv3x3_halo_bf16");

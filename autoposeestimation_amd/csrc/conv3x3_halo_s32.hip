@@ -517,23 +517,13 @@ template <int D>
 int launch_halo_s32(const HaloS32Args& a, hipStream_t st)
 {
     auto kern = halo_s32_kernel<D>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-            return APE_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static ape::DeviceOnce once;       // (per kernel instantiation)
+    int ncu = 256;
+    if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), LDS_BYTES, &ncu)) return rc;
     // one workgroup fills a CU (160 KB of LDS, 8 waves x 256 registers): launch one per CU and let each walk its share of the tiles.
     // The walk keeps a workgroup on ONE channel tile (its weight descriptor is built once) when the tile stride grid / 8 is a multiple
     // of n_tiles; otherwise, and for grids smaller than the chip, every tile gets its own workgroup as before.
     const int nwg = a.B * a.tiles_x * a.tiles_y * a.n_tiles;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
-    }
     int grid = nwg;
     const int unit = 8 * a.n_tiles;
     if (!(a.dbg & 2) && nwg > ncu && ncu >= unit && (a.Cin / 32) % 2 == 0) grid = (ncu / unit) * unit;    // (kernel: a tile ends on an even chunk)

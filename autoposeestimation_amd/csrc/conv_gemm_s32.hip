@@ -506,25 +506,14 @@ int launch_s32_res(GemmS32Args& a, hipStream_t st)
 {
     constexpr size_t lds = 3 * (size_t)A_STAGE + 2 * (size_t)BN * 128;
     auto kern = RES ? gemm_s32_res_kernel<BN> : gemm_s32_kernel<BN>;
-    static bool attr_set = false;      // (one per instantiation of this function, i.e. per kernel)
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-            return APE_ELAUNCH;
-        }
-        attr_set = true;
-    }
+    static ape::DeviceOnce once;       // (one per instantiation of this function, i.e. per kernel)
+    int ncu_dev = 0;
+    if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), (int)lds, &ncu_dev)) return rc;
     a.m_tiles = ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.Cout, BN);
     // persistent walk (one workgroup per CU) where the k-tile stream can run through the tile boundary: an even number of k-tiles (the
     // weight stage parity repeats) and at least four (the look-ahead of three stays inside one tile); dbg bit 64: one tile per workgroup
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { ape::set_last_error("hipGetDeviceProperties"); return APE_ELAUNCH; }
-        ncu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-    }
+    const int ncu = ncu_dev > 8 ? ncu_dev / 8 * 8 : 8;
     const int tiles = a.m_tiles * a.n_tiles;
     const bool walk = !RES && !(a.dbg & 64) && a.nk >= 4 && a.nk % 2 == 0 && tiles > ncu;
     hipLaunchKernelGGL(kern, dim3(walk ? ncu : tiles), dim3(512), lds, st, a);

@@ -594,23 +594,11 @@ template <int G, bool HEAD, bool FMA>
 int launch_fused(const UpFuseArgs& a, hipStream_t st)
 {
     auto kern = upconv_fused_kernel<G, HEAD, FMA>;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    static unsigned long long attr_set = 0;      // one bit per device (the attribute is per device, not per process)
-    static int ncu_of[64];
-    const int di = dev & 63;
-    if (!((attr_set >> di) & 1ull)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(G)) != hipSuccess) {
-            ape::set_last_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-            return APE_ELAUNCH;
-        }
-        int ncu = 0;
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
-        ncu_of[di] = ncu;
-        attr_set |= 1ull << di;
-    }
+    static ape::DeviceOnce once;       // (per kernel instantiation)
+    int ncu = 256;
+    if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), lds_bytes(G), &ncu)) return rc;
     const long nt = (long)a.B * a.tiles_x * a.tiles_y;
-    int grid = (int)(nt < ncu_of[di] ? nt : ncu_of[di]);
+    int grid = (int)(nt < ncu ? nt : ncu);
     if (grid > 8) grid -= grid % 8;             // whole XCD rounds: dispatch id % 8 labels a workgroup's XCD for every tile it walks
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes(G), st, a);
     return ape::check_launch("ape_upconv3x3_fused");
