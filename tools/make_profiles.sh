@@ -22,6 +22,7 @@ python tools/prof_summary.py $O/prof_def/*/*_kernel_trace.csv --steps 3 --warmup
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes --dump-launches $O/launches.json > $O/pmc_fetch.log 2>&1 || exit 1
 $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes > $O/pmc_write.log 2>&1 || exit 1
 python tools/pmc_summary.py $O/pmc_fetch/*/*_counter_collection.csv $O/pmc_write/*/*_counter_collection.csv --shapes $O/launches.json > $O/${R}_pmc_traffic.json || exit 1
+cp $O/${R}_pmc_traffic.json profiles/      # (this box's copy of the tree: step 6's bench line reads its `traffic` fields from the newest profiles/*_pmc_traffic.json)
 # 4. matrix-pipe / vector / LDS counters of the largest kernels
 $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_util -- python3 tools/pmc_big3.py > $O/pmc_util.log 2>&1 || exit 1
 python tools/pmc_big3.py --reduce $O/pmc_util/*/*_counter_collection.csv > $O/${R}_pmc_utilisation.txt || exit 1
