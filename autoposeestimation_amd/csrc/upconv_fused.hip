@@ -113,7 +113,10 @@ __device__ __forceinline__ void dma_piece(unsigned voff, const i32x4& rs, unsign
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+    // (s_nop 4 first: hipcc may reload a spilled SGPR operand -- v_readlane, a VALU write of an SGPR -- right in front of the statement, and a
+    // vector-memory instruction that reads such an SGPR is owed five wait states, which hipcc pays for its own instructions only.  Found in the
+    // streamed experiment of this kernel (branch exp/upfuse-streamed), where a weight read took a stale offset that way, deterministically.)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
 #endif
 }
