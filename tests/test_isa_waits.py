@@ -86,3 +86,23 @@ toy:
     # still pending on the branch-taken path (line 14); barrier behind the DMA (line 16)
     assert kinds == ["barrier behind an un-waited LDS-DMA", "ds_read result used before its wait", "ds_read result used before its wait"], r["findings"]
     assert lines == [7, 14, 16], r["findings"]
+
+
+def test_inline_asm_vector_memory_reads_no_freshly_reloaded_sgpr(audit_mod, tmp_path_factory):
+    """upconv_fused.hip issues its LDS-DMA from an asm statement (hipcc must not know of the transfer).  hipcc reloads spilled SGPRs with
+    v_readlane right in front of whatever uses them -- and owes a vector-memory instruction that reads such an SGPR five wait states, which it
+    inserts for its own instructions only.  Every shipped variant has such reloads in front of DMA statements; the statement therefore
+    starts with `s_nop 4`.  This walks the ISA of every variant and fails if a descriptor / offset SGPR of an asm buffer load was written by
+    a VALU instruction fewer than five wait states earlier."""
+    out = os.path.join(REPO, "autoposeestimation_amd", "csrc", "build", "isa_audit")
+    asm = audit_mod.compile_to_asm(os.path.join(REPO, "autoposeestimation_amd", "csrc", "upconv_fused.hip"), out)
+    syms = [s for s in audit_mod.kernel_symbols(asm) if "upconv_fused_kernel" in s]
+    assert len(syms) == 4
+    for sym in syms:
+        assert audit_mod.sgpr_vmem_hazards(asm, sym) == [], sym
+    # the walk sees the pattern it is looking for (a reload two instructions in front of the load) and accepts five wait states
+    probe = os.path.join(str(tmp_path_factory.mktemp("isa")), "probe.s")
+    open(probe, "w").write("\nk1:\n\tv_readlane_b32 s37, v9, 3\n\ts_mov_b32 m0, s6\n\tbuffer_load_dwordx4 v1, s[36:39], 0 offen lds\n\ts_endpgm\n"
+                           "\nk2:\n\tv_readlane_b32 s2, v9, 3\n\ts_nop 4\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen offset:64\n\ts_endpgm\n"
+                           "\nk3:\n\tv_readlane_b32 s2, v9, 3\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen\n\ts_endpgm\n")
+    assert len(audit_mod.sgpr_vmem_hazards(probe, "k1")) == 1 and audit_mod.sgpr_vmem_hazards(probe, "k2") == [] and len(audit_mod.sgpr_vmem_hazards(probe, "k3")) == 1

@@ -284,3 +284,37 @@ if __name__ == "__main__":
             print("   FINDING:", f)
         for f in r["candidates"][:5]:
             print("   candidate (pass 2, pessimistic merge):", f)
+
+
+def sgpr_vmem_hazards(asm_path, symbol, wait_states=5):
+    """Inline-asm vector-memory instructions (hipcc's hazard recognizer does not look inside asm statements): an LDS-DMA / buffer load that
+    reads an SGPR -- its descriptor quad or its scalar offset -- written by a VALU instruction (`v_readlane` / `v_readfirstlane`: how hipcc
+    reloads SPILLED SGPRs, wherever the next use is) fewer than `wait_states` wait states earlier reads a stale value.  Linear walk back
+    from every `buffer_load ... offen` of the kernel (a label ends the walk: nothing is claimed across it).  -> [(line, instruction, writer)]"""
+    text = open(asm_path).read()
+    start = text.index("\n" + symbol + ":")
+    body = text[start:text.index("s_endpgm", start)].splitlines()
+    found = []
+    for i, line in enumerate(body):
+        t = line.strip()
+        m = re.match(r"buffer_load_dword\w* (?:v\[?[\d:]+\]?, )?v\d+, s\[(\d+):(\d+)\], (s\d+|\d+|0)", t)
+        if not m or "offen" not in t:
+            continue
+        reads = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        if m.group(3).startswith("s"):
+            reads.add(int(m.group(3)[1:]))
+        ws, j = 0, i - 1
+        while j >= 0 and ws < wait_states:
+            u = body[j].strip()
+            j -= 1
+            if not u or u.startswith(";") or u.startswith("."):
+                if u.startswith(".LBB"):
+                    break
+                continue
+            w = re.match(r"v_read(?:first)?lane_b32 s(\d+)", u)
+            if w and int(w.group(1)) in reads:
+                found.append((i + 1, t, u))
+                break
+            nop = re.match(r"s_nop (\d+)", u)
+            ws += int(nop.group(1)) + 1 if nop else 1
+    return found
