@@ -89,14 +89,29 @@ constexpr int lds_bytes(int G) { return xa_bytes(G) + xb_bytes(G) + SB_BYTES + H
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// APE_NO_ASM_MATH = 0 builds both interpolations from the hand-written two-channel instructions below (v_pk_fma_f32 / v_pk_mul_f32 with an
-// op_sel weight broadcast): 5 % faster at bench size (2.40 vs 2.53 ms), bit-identical on every test size -- and, at 2 x 480 x 640 and
-// above, rare whole 16-pixel groups with slightly wrong logits (tools/dbg_upfuse.py: 0..800 of 614 400 pixels per launch, load dependent,
-// head builds mostly).  Bisected to the asm statements (the same arithmetic written in C is right in every run); not to M0 handling, not to
-// the head's matrix-instruction chain, not to register re-use behind it (each tried).  hipcc's hazard recognizer does not look inside
-// asm statements, so some software-managed wait state around them is the suspect; until it is found the C form is the product.
+// Both interpolations are built from the hand-written two-channel instructions below (v_pk_fma_f32 / v_pk_mul_f32 with an op_sel weight
+// broadcast); APE_NO_ASM_MATH = 1 writes the same arithmetic in C (hipcc's SLP vectoriser then emits packed instructions of its own, with two
+// v_mov per broadcast in places: 1.5 % slower at bench size, same bits).
+//
+// THE BROADCAST OPERAND MUST BE src0.  Rounds 1-4 carried an intermittent fault here (and, with the same signature, in round 1's fused
+// up-sampling of conv3x3_halo.hip): with the weight pair as the SECOND source -- `v_pk_fma_f32 d, data, w, d op_sel:[0,1,0]` -- the LOW half of
+// the result is occasionally computed from a wrong weight in lanes 48-63.  Round 5 isolated it on the GPU (tools/stress_upfuse.py,
+// `make variant`): only the column interpolation (per-lane weights in a VGPR pair; the row interpolation's SGPR pairs are fine), only its
+// top-half instance, which a wave enters right after issuing its two LDS-DMA pieces, only waves 8-11 (the third wave of every SIMD: last at
+// the barrier, so it runs alone and issues back to back), only j = 3 / lanes 48-63 / the low half of a pair; 8 wait states in front of AND
+// behind every statement hide it, pads on one side do not; no matrix instruction is within 16 wait states of any statement
+// (tools/isa_audit.mfma_asm_hazards) and every LDS / vector-memory wait is in place.  What decides it is the operand slot alone: the same
+// instruction with the swizzled pair as src0 (`v_pk_fma_f32 d, w, data, d op_sel:[1,0,0]`, the form hipcc itself emits for every broadcast)
+// gave 0 wrong pixels in 600 stress launches where the src1 form fails in EVERY launch (2 x 240 x 320, non-fma head build: 10^3..10^4 pixels),
+// and without any op_sel (weights broadcast by v_mov) both operand orders are clean.  So: an op_sel / op_sel_hi broadcast of a VGPR pair in
+// the src1 slot of a packed-f32 instruction is not safe on gfx950 under back-to-back issue -- no LLVM hazard entry, no ISA-manual rule; kept
+// out of the tree by tests/test_isa_waits.py (tools/isa_audit.pk_src1_swizzles).  APE_ASM_SRC1_BCAST = 1 rebuilds the faulty form (the
+// audit's red case and tools/stress_upfuse.py's positive control; never the product).
 #ifndef APE_NO_ASM_MATH
-#define APE_NO_ASM_MATH 1
+#define APE_NO_ASM_MATH 0
+#endif
+#ifndef APE_ASM_SRC1_BCAST
+#define APE_ASM_SRC1_BCAST 0
 #endif
 #ifndef APE_NO_FAST_ROWS
 #define APE_NO_FAST_ROWS 0
@@ -132,20 +147,37 @@ __device__ __forceinline__ float lane_value(float v, int l)
 // bit for bit the scalar fmaf / multiply.  WC = "v" (a VGPR pair, the gather's per-lane weights) or "s" (an SGPR pair, the row weights).
 // The statements are VOLATILE on purpose: hipcc's hazard recognizer does not look inside an asm statement, and a register-only asm is free
 // to move above the `s_barrier` statement in front of it -- right behind the matrix instruction that produces its operand, inside the wait
-// states software owes between an MFMA's write and a vector read (seen as rare wrong pixels).  Volatile statements keep their order
-// against the barrier statements, which puts dozens of instructions between the last matrix instruction and the first read.
+// states software owes between an MFMA's write and a vector read.  Volatile statements keep their order against the barrier statements,
+// which puts dozens of instructions between the last matrix instruction and the first read (checked per build by
+// tools/isa_audit.mfma_asm_hazards).
 #if defined(__HIP_DEVICE_COMPILE__)
+#if APE_ASM_SRC1_BCAST
+// (the historic, FAULTY operand order: data src0, weight pair src1 -- see the note at APE_NO_ASM_MATH)
 #define APE_PK_OPS(SUF, WC, WT)                                                                                                            \
     __device__ __forceinline__ void pk_fma0_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                  \
-    { asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(v), WC(w)); }                                                     \
+    { asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(v), WC(w)); }                                           \
     __device__ __forceinline__ void pk_fma_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
-    { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d) : "v"(v), WC(w)); }                                                    \
+    { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(d) : "v"(v), WC(w)); }                                          \
     __device__ __forceinline__ void pk_fma_hi_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
-    { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(v), WC(w)); }                                     \
+    { asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(v), WC(w)); }                           \
     __device__ __forceinline__ f32x2 pk_mul_lo_##SUF(const f32x2 v, const WT w)                                                            \
-    { f32x2 d; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(v), WC(w)); return d; }                                       \
+    { f32x2 d; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(v), WC(w)); return d; }                             \
     __device__ __forceinline__ f32x2 pk_mul_hi_##SUF(const f32x2 v, const WT w)                                                            \
     { f32x2 d; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(v), WC(w)); return d; }
+#else
+// the weight pair is src0, the operand slot hipcc itself uses for a broadcast (products commute: bit for bit the same results)
+#define APE_PK_OPS(SUF, WC, WT)                                                                                                            \
+    __device__ __forceinline__ void pk_fma0_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                  \
+    { asm volatile("v_pk_fma_f32 %0, %2, %1, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(v), WC(w)); }                                           \
+    __device__ __forceinline__ void pk_fma_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
+    { asm volatile("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "v"(v), WC(w)); }                                          \
+    __device__ __forceinline__ void pk_fma_hi_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
+    { asm volatile("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(v), WC(w)); }                           \
+    __device__ __forceinline__ f32x2 pk_mul_lo_##SUF(const f32x2 v, const WT w)                                                            \
+    { f32x2 d; asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(v), WC(w)); return d; }                             \
+    __device__ __forceinline__ f32x2 pk_mul_hi_##SUF(const f32x2 v, const WT w)                                                            \
+    { f32x2 d; asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(v), WC(w)); return d; }
+#endif
 APE_PK_OPS(v, "v", f32x2)
 APE_PK_OPS(s, "s", unsigned long long)
 #undef APE_PK_OPS
@@ -535,6 +567,14 @@ __global__ __launch_bounds__(NW * 64) void upconv_fused_kernel(const UpFuseArgs 
                     a.label[pix] = (uint8_t)am;
                     a.score[pix] = pm;
                 }
+#ifdef APE_UPFUSE_DUMP
+                // diagnostic build only (tools/dump_upfuse.py): the activations the head consumed, [pixel][64] floats behind the stamps pointer
+                if (a.stamps && pix_ok) {
+                    float* dd = reinterpret_cast<float*>(a.stamps) + (((size_t)b * H2 + Y) * W2 + X) * 64;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(dd + 16 * j + 4 * g_fc) = xv[j];
+                }
+#endif
             }
         };
 

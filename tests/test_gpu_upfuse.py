@@ -149,3 +149,35 @@ def test_strip_gather_equals_the_row_gather_bitwise(b, h, w, c, fma, out_s32):
     for rows in (1, 2, 7, 30, 1000):
         assert torch.equal(run(rows), want), rows
     assert lib.ape_upconv3x3_gather_strip_rows(-1) == 30            # the default is back
+
+
+@pytest.mark.parametrize("shape,reps", [((2, 240, 320), 300), ((64, 240, 320), 50)])
+def test_fused_head_stress_beside_a_busy_stream(shape, reps):
+    """Back-to-back launches at bench-like sizes while a second stream keeps changing which compute units are free (the default bench runs
+    the pose stage beside the segmentor), every launch compared bit for bit with the three-call form.  This is the test that the historic
+    operand order of the hand-written interpolations (csrc/upconv_fused.hip, APE_ASM_SRC1_BCAST) fails in EVERY launch; the idle-GPU,
+    one-launch-per-size tests above never saw that fault."""
+    from autoposeestimation_amd import engine as E
+    b, h, w = shape
+    up, _, _ = _layer(True, seed=5)
+    xs = _input(b, h, w, seed=7)
+    g = torch.Generator().manual_seed(13)
+    hw = (torch.randn(13, 64, generator=g) / 8).cuda()
+    hb = torch.randn(13, generator=g).cuda()
+    want_l, want_s = up.seg_head(xs, hw, hb, True, fused=False)
+    want_a = up(xs, fused=False) if b <= 8 else None
+    conv = E.Conv(torch.randn(256, 256, 3, 3, generator=g) / 48, None, 1, 1, 1, E.ACT_RELU, precision="bf16x3")
+    xb = torch.randn(4, 60, 80, 256, generator=g).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(20 * reps):
+            conv(xb)
+    bad = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for _ in range(reps):
+        got_l, got_s = up.seg_head(xs, hw, hb, True, fused=True)
+        bad[0] += ((got_s != want_s) | (got_l != want_l)).sum()
+        if want_a is not None:
+            bad[1] += (up(xs, fused=True) != want_a).sum()
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0], "wrong head pixels / wrong activations over %d launches: %s" % (reps, bad.tolist())

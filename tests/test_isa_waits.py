@@ -106,3 +106,62 @@ def test_inline_asm_vector_memory_reads_no_freshly_reloaded_sgpr(audit_mod, tmp_
                            "\nk2:\n\tv_readlane_b32 s2, v9, 3\n\ts_nop 4\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen offset:64\n\ts_endpgm\n"
                            "\nk3:\n\tv_readlane_b32 s2, v9, 3\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen\n\ts_endpgm\n")
     assert len(audit_mod.sgpr_vmem_hazards(probe, "k1")) == 1 and audit_mod.sgpr_vmem_hazards(probe, "k2") == [] and len(audit_mod.sgpr_vmem_hazards(probe, "k3")) == 1
+
+
+
+def test_matrix_instruction_wait_states_around_asm_statements(audit_mod, tmp_path):
+    """hipcc pads the wait states software owes around matrix instructions for the instructions it emits itself, and treats an asm statement
+    neither as a vector nor as a matrix instruction: an MFMA result read (or overwritten) by an instruction inside an asm statement, an MFMA's
+    SrcC overwritten from inside one, or an asm vector instruction feeding an MFMA operand gets no pad.  Every kernel that mixes asm statements
+    with matrix instructions is walked over ALL control-flow paths (loop back-edges included): none may have such a pair inside the window."""
+    out_dir = os.path.join(REPO, "autoposeestimation_amd", "csrc", "build", "isa_audit")
+    for hip_file in sorted(KERNELS) + ["upconv_fused.hip"]:
+        asm = audit_mod.compile_to_asm(os.path.join(audit_mod.CSRC, hip_file), out_dir)
+        syms = audit_mod.kernel_symbols(asm)
+        assert syms
+        for sym in syms:
+            assert audit_mod.mfma_asm_hazards(asm, sym) == [], (hip_file, sym)
+    toy = tmp_path / "toy.s"
+    toy.write_text("""
+toy:
+	v_mfma_f32_16x16x32_bf16 v[20:23], v[4:7], v[8:11], v[20:23]
+	s_branch .LBB0_1
+.LBB0_1:
+	s_nop 1
+	;;#ASMSTART
+	v_pk_fma_f32 v[30:31], v[20:21], v[40:41], 0
+	;;#ASMEND
+	v_mfma_f32_16x16x32_bf16 v[60:63], v[4:7], v[8:11], v[64:67]
+	s_nop 4
+	;;#ASMSTART
+	v_max_f32 v64, v51, v52
+	v_max_f32 v50, v51, v52
+	;;#ASMEND
+	v_mfma_f32_16x16x4_f32 v[70:73], v50, v74, v[70:73]
+	v_mfma_f32_16x16x4_f32 v[70:73], v51, v74, v[70:73]
+	s_endpgm
+.Lfunc_end0:
+""")
+    kinds = sorted(h[4] for h in audit_mod.mfma_asm_hazards(str(toy), "toy"))
+    # the result read two states later across a block boundary; SrcC v[64:67] overwritten five states later (a 4-pass MFMA is owed eight);
+    # an MFMA operand written by the asm one state earlier; the accumulate chain itself is not a finding
+    assert kinds == ["MFMA SrcC read -> asm VALU write", "MFMA write -> asm access", "asm VALU write -> MFMA read"], kinds
+
+
+def test_packed_f32_broadcasts_sit_in_src0(audit_mod):
+    """csrc/upconv_fused.hip's interpolations are hand-written v_pk_fma_f32 / v_pk_mul_f32 with an op_sel weight broadcast.  With the weight
+    pair (a VGPR pair) as the SECOND source the low half of lanes 48-63 came out wrong under back-to-back issue -- rounds 1-4's "rare whole
+    16-pixel groups" (tools/stress_upfuse.py fails in every launch on that build); as src0 the same instruction is clean.  Green: no asm
+    statement of the product build swizzles a VGPR pair in src1 / src2.  Red: the audit flags the historic operand order."""
+    out = os.path.join(REPO, "autoposeestimation_amd", "csrc", "build", "isa_audit")
+    src = os.path.join(REPO, "autoposeestimation_amd", "csrc", "upconv_fused.hip")
+    asm = audit_mod.compile_to_asm(src, out)
+    syms = [s for s in audit_mod.kernel_symbols(asm) if "upconv_fused_kernel" in s]
+    assert len(syms) == 4
+    for sym in syms:
+        assert audit_mod.pk_src1_swizzles(asm, sym) == [], sym
+        n_pk = sum(1 for blk in audit_mod._parse_cfg_with_asm(asm, sym)[0] for _, t, ia in blk if ia and t.startswith("v_pk_"))
+        assert n_pk >= 100, (sym, n_pk)             # the walk saw the hand-written interpolations
+    old = audit_mod.compile_to_asm(src, out + "_src1", defs=("-DAPE_ASM_SRC1_BCAST=1",))
+    for sym in [s for s in audit_mod.kernel_symbols(old) if "upconv_fused_kernel" in s]:
+        assert len(audit_mod.pk_src1_swizzles(old, sym)) >= 50, sym

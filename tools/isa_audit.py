@@ -1,6 +1,8 @@
 """Static audit of the wait counters in a gfx950 kernel's ISA (`hipcc -save-temps` .s): the standing check behind the kernels whose hazards the
 compiler cannot see (inline-asm `ds_read_b128` whose results hipcc believes are ready at once, LDS-DMA `buffer_load ... lds` kept in flight
-across barriers behind hand-counted `s_waitcnt vmcnt(N)`).  Runs on the CPU (hipcc cross-compiles), used by tests/test_isa_waits.py.
+across barriers behind hand-counted `s_waitcnt vmcnt(N)`).  Runs on the CPU (hipcc cross-compiles), used by tests/test_isa_waits.py.  Beside the wait counters: wait states software owes around matrix
+instructions when one side of the pair is inside an asm statement (mfma_asm_hazards), VALU-written SGPRs in front of asm vector-memory
+instructions (sgpr_vmem_hazards) and the packed-f32 operand form that proved faulty on gfx950 (pk_src1_swizzles).
 
 Counter model (MI355X_MICROARCH.md "s_waitcnt"): vector-memory operations -- loads, stores, atomics, LDS-DMA -- retire in issue order on
 vmcnt; LDS operations retire in order on lgkmcnt; scalar-memory loads share lgkmcnt and may return out of order (with one pending only
@@ -21,15 +23,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-DAPE_NO_ABLATIONS"]     # ... without the kernels' timing-only ablation switches (wrong-result debug paths, e.g. "no barrier")
 
 
-def compile_to_asm(hip_file, out_dir):
-    """-> path of the gfx950 .s of `hip_file` (cached under out_dir while it is newer than the source and its headers)"""
+def compile_to_asm(hip_file, out_dir, defs=()):
+    """-> path of the gfx950 .s of `hip_file` (cached under out_dir while it is newer than the source and its headers); `defs`: extra -D
+    switches (give such a build its own out_dir)"""
     os.makedirs(out_dir, exist_ok=True)
     stem = os.path.splitext(os.path.basename(hip_file))[0]
     asm = os.path.join(out_dir, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
     deps = [hip_file] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [os.path.join(REPO, "include", "ape_hip.h")]
     if os.path.exists(asm) and all(os.path.getmtime(asm) >= os.path.getmtime(d) for d in deps):
         return asm
-    subprocess.check_call([HIPCC] + FLAGS + ["-save-temps", "-c", hip_file, "-I" + CSRC, "-o", os.path.join(out_dir, stem + ".o")], cwd=out_dir,
+    subprocess.check_call([HIPCC] + FLAGS + list(defs) + ["-save-temps", "-c", hip_file, "-I" + CSRC, "-o", os.path.join(out_dir, stem + ".o")], cwd=out_dir,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return asm
 
@@ -269,23 +272,6 @@ def audit(asm_path, symbol, max_findings=20):
             "meta": kernel_metadata(asm_path, symbol)}
 
 
-if __name__ == "__main__":
-    src = sys.argv[1]
-    pats = sys.argv[2:]
-    asm = src if src.endswith(".s") else compile_to_asm(os.path.join(CSRC, src) if not os.path.exists(src) else src, "/tmp/ape_isa_audit")
-    for sym in kernel_symbols(asm):
-        if pats and not any(p in sym for p in pats):
-            continue
-        r = audit(asm, sym)
-        print(sym)
-        print("   %d instructions, %d MFMA, %d ds_read, %d LDS-DMA; vmcnt literals %s; %s" %
-              (r["n_insns"], r["n_mfma"], r["n_dsread"], r["n_dma"], r["vmcnt_literals"], r["meta"]))
-        for f in r["findings"]:
-            print("   FINDING:", f)
-        for f in r["candidates"][:5]:
-            print("   candidate (pass 2, pessimistic merge):", f)
-
-
 def sgpr_vmem_hazards(asm_path, symbol, wait_states=5):
     """Inline-asm vector-memory instructions (hipcc's hazard recognizer does not look inside asm statements): an LDS-DMA / buffer load that
     reads an SGPR -- its descriptor quad or its scalar offset -- written by a VALU instruction (`v_readlane` / `v_readfirstlane`: how hipcc
@@ -308,7 +294,8 @@ def sgpr_vmem_hazards(asm_path, symbol, wait_states=5):
             u = body[j].strip()
             j -= 1
             if not u or u.startswith(";") or u.startswith("."):
-                if u.startswith(".LBB"):
+                if u.startswith(".LBB"):          # a predecessor block may end in the reload: the pair is unknown, not clean
+                    found.append((i + 1, t, "label %s inside the %d-state window: unknown" % (u.rstrip(":"), wait_states)))
                     break
                 continue
             w = re.match(r"v_read(?:first)?lane_b32 s(\d+)", u)
@@ -318,3 +305,199 @@ def sgpr_vmem_hazards(asm_path, symbol, wait_states=5):
             nop = re.match(r"s_nop (\d+)", u)
             ws += int(nop.group(1)) + 1 if nop else 1
     return found
+
+
+# ---- wait states that software owes around matrix instructions, where ONE side of the pair sits inside an asm statement ------------------
+# hipcc's hazard recognizer pads these pairs for the instructions it emits itself and looks at an INLINEASM statement neither as a vector
+# instruction nor as a matrix instruction (cdna_hip_programming.md 5.7 item 2): a pair with its producer or its consumer inside
+# `;;#ASMSTART ... ;;#ASMEND` gets nothing.  Wait states are counted like the recognizer counts them: one per instruction, `s_nop N` = N + 1.
+_MFMA_PASSES = (("v_mfma_f32_32x32x16", 8), ("v_mfma_f32_16x16x32", 4), ("v_mfma_f32_32x32x2_f32", 16), ("v_mfma_f32_16x16x4_f32", 8),
+                ("v_mfma_f32_32x32x8", 8), ("v_mfma_f32_16x16x16", 4), ("v_mfma_f32_4x4", 2), ("v_mfma_scale_f32_16x16x128", 8),
+                ("v_mfma_scale_f32_32x32x64", 16), ("v_mfma_f32_16x16x128", 8), ("v_mfma_f32_32x32x64", 16), ("v_mfma_f64", 16))
+
+
+def _mfma_passes(op):
+    for prefix, n in _MFMA_PASSES:
+        if op.startswith(prefix):
+            return n
+    return 16            # an unknown shape: the longest
+
+
+def _operands(text):
+    """-> (op, [operand strings]) of one instruction line"""
+    op, _, rest = text.partition(" ")
+    return op, [o.strip() for o in rest.split(",")] if rest else []
+
+
+def _is_valu(op):
+    return op.startswith("v_") and not op.startswith(("v_mfma", "v_smfma", "v_nop"))
+
+
+def _parse_cfg_with_asm(asm_path, symbol):
+    """-> (blocks, preds): blocks = lists of (line, text, in_asm); preds[b] = predecessor block indices (fall-through and branch targets)"""
+    lines = open(asm_path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith(symbol + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    blocks, labels, cur, in_asm = [], {}, [], False
+    for ln in range(start + 1, end):
+        raw = lines[ln]
+        if ";;#ASMSTART" in raw:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in raw:
+            in_asm = False
+            continue
+        t = raw.split(";")[0].strip()
+        if not t:
+            continue
+        m = re.match(r"^(\.?\w+):$", t)
+        if m:
+            if cur:
+                blocks.append(cur)
+                cur = []
+            labels[m.group(1)] = len(blocks)
+            continue
+        if t.startswith("."):
+            continue
+        cur.append((ln + 1, t, in_asm))
+        op = t.split(" ")[0]
+        if op == "s_branch" or op.startswith("s_cbranch") or op in ("s_endpgm", "s_setpc_b64", "s_trap"):
+            blocks.append(cur)
+            cur = []
+    if cur:
+        blocks.append(cur)
+    preds = [[] for _ in blocks]
+    for bi, blk in enumerate(blocks):
+        op, _, rest = blk[-1][1].partition(" ")
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            tgt = labels.get(rest.strip().split()[-1])
+            if tgt is not None and tgt < len(blocks):
+                preds[tgt].append(bi)
+            if op != "s_branch" and bi + 1 < len(blocks):
+                preds[bi + 1].append(bi)
+        elif op not in ("s_endpgm", "s_setpc_b64", "s_trap") and bi + 1 < len(blocks):
+            preds[bi + 1].append(bi)
+    return blocks, preds
+
+
+def _walk_back(blocks, preds, bi, ii, budget):
+    """every instruction that can execute fewer than `budget` wait states before blocks[bi][ii], over all paths of the control-flow graph:
+    yields (wait states in between, line, text, in_asm)"""
+    stack, best = [(bi, ii - 1, 0)], {}
+    while stack:
+        b, i, ws = stack.pop()
+        while i >= 0 and ws < budget:
+            ln, t, ia = blocks[b][i]
+            yield ws, ln, t, ia
+            nop = re.match(r"s_nop (\d+)", t)
+            ws += int(nop.group(1)) + 1 if nop else 1
+            i -= 1
+        if i < 0 and ws < budget:
+            for pb in preds[b]:
+                if best.get(pb, 1 << 30) > ws:          # reach a predecessor again only along a path with fewer wait states
+                    best[pb] = ws
+                    stack.append((pb, len(blocks[pb]) - 1, ws))
+
+
+def mfma_asm_hazards(asm_path, symbol, slack=4):
+    """Walk backwards from every candidate consumer over ALL paths of the control-flow graph (loop back-edges included).
+    Pairs looked for, `passes` = the matrix instruction's pass count (4 cycles each):
+      RAW/WAW  matrix instruction writes VGPRs -> an instruction INSIDE an asm statement reads or writes them fewer than passes + `slack`
+               wait states later (the recognizer's own figures are passes + 2 / + 3, + 1 on gfx950) -- unless that instruction is itself a
+               matrix instruction that takes them whole as its C operand and destination (the accumulate chain: 0 states);
+      WAR      matrix instruction reads VGPRs as SrcC (other than its destination) -> a vector instruction inside an asm statement writes them
+               fewer than passes + `slack` states later;
+      VALU->MFMA  a vector instruction inside an asm statement writes VGPRs -> a matrix instruction (anywhere) reads them as A, B or C fewer
+               than 2 wait states later.
+    -> [(line, text, partner line, partner text, kind, states seen, states owed)]"""
+    blocks, preds = _parse_cfg_with_asm(asm_path, symbol)
+    found, seen = [], set()
+
+    def note(*rec):
+        if (rec[0], rec[2], rec[4]) not in seen:
+            seen.add((rec[0], rec[2], rec[4]))
+            found.append(rec)
+
+    for bi, blk in enumerate(blocks):
+        for ii, (ln, t, ia) in enumerate(blk):
+            op, ops = _operands(t)
+            is_mfma = op.startswith(("v_mfma", "v_smfma"))
+            if ia and (op.startswith("v_") or op.startswith(("ds_", "buffer_", "global_"))) and not op.startswith("v_nop"):
+                touched = _vregs(" ".join(ops))
+                writes = _vregs(ops[0]) if (_is_valu(op) and ops) else set()
+                if touched:
+                    for ws, pl, pt, pia in _walk_back(blocks, preds, bi, ii, 16 + slack):
+                        pop, pops = _operands(pt)
+                        if not pop.startswith(("v_mfma", "v_smfma")):
+                            continue
+                        owed = _mfma_passes(pop) + slack
+                        if ws >= owed:
+                            continue
+                        pdst = _vregs(pops[0])
+                        psrcc = _vregs(pops[3]) if len(pops) > 3 else set()
+                        chain = is_mfma and len(ops) > 3 and _vregs(ops[0]) == pdst and _vregs(ops[3]) == pdst
+                        if pdst & touched and not chain:
+                            note(ln, t, pl, pt, "MFMA write -> asm access", ws, owed)
+                        elif (psrcc - pdst) & writes:
+                            note(ln, t, pl, pt, "MFMA SrcC read -> asm VALU write", ws, owed)
+            if is_mfma:
+                reads = _vregs(" ".join(ops[1:]))
+                for ws, pl, pt, pia in _walk_back(blocks, preds, bi, ii, 2):
+                    pop, pops = _operands(pt)
+                    if pia and _is_valu(pop) and pops and _vregs(pops[0]) & reads:
+                        note(ln, t, pl, pt, "asm VALU write -> MFMA read", ws, 2)
+    return found
+
+
+
+def pk_src1_swizzles(asm_path, symbol, asm_only=True):
+    """Packed-f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose SECOND or THIRD source is a VGPR pair read through an
+    op_sel / op_sel_hi swizzle (anything but the natural "low result from the low dword, high result from the high dword").  On gfx950 that
+    form computed the low half of lanes 48-63 from a wrong dword under back-to-back issue (csrc/upconv_fused.hip, note at APE_NO_ASM_MATH;
+    reproduced in every launch of tools/stress_upfuse.py's positive control); with the swizzled pair as src0 -- the slot hipcc uses for its own
+    broadcasts -- the same instruction is clean.  asm_only: instructions inside asm statements only (hipcc's own
+    `v_pk_add_f32 d, a, a op_sel:[0,1] op_sel_hi:[1,0]` horizontal adds are reported with asm_only=False; no fault has been seen on them).
+    -> [(line, text)]"""
+    blocks, _ = _parse_cfg_with_asm(asm_path, symbol)
+    found = []
+    for blk in blocks:
+        for ln, t, ia in blk:
+            op, ops = _operands(t)
+            if not op.startswith(("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")) or (asm_only and not ia):
+                continue
+            nsrc = 3 if op.startswith("v_pk_fma") else 2
+            tail = t
+            sel = re.search(r"op_sel:\[([01,]+)\]", tail)
+            sel_hi = re.search(r"op_sel_hi:\[([01,]+)\]", tail)
+            lo = [int(v) for v in sel.group(1).split(",")] if sel else [0] * nsrc
+            hi = [int(v) for v in sel_hi.group(1).split(",")] if sel_hi else [1] * nsrc
+            srcs = [re.sub(r"\s+op_sel.*$", "", o) for o in ops[1:1 + nsrc]]
+            for k in range(1, nsrc):
+                if k < len(srcs) and re.fullmatch(r"v\[\d+:\d+\]", srcs[k].strip()) and (lo[k] != 0 or hi[k] != 1):
+                    found.append((ln, t))
+                    break
+    return found
+
+
+if __name__ == "__main__":
+    src = sys.argv[1]
+    pats = sys.argv[2:]
+    asm = src if src.endswith(".s") else compile_to_asm(os.path.join(CSRC, src) if not os.path.exists(src) else src, "/tmp/ape_isa_audit")
+    for sym in kernel_symbols(asm):
+        if pats and not any(p in sym for p in pats):
+            continue
+        r = audit(asm, sym)
+        print(sym)
+        print("   %d instructions, %d MFMA, %d ds_read, %d LDS-DMA; vmcnt literals %s; %s" %
+              (r["n_insns"], r["n_mfma"], r["n_dsread"], r["n_dma"], r["vmcnt_literals"], r["meta"]))
+        for f in r["findings"]:
+            print("   FINDING:", f)
+        for f in r["candidates"][:5]:
+            print("   candidate (pass 2, pessimistic merge):", f)
+        for h in sgpr_vmem_hazards(asm, sym):
+            print("   SGPR->VMEM:", h)
+        for h in mfma_asm_hazards(asm, sym):
+            print("   MFMA/asm: line %d `%s` <- line %d `%s`: %s, %d of %d wait states" % h)
+        sw = pk_src1_swizzles(asm, sym)
+        if sw:
+            print("   packed-f32 src1/src2 VGPR swizzle inside asm: %d instruction(s), first at line %d `%s`" % (len(sw), sw[0][0], sw[0][1]))
