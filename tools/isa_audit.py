@@ -425,21 +425,38 @@ def mfma_asm_hazards(asm_path, symbol, slack=4):
             if ia and (op.startswith("v_") or op.startswith(("ds_", "buffer_", "global_"))) and not op.startswith("v_nop"):
                 touched = _vregs(" ".join(ops))
                 writes = _vregs(ops[0]) if (_is_valu(op) and ops) else set()
-                if touched:
-                    for ws, pl, pt, pia in _walk_back(blocks, preds, bi, ii, 16 + slack):
+                # depth-first over the predecessors with the registers still "owned" by an older producer: a compiler instruction in between
+                # that redefines a register ends the search for it on that path (that pair -- MFMA write, then the compiler's own write -- is
+                # hipcc's to pad, and the asm statement then reads hipcc's value)
+                stack, best = [(bi, ii - 1, 0, frozenset(touched))], {}
+                while stack:
+                    b, i, ws, live = stack.pop()
+                    while i >= 0 and ws < 16 + slack and live:
+                        pl, pt, pia = blocks[b][i]
                         pop, pops = _operands(pt)
-                        if not pop.startswith(("v_mfma", "v_smfma")):
-                            continue
-                        owed = _mfma_passes(pop) + slack
-                        if ws >= owed:
-                            continue
-                        pdst = _vregs(pops[0])
-                        psrcc = _vregs(pops[3]) if len(pops) > 3 else set()
-                        chain = is_mfma and len(ops) > 3 and _vregs(ops[0]) == pdst and _vregs(ops[3]) == pdst
-                        if pdst & touched and not chain:
-                            note(ln, t, pl, pt, "MFMA write -> asm access", ws, owed)
-                        elif (psrcc - pdst) & writes:
-                            note(ln, t, pl, pt, "MFMA SrcC read -> asm VALU write", ws, owed)
+                        if pop.startswith(("v_mfma", "v_smfma")):
+                            owed = _mfma_passes(pop) + slack
+                            pdst = _vregs(pops[0])
+                            psrcc = _vregs(pops[3]) if len(pops) > 3 else set()
+                            chain = is_mfma and len(ops) > 3 and _vregs(ops[0]) == pdst and _vregs(ops[3]) == pdst
+                            if ws < owed and not chain:
+                                if pdst & live:
+                                    note(ln, t, pl, pt, "MFMA write -> asm access", ws, owed)
+                                elif (psrcc - pdst) & writes & live:
+                                    note(ln, t, pl, pt, "MFMA SrcC read -> asm VALU write", ws, owed)
+                            live = live - pdst
+                        elif not pia and pops and (pop.startswith("v_") or pop.startswith(("ds_read", "buffer_load", "global_load"))) \
+                                and not re.search(r"\blds\b", pt):
+                            live = live - _vregs(pops[0])
+                        nop = re.match(r"s_nop (\d+)", pt)
+                        ws += int(nop.group(1)) + 1 if nop else 1
+                        i -= 1
+                    if i < 0 and ws < 16 + slack and live:
+                        for pb in preds[b]:
+                            key = (pb, live)
+                            if best.get(key, 1 << 30) > ws:
+                                best[key] = ws
+                                stack.append((pb, len(blocks[pb]) - 1, ws, live))
             if is_mfma:
                 reads = _vregs(" ".join(ops[1:]))
                 for ws, pl, pt, pia in _walk_back(blocks, preds, bi, ii, 2):
