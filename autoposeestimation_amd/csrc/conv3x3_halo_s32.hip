@@ -18,6 +18,9 @@
 //   * the weights of the next taps sit in a ring of four 16 KB tiles, issued three taps ahead;
 //   * the fragments of tap t+1 are read from LDS (pinned inline asm, cf. conv_gemm_s32.hip) into a second register set while the
 //     48 MFMAs of tap t run; one barrier per tap, counted vmcnt (never 0 in the steady state).
+//   * RAGGED LAST TILE ROW: a tile that holds fewer than 13 image rows (the segmentor's 60-row maps: rows 48..59 of every frame, a quarter
+//     of all tiles) gives each pixel-row group of waves THREE rows instead of four (`rpw`): the fourth row's 12 MFMAs per tap are skipped
+//     instead of multiplying rows that do not exist;
 // LDS image: a pixel (a weight row) is 128 B = chunks 0..3 hi | 4..7 lo, chunk c of pixel column hx in slot c ^ ((hx >> 1) & 7)
 // (weights: row instead of hx); the permutation is applied to the per-lane DMA SOURCE address, inside the 128-B line.
 #include <type_traits>
@@ -52,7 +55,8 @@ struct HaloS32Args {
     int out_fmt, res_fmt;
     int tiles_x, tiles_y, n_tiles;
     int dbg;                // ape_conv3x3_halo_s32_debug: 1 = static priority 1 for waves 4-7, 2 = one workgroup per tile instead of the
-                            // persistent walk (results unchanged by either); timing-only ablations: 4 = no epilogue stores, 8 = no residual loads
+                            // persistent walk, 16 = four rows per wave-row group in every tile (results unchanged by any of them);
+                            // timing-only ablations: 4 = no epilogue stores, 8 = no residual loads
 };
 
 // NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
@@ -149,6 +153,10 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     };
     int cur_orig = blockIdx.x;
     decode(cur_orig, cur_b, cur_y0, cur_x0, n0);
+    // rows per pixel-row group of waves in a tile at image row ty0 (4, or fewer when the tile holds fewer than 13 / 9 / 5 image rows), times
+    // this wave's group index: the tile row this wave's first output row is (dbg bit 16: always 4)
+    auto rows_per_wave = [&](int ty0) { const int rows = a.H - ty0 < TS ? a.H - ty0 : TS; return (a.dbg & 16) ? 4 : (rows + 3) >> 2; };
+    int rpw = rows_per_wave(cur_y0), rpw_next = rpw;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,12 +179,14 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     auto set_dma_tile = [&](int tb, int ty0, int tx0) {
         dma_b = tb;
         dma_y0 = ty0;
+        int ln = lane;          // (opaque: the lane-only parts of the offsets are loop-invariant, and hoisted out of the tile loop they get spilled --
+        asm volatile("" : "+v"(ln));       // a scratch reload per tile whose vmcnt(0) drains the DMA pipeline)
 #pragma unroll
         for (int xp = 0; xp < 3; ++xp) {
-            const int hx = xp * 8 + (lane >> 3);
+            const int hx = xp * 8 + (ln >> 3);
             const int gx = tx0 - D + hx;
             const bool ok = hx < TS + 2 * D && (unsigned)gx < (unsigned)a.W;
-            lane_x[xp] = ok ? (unsigned)((gx * a.ldx + a.xoff) * 4 + (((lane & 7) ^ ((hx >> 1) & 7)) * 16)) : 0x80000000u;
+            lane_x[xp] = ok ? (unsigned)((gx * a.ldx + a.xoff) * 4 + (((ln & 7) ^ ((hx >> 1) & 7)) * 16)) : 0x80000000u;
         }
     };
     set_dma_tile(cur_b, cur_y0, cur_x0);
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         constexpr int half = decltype(half_c)::value, bset = decltype(bset_c)::value;
         const int ky = tap / 3, kx = tap - ky * 3;
         const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
-        const int rb = ring0 + 4 * wm + ky * D + 2 * half;
+        const int rb = ring0 + rpw * wm + ky * D + 2 * half;
         const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
         const unsigned so = (unsigned)((tgb & (B_RING - 1)) * B_TILE);
         ds_read_half<2 * half>(Ah[half], Bf[bset], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         {
             const int ky = tap / 3, kx = tap - ky * 3;
             const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
-            const int rb = ring_cur + 4 * wm + ky * D + 2;
+            const int rb = ring_cur + rpw * wm + ky * D + 2;
             const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
             const unsigned so = (unsigned)(((tg + 1) & (B_RING - 1)) * B_TILE);
             ds_read_half<0>(Ah[1], Bf[P ^ 1], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
@@ -342,17 +352,17 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         {
             const int ky = ntap / 3, kx = ntap - ky * 3;
             const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
-            const int rb = nring + 4 * wm + ky * D;
+            const int rb = nring + ((wrap && last_of_tile) ? rpw_next : rpw) * wm + ky * D;      // (across a tile seam: the next tile's row of this wave)
             const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
             const unsigned so = (unsigned)(((tg + 1) & (B_RING - 1)) * B_TILE);
             ds_read_half<2>(Ah[0], Bf[P ^ 1], ah + r0, al + r0, ah + r1, al + r1, b_lane[0] + so, b_lane[1] + so);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfma_row(set_c, I2{});
+        if (rpw > 2) mfma_row(set_c, I2{});
         __builtin_amdgcn_sched_barrier(0);
         if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I2{});
         __builtin_amdgcn_sched_barrier(0);
-        mfma_row(set_c, I3{});
+        if (rpw > 3) mfma_row(set_c, I3{});
         __builtin_amdgcn_sched_barrier(0);
         if (more_b) {
             const int t3 = tap + 3;          // (chunk, tap) of flattened tap tg + 3: the same weights for every tile of this workgroup
@@ -388,8 +398,8 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             const long second = rs32 ? 64 : 8;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int gy = cur_y0 + 4 * wm + i;
-                const bool pix_ok = gy < a.H && gx < a.W;
+                const int gy = cur_y0 + rpw * wm + i;
+                const bool pix_ok = i < rpw && gy < a.H && gx < a.W;
                 const size_t m = ((size_t)cur_b * a.H + (pix_ok ? gy : 0)) * a.W + (pix_ok ? gx : 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -413,8 +423,8 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             constexpr bool OUT_S32 = decltype(s32_c)::value != 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int gy = cur_y0 + 4 * wm + i;
-                if (gy >= a.H || gx >= a.W) continue;
+                const int gy = cur_y0 + rpw * wm + i;
+                if (i >= rpw || gy >= a.H || gx >= a.W) continue;
                 const size_t m = ((size_t)cur_b * a.H + gy) * a.W + gx;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -477,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
                 int tb, ty0, tx0, tn0;
                 decode(cur_orig + grid, tb, ty0, tx0, tn0);
                 set_dma_tile(tb, ty0, tx0);
+                rpw_next = rows_per_wave(ty0);
             }
         }
         constexpr int FREE = RING_ROWS - I;                // rows of the next image that land on ring rows no image uses now
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             epilogue();
             zero_acc();
             cur_orig += grid;
-            if (gc + 2 < total_chunks) { int tn0; decode(cur_orig, cur_b, cur_y0, cur_x0, tn0); }
+            if (gc + 2 < total_chunks) { int tn0; decode(cur_orig, cur_b, cur_y0, cur_x0, tn0); rpw = rows_per_wave(cur_y0); }
         }
     }
 #endif

@@ -525,13 +525,16 @@ class UpConv:
                                                 out_fmt, b, h, w, self.cin, ACT_PRELU, self.alpha, int(self.fma), _st())
         _lib.check(rc, "ape_upconv3x3_fused_s32")
         if e0 is not None:
-            _prof_end(e0, label, "%dx%dx%d %d->%d up" % (b, 2 * h, 2 * w, self.cin, self.cout), *self._fused_cost(b, h, w, 4.0 * self.cout))
+            _prof_end(e0, label, "%dx%dx%d %d->%d up (executed flop; direct form x4)" % (b, 2 * h, 2 * w, self.cin, self.cout), *self._fused_cost(b, h, w, 4.0 * self.cout))
         return S32(out) if out_fmt == FMT_S32 else out
 
     def _fused_cost(self, b, h, w, out_bytes_per_pixel):
-        """(algorithmic flop, algorithmic bytes) of the one-kernel form: the reference's convolution at HIGH resolution (what the layer
-        computes, pspnet.py:30-33) and the input read + the output written once"""
-        return (2.0 * b * 4 * h * w * self.cout * 9 * self.cin,
+        """(flop, algorithmic bytes) of the one-kernel form.  The flop are the ones the kernel EXECUTES on the matrix cores -- the channel
+        mixing at LOW resolution, 2 * B * h * w * (9 * Cout) * Cin -- a quarter of the reference's convolution at high resolution
+        (pspnet.py:30-33: 2 * B * 4 h w * Cout * 9 * Cin): pricing the layer's direct form against the matrix peak would overstate the
+        matrix-core throughput four times over (the kernel is bound by vector-instruction issue, not by the matrix pipe).  Bytes: the input
+        read + the output written once."""
+        return (2.0 * b * h * w * 9 * self.cout * self.cin,
                 4.0 * (b * h * w * self.cin + 9 * self.cout * self.cin) + out_bytes_per_pixel * b * 4 * h * w)
 
     def seg_head(self, x, head_w, head_b, double_softmax=True, fused=None):
@@ -551,7 +554,7 @@ class UpConv:
                                                         _lib.dptr(head_b), c, _lib.dptr(label), _lib.dptr(score), int(bool(double_softmax)), _st())
         _lib.check(rc, "ape_upconv3x3_fused_seghead_s32")
         if e0 is not None:
-            _prof_end(e0, klabel, "%dx%dx%d %d->%d up +head" % (b, 2 * h, 2 * w, self.cin, self.cout), *self._fused_cost(b, h, w, 5.0))
+            _prof_end(e0, klabel, "%dx%dx%d %d->%d up +head (executed flop; direct form x4)" % (b, 2 * h, 2 * w, self.cin, self.cout), *self._fused_cost(b, h, w, 5.0))
         return label, score
 
 

@@ -298,7 +298,7 @@ def parity_block(out, oracle_results, frames, seg_sd):
 def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence):
     """`bench.py --mixed`: --batch frames per rank of synthetic.mixed_frame (1-3 objects, five painted sizes) through FramePipeline --
     segmentation, components, then ONE pose-stage pass per distinct crop size of the batch (FramePipeline.poses' buckets) -- and one
-    all_gather of a [frames, 3, 8] result block per step.  Returns the `sweep` object (rank 0; None elsewhere)."""
+    all_gather of a [frames, len(CLASSES), 8] result block per step.  Returns the `sweep` object (rank 0; None elsewhere)."""
     from autoposeestimation_amd.pipeline.utils import FramePipeline
     from autoposeestimation_amd.sharding import gather_results
     n = args.batch
@@ -309,7 +309,7 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
 
     def tail(out):
         with torch.cuda.stream(out.get("stream") or torch.cuda.current_stream()):
-            block = torch.zeros(n, 3, 8, dtype=torch.float32, device=device)
+            block = torch.zeros(n, len(CLASSES), 8, dtype=torch.float32, device=device)    # (one detection per class at most: FramePipeline keeps the best component of each)
             if out["objects"]:
                 o = np.asarray(out["objects"], dtype=np.int64)
                 first = np.searchsorted(o[:, 0], o[:, 0], side="left")          # objects are frame-major: slot = position within the frame

@@ -102,10 +102,16 @@ def test_inline_asm_vector_memory_reads_no_freshly_reloaded_sgpr(audit_mod, tmp_
         assert audit_mod.sgpr_vmem_hazards(asm, sym) == [], sym
     # the walk sees the pattern it is looking for (a reload two instructions in front of the load) and accepts five wait states
     probe = os.path.join(str(tmp_path_factory.mktemp("isa")), "probe.s")
-    open(probe, "w").write("\nk1:\n\tv_readlane_b32 s37, v9, 3\n\ts_mov_b32 m0, s6\n\tbuffer_load_dwordx4 v1, s[36:39], 0 offen lds\n\ts_endpgm\n"
-                           "\nk2:\n\tv_readlane_b32 s2, v9, 3\n\ts_nop 4\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen offset:64\n\ts_endpgm\n"
-                           "\nk3:\n\tv_readlane_b32 s2, v9, 3\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen\n\ts_endpgm\n")
+    A, E = "\t;;#ASMSTART\n", "\t;;#ASMEND\n"
+    open(probe, "w").write("\nk1:\n\tv_readlane_b32 s37, v9, 3\n" + A + "\ts_mov_b32 m0, s6\n\tbuffer_load_dwordx4 v1, s[36:39], 0 offen lds\n" + E + "\ts_endpgm\n"
+                           "\nk2:\n\tv_readlane_b32 s2, v9, 3\n" + A + "\ts_nop 4\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen offset:64\n" + E + "\ts_endpgm\n"
+                           "\nk3:\n\tv_readlane_b32 s2, v9, 3\n" + A + "\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen\n" + E + "\ts_endpgm\n"
+                           "\nk4:\n\tv_readlane_b32 s2, v9, 3\n\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen\n\ts_endpgm\n"       # hipcc's own: its to pad
+                           "\nk5:\n\tv_readlane_b32 s2, v9, 3\n.LBB0_3:\n" + A + "\tbuffer_load_dwordx4 v[4:7], v1, s[36:39], s2 offen\n" + E + "\ts_endpgm\n")
     assert len(audit_mod.sgpr_vmem_hazards(probe, "k1")) == 1 and audit_mod.sgpr_vmem_hazards(probe, "k2") == [] and len(audit_mod.sgpr_vmem_hazards(probe, "k3")) == 1
+    assert audit_mod.sgpr_vmem_hazards(probe, "k4") == []
+    unknown = audit_mod.sgpr_vmem_hazards(probe, "k5")          # a label inside the window: reported, not taken for clean
+    assert len(unknown) == 1 and "unknown" in unknown[0][2]
 
 
 

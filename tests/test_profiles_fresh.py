@@ -16,11 +16,14 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 
 
 def _newest():
-    metas = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_meta.json")))
+    import re
+    metas = [(int(m.group(1)), p) for p in glob.glob(os.path.join(REPO, "profiles", "r*_meta.json"))
+             for m in [re.match(r"r(\d+)_meta\.json$", os.path.basename(p))] if m]
     if not metas:
         pytest.skip("no rNN_meta.json yet (profiles of this round not generated)")
-    meta = json.load(open(metas[-1]))
-    return os.path.basename(metas[-1])[:3], meta
+    _, path = max(metas)                              # numerically newest round (r100 sorts after r99)
+    meta = json.load(open(path))
+    return os.path.basename(path)[:-len("_meta.json")], meta
 
 
 def test_profiles_were_generated_from_this_tree():
@@ -35,7 +38,7 @@ def test_launches_per_step_agree_between_the_bench_line_and_rocprof():
     line = meta["bench_line"]
     timed = json.load(open(os.path.join(REPO, "profiles", "%s_default_overlap_timed_region.json" % rnd)))
     by_name = {k.replace(" ", ""): v for k, v in timed.items()}
-    steps_prof = 3                                   # tools/make_profiles.sh: --steps 3
+    steps_prof = meta.get("profile_steps", 3)        # tools/make_profiles.sh stores the step count of its profiled runs (r04 and older: 3)
     assert line["roofline"]["kernels"], "the line carries no roofline kernels"
     for k in line["roofline"]["kernels"]:
         name = k["kernel"].replace(" ", "")

@@ -276,15 +276,20 @@ def sgpr_vmem_hazards(asm_path, symbol, wait_states=5):
     """Inline-asm vector-memory instructions (hipcc's hazard recognizer does not look inside asm statements): an LDS-DMA / buffer load that
     reads an SGPR -- its descriptor quad or its scalar offset -- written by a VALU instruction (`v_readlane` / `v_readfirstlane`: how hipcc
     reloads SPILLED SGPRs, wherever the next use is) fewer than `wait_states` wait states earlier reads a stale value.  Linear walk back
-    from every `buffer_load ... offen` of the kernel (a label ends the walk: nothing is claimed across it).  -> [(line, instruction, writer)]"""
+    from every `buffer_load ... offen` INSIDE an asm statement (hipcc pads its own); a label inside the window is reported as "unknown", never
+    taken for clean: a predecessor block may end in the reload.  -> [(line, instruction, writer)]"""
     text = open(asm_path).read()
     start = text.index("\n" + symbol + ":")
     body = text[start:text.index("s_endpgm", start)].splitlines()
-    found = []
+    found, in_asm = [], False
     for i, line in enumerate(body):
+        if ";;#ASMSTART" in line:
+            in_asm = True
+        elif ";;#ASMEND" in line:
+            in_asm = False
         t = line.strip()
         m = re.match(r"buffer_load_dword\w* (?:v\[?[\d:]+\]?, )?v\d+, s\[(\d+):(\d+)\], (s\d+|\d+|0)", t)
-        if not m or "offen" not in t:
+        if not m or "offen" not in t or not in_asm:
             continue
         reads = set(range(int(m.group(1)), int(m.group(2)) + 1))
         if m.group(3).startswith("s"):
@@ -295,7 +300,7 @@ def sgpr_vmem_hazards(asm_path, symbol, wait_states=5):
             j -= 1
             if not u or u.startswith(";") or u.startswith("."):
                 if u.startswith(".LBB"):          # a predecessor block may end in the reload: the pair is unknown, not clean
-                    found.append((i + 1, t, "label %s inside the %d-state window: unknown" % (u.rstrip(":"), wait_states)))
+                    found.append((i + 1, t, "label %s inside the %d-state window: unknown" % (u.split(":")[0], wait_states)))
                     break
                 continue
             w = re.match(r"v_read(?:first)?lane_b32 s(\d+)", u)
@@ -423,7 +428,10 @@ def mfma_asm_hazards(asm_path, symbol, slack=4):
             op, ops = _operands(t)
             is_mfma = op.startswith(("v_mfma", "v_smfma"))
             if ia and (op.startswith("v_") or op.startswith(("ds_", "buffer_", "global_"))) and not op.startswith("v_nop"):
-                touched = _vregs(" ".join(ops))
+                # a vector instruction touches its destination at once (WAW) and reads its sources; a memory instruction READS its address / data
+                # operands now and writes its destination only when the data returns, tens of cycles later (not a wait-state hazard)
+                loads = op.startswith(("ds_read", "buffer_load", "global_load")) and not re.search(r"\blds\b", t)
+                touched = _vregs(" ".join(ops[1:] if loads else ops))
                 writes = _vregs(ops[0]) if (_is_valu(op) and ops) else set()
                 # depth-first over the predecessors with the registers still "owned" by an older producer: a compiler instruction in between
                 # that redefines a register ends the search for it on that path (that pair -- MFMA write, then the compiler's own write -- is

@@ -4,20 +4,21 @@
 # Output goes to gpurun_out/<round>/ (merged back by gpurun); copy it into profiles/ and commit.  The counters run in their own passes
 # (--pmc never together with --stats-less tracing domains), every pass with the program itself behind `--`.
 set -o pipefail
-R=${1:-r04}
+R=${1:-r05}
+PSTEPS=3        # steps of the profiled runs (stored in rNN_meta.json: tests/test_profiles_fresh.py divides the launch counts by it)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$R
 mkdir -p $O
 T="timeout -k 10 280"
 # 1. single stream under the kernel trace: per-kernel stats, timed region, one step's launch list
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_no -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-modes > $O/prof_no.log 2>&1 || exit 1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_no -- python3 bench.py --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-overlap --no-modes > $O/prof_no.log 2>&1 || exit 1
 cp $O/prof_no/*/*_kernel_stats.csv $O/${R}_bf16x3_kernel_stats.csv
-python tools/prof_summary.py $O/prof_no/*/*_kernel_trace.csv --steps 3 --warmup 2 > $O/${R}_bf16x3_timed_region.json || exit 1
+python tools/prof_summary.py $O/prof_no/*/*_kernel_trace.csv --steps $PSTEPS --warmup 2 > $O/${R}_bf16x3_timed_region.json || exit 1
 python tools/prof_step_list.py $O/prof_no/*/*_kernel_trace.csv > $O/${R}_step_launch_list.txt || exit 1
 # 2. the DEFAULT command (software-pipelined loop) under the kernel trace
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_def -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-modes > $O/prof_def.log 2>&1 || exit 1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_def -- python3 bench.py --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-modes > $O/prof_def.log 2>&1 || exit 1
 cp $O/prof_def/*/*_kernel_stats.csv $O/${R}_default_overlap_kernel_stats.csv
-python tools/prof_summary.py $O/prof_def/*/*_kernel_trace.csv --steps 3 --warmup 2 --tail-steps 3 > $O/${R}_default_overlap_timed_region.json || exit 1
+python tools/prof_summary.py $O/prof_def/*/*_kernel_trace.csv --steps $PSTEPS --warmup 2 --tail-steps 3 > $O/${R}_default_overlap_timed_region.json || exit 1
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, split per layer shape
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes --dump-launches $O/launches.json > $O/pmc_fetch.log 2>&1 || exit 1
 $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes > $O/pmc_write.log 2>&1 || exit 1
@@ -31,13 +32,13 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_label -- pyth
 cp $O/prof_label/*/*_kernel_stats.csv $O/${R}_label_kernel_stats.csv
 # 6. the un-profiled default line of the same tree (with the CPU baseline and the parity block) and the freshness stamp
 $T python3 bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1 || exit 1
-python - "$O" "$R" <<'PY'
+python - "$O" "$R" "$PSTEPS" <<'PY'
 import json, sys, os
 sys.path.insert(0, "tools")
 from profile_stamp import source_hash
-o, r = sys.argv[1], sys.argv[2]
+o, r, psteps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 line = [l for l in open(os.path.join(o, "bench_default.log")) if l.startswith("{")][-1]
-json.dump({"source_hash": source_hash(), "bench_line": json.loads(line),
+json.dump({"source_hash": source_hash(), "round": int(r[1:]), "profile_steps": psteps, "bench_line": json.loads(line),
            "made_by": "tools/make_profiles.sh %s (rocprofv3 passes of bench.py on one MI355X, all from one tree)" % r}, open(os.path.join(o, r + "_meta.json"), "w"), indent=1)
 PY
 rm -rf $O/prof_no $O/prof_def $O/pmc_fetch $O/pmc_write $O/pmc_util $O/prof_label
