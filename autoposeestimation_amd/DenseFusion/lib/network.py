@@ -249,7 +249,8 @@ class _PSPPlan:
         (bilinearly re-sampled inside up_3's halo load)."""
         S = E.FMT_S32
         y = E.stem_pool(self.stem, x)
-        for c1, c2, down in self.blocks:
+        fold = E.USE_PSP_FOLD                             # the last layer-4 conv then writes a map with 64 spare channels for the prior coefficients
+        for bi, (c1, c2, down) in enumerate(self.blocks):
             wide = c1.cout >= 128
             if not wide:                                  # layer 1: fp32 in and out
                 res = y if down is None else down(y)
@@ -257,15 +258,22 @@ class _PSPPlan:
                 continue
             res = y if down is None else down(y)          # fp32 (a residual only) from either kernel
             t = c1(y, out_fmt=S)                          # stride-2 first conv of layer 2: conv_gemm.hip with an S32 epilogue
-            y = c2(t, residual=res, out_fmt=S)
+            out = None
+            if fold and bi == len(self.blocks) - 1:
+                out = E.S32(torch.empty(t.shape[0], t.shape[1], t.shape[2], c2.cout + E.PSP_FOLD_K, dtype=torch.float32, device=x.device))
+            y = c2(t, residual=res, out=out, out_fmt=S)
         f = y
         b, h, w, _ = f.shape
+        nf = self.bott_feats.cin
         pools = E.adaptive_avgpool_multi(f, (2, 3, 6))
         pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f.to_f32(), 1)
-        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]
-        p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w), out_fmt=S)
+        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]       # (a prior conv reads the first 512 channels of its pooled map)
+        if fold:
+            p = E.psp_bottleneck_folded(self.bott_feats, f, zs, out_fmt=S)
+        else:
+            p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w), out_fmt=S)
         if taps is not None:
-            taps["feats"], taps["psp"] = f.to_f32(), p.to_f32()
+            taps["feats"], taps["psp"] = f.to_f32()[..., :nf].contiguous(), p.to_f32()
         p = self.up[0](p, out_fmt=S)
         if taps is not None:
             taps["up_1"] = p.to_f32()

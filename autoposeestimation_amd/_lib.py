@@ -30,6 +30,8 @@ SIGNATURES = {
     "ape_conv_gemm_s32_debug": [_I],
     "ape_conv3x3_halo_s32_debug": [_I],
     "ape_conv_gemm_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
+    "ape_conv_gemm_s32_per_image": [_P, _P, _c.c_long, _P, _P, _I, _P, _P],
+    "ape_psp_fold_operands": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ape_conv_gemm_bf16_fmt": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "ape_conv_gemm_splitk_workspace_bytes": [_P],
     "ape_conv_gemm_bf16_splitk": [_P, _P, _P, _P, _P, _P, _I, _P, _c.c_size_t, _P],

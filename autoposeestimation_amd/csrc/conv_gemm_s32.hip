@@ -54,6 +54,9 @@ struct GemmS32Args {
     int bias_bstride, rows_per_image;
     int out_fmt, res_fmt;   // APE_FMT_F32 / APE_FMT_S32
     int m_tiles, n_tiles, nk;
+    int img_tiles;          // 0: M is one flat run of rows cut into 256-row tiles; > 0: every image (rows_per_image rows) is cut into img_tiles tiles
+                            // of its own -- no tile holds rows of two images -- and ...
+    long w_img_stride;      // ... image i multiplies with the weights at w + i * w_img_stride bytes (0: one weight matrix for all)
     int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads;
                             // 16: per-workgroup k-tile rotation (valid results; tested against L2 hot-spotting on the shared weight lines: +-0);
                             // 32: no static priority for waves 4-7; 64: one tile per workgroup (no persistent walk)
@@ -147,18 +150,32 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
     const int wm = wave >> 2, wn = wave & 3;
 
     // ---- LDS-DMA sources: buffer descriptors whose range ends at the last valid row (rows beyond read as zeros) -----------
-    auto make_rs_a = [&](int m0_) {
-        const long a_bytes = ((long)(a.M - m0_) * a.ldx - a.xoff) * 4;
+    // pixel tile mt -> first row, end of the rows it may touch (the image's end with per-image tiling: rows past it read as zeros and are
+    // not stored), image index (selects the weights)
+    auto tile_rows = [&](int mt, int& m0_, int& mend_, int& img_) {
+        if (a.img_tiles > 0) {
+            img_ = mt / a.img_tiles;
+            m0_ = img_ * a.rows_per_image + (mt - img_ * a.img_tiles) * BM;
+            mend_ = (img_ + 1) * a.rows_per_image;
+        } else {
+            img_ = 0;
+            m0_ = mt * BM;
+            mend_ = a.M;
+        }
+    };
+    auto make_rs_a = [&](int m0_, int mend_) {
+        const long a_bytes = ((long)(mend_ - m0_) * a.ldx - a.xoff) * 4;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((long)m0_ * a.ldx + a.xoff) * 4), 0,
                                                  (int)(a_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)a_bytes), 0x00020000);
     };
-    auto make_rs_b = [&](int n0_) {
+    auto make_rs_b = [&](int n0_, int img_) {
         const long b_bytes = (long)(a.Cout - n0_) * a.K * 4;
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long)n0_ * a.K * 4), 0,
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long)img_ * a.w_img_stride + (long)n0_ * a.K * 4), 0,
                                                  (int)(b_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)b_bytes), 0x00020000);
     };
-    int m0 = (logical / a.n_tiles) * BM, n0 = (logical % a.n_tiles) * BN;
-    __amdgpu_buffer_rsrc_t rs_a = make_rs_a(m0), rs_b = make_rs_b(n0);
+    int m0, m_end, img, n0 = (logical % a.n_tiles) * BN;
+    tile_rows(logical / a.n_tiles, m0, m_end, img);
+    __amdgpu_buffer_rsrc_t rs_a = make_rs_a(m0, m_end), rs_b = make_rs_b(n0, img);
     bool has_next = false;                                    // (the NEXT tile's descriptors are built where a k-tile index wraps into it)
     // one DMA = 8 rows x 128 B: lanes 8 r .. 8 r + 7 fetch ONE row (a whole 128-B line), its 16-B chunks permuted by the row's XOR
     // swizzle ((row >> 1) & 7: the rows of a block are 8-aligned, so this is ((lane >> 4) & 3) | parity-free bits of the block)
@@ -361,7 +378,9 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
         // k-tiles past the end of this tile are the first ones of the next tile
         const bool wrap_b = kt + 2 >= nk, wrap_a = kt + 3 >= nk;
         const int nl = logical + G;
-        const __amdgpu_buffer_rsrc_t rs_b_use = wrap_b ? make_rs_b((nl % a.n_tiles) * BN) : rs_b, rs_a_use = wrap_a ? make_rs_a((nl / a.n_tiles) * BM) : rs_a;
+        int nm0, nmend, nimg;
+        tile_rows(nl / a.n_tiles, nm0, nmend, nimg);
+        const __amdgpu_buffer_rsrc_t rs_b_use = wrap_b ? make_rs_b((nl % a.n_tiles) * BN, nimg) : rs_b, rs_a_use = wrap_a ? make_rs_a(nm0, nmend) : rs_a;
         const int kb = wrap_b ? kt + 2 - nk : kt + 2, ka = wrap_a ? kt + 3 - nk : kt + 3;
         const int slot = slot_free;
         slot_free = slot_free + A_STAGE == NA * A_STAGE ? 0 : slot_free + A_STAGE;
@@ -434,7 +453,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
         for (int ii = 0; ii < 4; ++ii) {
             const int i = i0 + ii;
             const int m = m0 + wm * 128 + i * 16 + frow_e;
-            if (m >= a.M) continue;
+            if (m >= m_end) continue;
             const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -474,10 +493,10 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
     if (RES || !has_next) break;
     // ---- on to the next tile: its first k-tiles are in flight or landed ----
     logical += G;
-    m0 = (logical / a.n_tiles) * BM;
+    tile_rows(logical / a.n_tiles, m0, m_end, img);
     n0 = (logical % a.n_tiles) * BN;
-    rs_a = make_rs_a(m0);
-    rs_b = make_rs_b(n0);
+    rs_a = make_rs_a(m0, m_end);
+    rs_b = make_rs_b(n0, img);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -509,7 +528,7 @@ int launch_s32_res(GemmS32Args& a, hipStream_t st)
     static ape::DeviceOnce once;       // (one per instantiation of this function, i.e. per kernel)
     int ncu_dev = 0;
     if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), (int)lds, &ncu_dev)) return rc;
-    a.m_tiles = ape::ceil_div(a.M, BM);
+    a.m_tiles = a.img_tiles > 0 ? (a.M / a.rows_per_image) * a.img_tiles : ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.Cout, BN);
     // persistent walk (one workgroup per CU) where the k-tile stream can run through the tile boundary: an even number of k-tiles (the
     // weight stage parity repeats) and at least four (the look-ahead of three stays inside one tile); dbg bit 64: one tile per workgroup
@@ -606,8 +625,8 @@ extern "C" int ape_conv_gemm_s32_debug(int bits) { g_s32_dbg = bits; return APE_
 
 extern "C" int ape_conv_gemm_s32_supported(const ape_conv_params* params) { return params && supported_s32(*params) ? 1 : 0; }
 
-extern "C" int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
-                                 int out_fmt, const ape_conv_params* params, void* stream)
+static int conv_gemm_s32_run(const void* x_s32, const void* w_s32k, long w_image_stride_bytes, const float* bias, const void* residual,
+                             int res_fmt, void* y, int out_fmt, const ape_conv_params* params, void* stream)
 {
     if (!x_s32 || !w_s32k || !y || !params) return APE_EINVAL;
     const ape_conv_params& p = *params;
@@ -625,10 +644,141 @@ extern "C" int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const fl
     a.out_fmt = out_fmt; a.res_fmt = res_fmt;
     a.nk = p.Cin / 32;
     a.dbg = g_s32_dbg;
+    a.img_tiles = 0;
+    a.w_img_stride = 0;
+    if (w_image_stride_bytes) {
+        a.img_tiles = ape::ceil_div(a.rows_per_image, BM);
+        a.w_img_stride = w_image_stride_bytes;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int waste256 = ape::ceil_div(p.Cout, 256) * 256 - p.Cout;
     const int waste192 = ape::ceil_div(p.Cout, 192) * 192 - p.Cout;
     if (p.Cout <= 128) return launch_s32<128>(a, st);
     if (waste192 < waste256) return launch_s32<192>(a, st);
     return launch_s32<256>(a, st);
+}
+
+extern "C" int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
+                                 int out_fmt, const ape_conv_params* params, void* stream)
+{
+    return conv_gemm_s32_run(x_s32, w_s32k, 0, bias, residual, res_fmt, y, out_fmt, params, stream);
+}
+
+extern "C" int ape_conv_gemm_s32_per_image(const void* x_s32, const void* w_s32k, long w_image_stride_bytes, const float* bias, void* y,
+                                           int out_fmt, const ape_conv_params* params, void* stream)
+{
+    if (w_image_stride_bytes <= 0 || w_image_stride_bytes % 16) return APE_EINVAL;
+    return conv_gemm_s32_run(x_s32, w_s32k, w_image_stride_bytes, bias, nullptr, APE_FMT_F32, y, out_fmt, params, stream);
+}
+
+// ---- the PSP bottleneck with its prior sum folded into the contraction (pspnet.py:12-24) ---------------------------------------------------
+// bottleneck(cat(up(stage_s(pool_s(f))), f)) = W_f . f + sum_s up(Z_s) + b with Z_s = (W_b,s W_s) . pool_s(f) ([s x s x Cout] per frame,
+// network.py _PSPPlan.prior) and `up` the bilinear (align_corners = False) resize to the map.  The resize is linear with coefficients that
+// depend on the pixel alone: up(Z_s)[p] = sum_cells c_s[p][cell] Z_s[cell], at most four non-zero per scale.  So the prior sum is 50 more
+// K-columns of the same contraction -- c[p][0..49] appended to the pixel's channels, Z_f[0..49][co] appended to frame f's weight rows --
+// instead of a 1.26 GB fp32 tensor written by one kernel and read back by the GEMM's epilogue (ape_psp_prior_sum_f32 + the residual
+// operand of ape_conv_gemm_s32: 1.68 ms per 64 frames; folded: 1.09 ms + these two small kernels).  Cells in the order 1x1 | 2x2 | 3x3 | 6x6,
+// row-major, padded to 64 columns with zeros.
+namespace {
+constexpr int PSP_CELLS = 50, PSP_KPAD = 64;
+__device__ __forceinline__ float psp_src_index(int dst, float scale)        // ATen area_pixel_compute_source_index, align_corners = False (= ops.hip src_index)
+{
+    const float s = scale * ((float)dst + 0.5f) - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
+// bilinear weight of prior cell `i` (0 .. S-1 along one axis) for output index `o` of `n`: ape_psp_prior_sum_f32's own expressions
+__device__ __forceinline__ float psp_axis_weight(int o, int n, int S, int i)
+{
+    const float f = psp_src_index(o, (float)S / (float)n);
+    const int i0 = (int)f;
+    const int i1 = i0 + (i0 < S - 1 ? 1 : 0);
+    const float l1 = f - (float)i0, l0 = 1.f - l1;
+    return (i == i0 ? l0 : 0.f) + (i == i1 ? l1 : 0.f);
+}
+// channels [coff, coff + 64) of every pixel of x (S32, ld channels per pixel) <- the pixel's 50 coefficients (hi | lo); one thread per
+// (pixel, 4 cells)
+__global__ void psp_fill_coeffs_kernel(char* __restrict__ x, int B, int h, int w, int ld, int coff)
+{
+    const long total = (long)B * h * w * (PSP_KPAD / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % (PSP_KPAD / 4));
+        const long pix = i / (PSP_KPAD / 4);
+        const int ox = (int)(pix % w), oy = (int)((pix / w) % h);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = q * 4 + e;
+            int S, cell;
+            if (j < 1) { S = 1; cell = j; }
+            else if (j < 5) { S = 2; cell = j - 1; }
+            else if (j < 14) { S = 3; cell = j - 5; }
+            else { S = 6; cell = j - 14; }
+            v[e] = j < PSP_CELLS ? psp_axis_weight(oy, h, S, cell / S) * psp_axis_weight(ox, w, S, cell % S) : 0.f;
+        }
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+        const int c = coff + q * 4;
+        char* p = x + pix * ld * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<bf16x4*>(p) = hi;
+        *reinterpret_cast<bf16x4*>(p + 64) = lo;
+    }
+}
+// out[b][co][g] (128-B groups, G = K/32 + 2 per row): g < K/32: the shared weights' group; the last two: frame b's Z values of row co
+__global__ void psp_pack_weights_kernel(const char* __restrict__ wf, const float* __restrict__ z1, const float* __restrict__ z2,
+                                        const float* __restrict__ z3, const float* __restrict__ z6, char* __restrict__ out, int B, int Cout, int KG)
+{
+    const int G = KG + 2;
+    const long total = (long)B * Cout * G * 8;          // 16-byte pieces
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int piece = (int)(i & 7);
+        const long grp = i >> 3;
+        const int g = (int)(grp % G);
+        const long row = grp / G;
+        const int co = (int)(row % Cout), b = (int)(row / Cout);
+        uint4 val;
+        if (g < KG) {
+            val = *reinterpret_cast<const uint4*>(wf + ((long)co * KG + g) * 128 + piece * 16);
+        } else {
+            // piece 0..3: hi of cells 8 (piece) .. + 7 of this group; 4..7: their lo
+            const int j0 = (g - KG) * 32 + (piece & 3) * 8;
+            __bf16 h8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = j0 + e;
+                float v = 0.f;
+                if (j < 1) v = z1[((long)b * 1 + j) * Cout + co];
+                else if (j < 5) v = z2[((long)b * 4 + (j - 1)) * Cout + co];
+                else if (j < 14) v = z3[((long)b * 9 + (j - 5)) * Cout + co];
+                else if (j < PSP_CELLS) v = z6[((long)b * 36 + (j - 14)) * Cout + co];
+                const __bf16 hh = (__bf16)v;
+                h8[e] = piece < 4 ? hh : (__bf16)(v - (float)hh);
+            }
+            val = *reinterpret_cast<const uint4*>(h8);
+        }
+        *reinterpret_cast<uint4*>(out + grp * 128 + piece * 16) = val;
+    }
+}
+}  // namespace
+
+extern "C" int ape_psp_fold_operands(const void* wf_s32k, const float* z1, const float* z2, const float* z3, const float* z6, void* w_out,
+                                     void* x_s32, int B, int h, int w, int ld, int Cin, int Cout, void* stream)
+{
+    if (!wf_s32k || !z1 || !z2 || !z3 || !z6 || !w_out || !x_s32 || B < 0 || h < 1 || w < 1) return APE_EINVAL;
+    if (Cin < 32 || Cin % 32 || ld < Cin + PSP_KPAD || ld % 32 || Cout < 1) return APE_EINVAL;
+    if (B == 0) return APE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const long total = (long)B * h * w * (PSP_KPAD / 4);
+        long g = (total + 255) / 256;
+        g = g > 65536 ? 65536 : g;
+        hipLaunchKernelGGL(psp_fill_coeffs_kernel, dim3((int)g), dim3(256), 0, st, (char*)x_s32, B, h, w, ld, Cin);
+    }
+    {
+        const long total = (long)B * Cout * (Cin / 32 + 2) * 8;
+        long g = (total + 255) / 256;
+        g = g > 65536 ? 65536 : g;
+        hipLaunchKernelGGL(psp_pack_weights_kernel, dim3((int)g), dim3(256), 0, st, (const char*)wf_s32k, z1, z2, z3, z6, (char*)w_out, B, Cout, Cin / 32);
+    }
+    return ape::check_launch("ape_psp_fold_operands");
 }

@@ -474,6 +474,37 @@ def psp_prior_sum(zs, h, w):
     return out
 
 
+USE_PSP_FOLD = os.environ.get("APE_USE_PSP_FOLD", "1") != "0"    # the PSP prior sum as 64 more K-columns of the bottleneck's contraction (S32 graph)
+PSP_FOLD_K = 64
+
+
+def psp_bottleneck_folded(conv, x576, zs, out_fmt=FMT_S32):
+    """relu(W_f . f + sum_s upsample(z_s) + bias) (pspnet.py:22-24 with the prior sum of :12-17 folded in) as ONE contraction over
+    K = Cin + 64: `x576` is the S32 map f[B,h,w,Cin + 64] whose last 64 channels this call fills with the pixels' bilinear coefficients,
+    `zs` = [z1[B,1,1,C], z2[B,2,2,C], z3[B,3,3,C], z6[B,6,6,C]] fp32 (the merged prior convs of the pooled maps), `conv` the bottleneck's
+    feats columns (Cin -> C, bias, ReLU).  No [B,h,w,C] prior-sum tensor is written or read (include/ape_hip.h ape_psp_fold_operands)."""
+    xt = x576.t
+    b, h, w, ld = xt.shape
+    if conv.nsplit != 3 or conv.kh != 1 or ld != conv.cin + PSP_FOLD_K or [tuple(z.shape) for z in zs] != [(b, s, s, conv.cout) for s in (1, 2, 3, 6)]:
+        raise ValueError("psp_bottleneck_folded: a split-bf16 1x1 layer, an S32 map of Cin + 64 channels and the four prior maps [B,s,s,Cout]")
+    groups = conv.cin // 32 + 2
+    wimg = torch.empty(b, conv.cout, groups * 64, dtype=torch.bfloat16, device=xt.device)
+    _lib.check(_lib.lib().ape_psp_fold_operands(_lib.dptr(conv.s32k()), *[_lib.dptr(z, torch.float32) for z in zs], _lib.dptr(wimg),
+                                                _lib.dptr(xt, torch.float32), b, h, w, ld, conv.cin, conv.cout, _st()), "ape_psp_fold_operands")
+    out = torch.empty(b, h, w, conv.cout, dtype=torch.float32, device=xt.device)
+    p = ConvParams(B=b, H=h, W=w, Cin=ld, ldx=ld, xoff=0, Ho=h, Wo=w, Cout=conv.cout, ldy=conv.cout, yoff=0, KH=1, KW=1, stride=1, pad=0, dil=1,
+                   act=conv.act, alpha=conv.alpha, bias_bstride=0, ldr=0, roff=0, ups=0)
+    label = "gemm_s32_kernel<%d>" % (128 if conv.cout <= 128 else 192 if (-(-conv.cout // 192) * 192 - conv.cout) < (-(-conv.cout // 256) * 256 - conv.cout) else 256)
+    e0 = _prof_begin(label)
+    rc = _lib.lib().ape_conv_gemm_s32_per_image(_lib.dptr(xt, torch.float32), _lib.dptr(wimg), conv.cout * groups * 128, _lib.dptr(conv.bias),
+                                                _lib.dptr(out), out_fmt, ctypes.byref(p), _st())
+    _lib.check(rc, "ape_conv_gemm_s32_per_image")
+    if e0 is not None:      # algorithmic: the layer's own contraction (K = Cin) + the prior sum's 50 coefficient columns; bytes: f in, out, per-frame weights
+        _prof_end(e0, label, "%dx%dx%d %d+%d->%d k1 s1 d1 psp-fold" % (b, h, w, conv.cin, PSP_FOLD_K, conv.cout), 2.0 * b * h * w * conv.cout * ld,
+                  4.0 * (b * h * w * ld + b * conv.cout * ld + b * h * w * conv.cout))
+    return S32(out) if out_fmt == FMT_S32 else out
+
+
 USE_UPFUSE = os.environ.get("APE_USE_UPFUSE", "1") != "0"    # 64-channel PSPUpsample layers on S32 inputs as ONE kernel (upconv_fused.hip)
 
 

@@ -105,6 +105,19 @@ int ape_conv3x3_halo_s32_debug(int bits);   /* 1 = with a static wave priority f
 int ape_conv_gemm_s32_debug(int bits);   /* timing ablations (tools/mb_gemm_s32.py); 0 = off, anything else breaks the results */
 int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
                       int out_fmt, const ape_conv_params* params_host, void* stream);
+/* The same contraction with PER-IMAGE weights: image i of the batch (params->H * params->W rows) multiplies with the S32K matrix at
+ * w_s32k + i * w_image_stride_bytes (a multiple of 16), and no 256-row tile holds rows of two images.  No residual operand.
+ * Used by the PSP module (DenseFusion/lib/pspnet.py:12-24), whose prior sum is folded into the bottleneck's contraction:
+ * ape_psp_fold_operands builds both operands' extra 64 K-columns -- channels [Cin, Cin + 64) of every pixel of x_s32 (ld >= Cin + 64
+ * channels per pixel) get the pixel's bilinear (align_corners = False) coefficients of the 1 + 4 + 9 + 36 prior cells, and
+ * w_out[B][Cout][Cin/32 + 2 groups] gets the shared weights wf_s32k[Cout][Cin/32 groups] followed by frame b's prior values
+ * z_s[b][cell][co] (z1..z6: the merged stage x bottleneck-column convs of the pooled maps, fp32 [B][s][s][Cout]) -- so that
+ *     relu(W_f . f + sum_s upsample(Z_s) + bias)  ==  ape_conv_gemm_s32_per_image over K = Cin + 64
+ * and the 4 * B * h * w * Cout-byte prior-sum tensor (ape_psp_prior_sum_f32) is neither written nor read back. */
+int ape_conv_gemm_s32_per_image(const void* x_s32, const void* w_s32k, long w_image_stride_bytes, const float* bias, void* y, int out_fmt,
+                                const ape_conv_params* params_host, void* stream);
+int ape_psp_fold_operands(const void* wf_s32k, const float* z1, const float* z2, const float* z3, const float* z6, void* w_out, void* x_s32,
+                          int B, int h, int w, int ld, int Cin, int Cout, void* stream);
 /* Format-aware forms of three fp32 entry points, for the tensors that cross between fp32 and S32 kernels: ape_conv_gemm_bf16 with the
  * OUTPUT in either format (the stride-2 convs that feed the first S32 3x3 layer), ape_adaptive_avgpool_multi_nhwc_f32 with the INPUT
  * in either format (the PSP pools of the S32 layer-4 map), ape_upconv3x3_gather_f32 with the OUTPUT in either format (up_1's result

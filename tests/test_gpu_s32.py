@@ -131,3 +131,57 @@ def test_s32_path_rejects_what_it_cannot_run():
         E.Conv(torch.randn(128, 64, 3, 3), None, 2, 1, 1, device="cuda", precision="bf16x3")(x)      # ... and stride 1
     with pytest.raises(ValueError):
         E.S32(torch.zeros(1, 8, 8, 48, device="cuda"))
+
+
+# (B, h, w, Cin, Cout): rows per image below one tile, ragged last tiles, the segmentor's map (4800 rows = 18.75 tiles), more tiles than CUs
+@pytest.mark.parametrize("shape", [(3, 12, 16, 128, 256), (2, 33, 61, 512, 1024), (5, 60, 80, 512, 1024), (20, 60, 80, 128, 192)])
+@pytest.mark.parametrize("out_s32", [False, True])
+def test_gemm_s32_per_image_equals_one_call_per_image_bitwise(shape, out_s32):
+    """ape_conv_gemm_s32_per_image: image i multiplies with the weights at w + i * stride and no tile holds rows of two images -- i.e. it is
+    the one-image call repeated, bit for bit (same tiles, same k order)."""
+    import ctypes
+    from autoposeestimation_amd import _lib, engine as E
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(cin + 3 * cout + h)
+    xs = E.S32.from_f32((torch.randn(b, h, w, cin, generator=g) * 3).cuda())
+    bias = torch.randn(cout, generator=g).cuda()
+    convs = [E.Conv(torch.randn(cout, cin, generator=g) / cin ** 0.5, bias, act=E.ACT_RELU, device="cuda", precision="bf16x3") for _ in range(b)]
+    fmt = E.FMT_S32 if out_s32 else E.FMT_F32
+    want = torch.stack([(convs[i](xs[i:i + 1], out_fmt=fmt).t if out_s32 else convs[i](xs[i:i + 1]))[0] for i in range(b)])
+    wall = torch.stack([c.s32k() for c in convs]).contiguous()              # [B][Cout * K * 2] bf16
+    got = torch.empty(b, h, w, cout, dtype=torch.float32, device="cuda")
+    p = E.ConvParams(B=b, H=h, W=w, Cin=cin, ldx=cin, xoff=0, Ho=h, Wo=w, Cout=cout, ldy=cout, yoff=0, KH=1, KW=1, stride=1, pad=0, dil=1,
+                     act=E.ACT_RELU, alpha=0.0, bias_bstride=0, ldr=0, roff=0, ups=0)
+    rc = _lib.lib().ape_conv_gemm_s32_per_image(_lib.dptr(xs.t, torch.float32), _lib.dptr(wall), cout * cin * 4, _lib.dptr(bias), _lib.dptr(got), fmt,
+                                                ctypes.byref(p), _lib.stream_ptr())
+    assert rc == 0
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert _lib.lib().ape_conv_gemm_s32_per_image(_lib.dptr(xs.t, torch.float32), _lib.dptr(wall), 0, _lib.dptr(bias), _lib.dptr(got), fmt,
+                                                  ctypes.byref(p), _lib.stream_ptr()) != 0          # a stride is required
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 16), (3, 33, 61), (4, 60, 80), (1, 7, 5)])
+def test_psp_bottleneck_with_the_prior_sum_folded_into_k(shape):
+    """pspnet.py:12-24: relu(W_f . f + sum_s upsample(z_s) + b).  Folded form (engine.psp_bottleneck_folded: 50 coefficient columns appended
+    to K, per-frame weight rows) against (a) the two-kernel form -- ape_psp_prior_sum_f32 as the residual of ape_conv_gemm_s32 -- within the
+    split-bf16 operand error of the extra columns, (b) float64: F.interpolate(bilinear, align_corners=False) of the priors + the 1x1 conv."""
+    from autoposeestimation_amd import engine as E
+    b, h, w = shape
+    cin, cout = 512, 1024
+    g = torch.Generator().manual_seed(h * 100 + w)
+    f = (torch.randn(b, h, w, cin, generator=g) * 2).cuda()
+    zs = [torch.randn(b, s, s, cout, generator=g).cuda() for s in (1, 2, 3, 6)]
+    conv = E.Conv(torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g), act=E.ACT_RELU, device="cuda", precision="bf16x3")
+    fs = E.S32.from_f32(f)
+    want = conv(fs, residual=E.psp_prior_sum(zs, h, w), out_fmt=E.FMT_S32).to_f32()
+    f576 = torch.full((b, h, w, cin + E.PSP_FOLD_K), float("nan"), dtype=torch.float32, device="cuda")     # (the spare channels start as garbage)
+    f576[..., :cin] = fs.t
+    got = E.psp_bottleneck_folded(conv, E.S32(f576), zs).to_f32()
+    assert torch.equal(f576[..., :cin], fs.t)                                    # the map's own channels are untouched
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 3e-5 * scale
+    ref = torch.einsum("bhwc,oc->bhwo", fs.to_f32().double(), conv.w.view(cout, -1)[:, :cin].double()) + conv.bias.double()
+    for z in zs:
+        ref = ref + F.interpolate(z.double().permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    ref = F.relu(ref)
+    assert (got.double() - ref).abs().max().item() <= 5e-5 * ref.abs().max().item()

@@ -1,0 +1,8 @@
+"""bench.py with the kernels' debug bits set from the environment (GEMM_DBG, HALO_DBG): same-box A/B of kernel variants in the whole loop"""
+import os, sys, runpy
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from autoposeestimation_amd import _lib
+_lib.lib().ape_conv_gemm_s32_debug(int(os.environ.get("GEMM_DBG", "0")))
+_lib.lib().ape_conv3x3_halo_s32_debug(int(os.environ.get("HALO_DBG", "0")))
+sys.argv = ["bench.py"] + sys.argv[1:]
+runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
