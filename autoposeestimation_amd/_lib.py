@@ -18,6 +18,7 @@ SIGNATURES = {
     "ape_abi_version": [],
     "ape_last_error": [],
     "ape_knn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ape_knn_debug": [_I],
     "ape_conv2d_nhwc_f32": [_P, _P, _P, _P, _P, _P, _P],
     "ape_packed_weights_bf16_elems": [_I, _I],
     "ape_pack_weights_bf16": [_P, _P, _I, _I, _P],
@@ -66,6 +67,7 @@ SIGNATURES = {
     "ape_pose_compose_f64": [_P, _P, _I, _P, _I, _I, _P],
     "ape_pose_recentre_f32": [_P, _P, _P, _I, _I, _P],
     "ape_adds_dis_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "ape_adds_dis_batched_f32": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "ape_adds_select_f32": [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P],
     "ape_recentre_qt_f32": [_P, _P, _P, _I, _P],
     "ape_seg_argmax_f32": [_P, _I, _I, _P, _P, _c.c_long, _I, _P],

@@ -267,6 +267,67 @@ __global__ __launch_bounds__(kT) void adds_grad_kernel(const float* __restrict__
     }
 }
 
+// ---- the evaluation of a BATCH of objects (ape_adds_dis_batched_f32): one workgroup per object leaves 7/8 of the chip idle at 32 objects, so
+// the pair evaluations are spread like the k-NN kernel spreads them -- S lanes per predicted point, (distance, index) merged by wave
+// shuffles with "lowest index wins" -- and the per-object mean is a second, tiny launch that adds in adds_dis_kernel's own order (thread t
+// sums points t, t + 256, ...; block_sum), so dis[b] is bit for bit what ape_adds_dis_f32 gives for that object alone.
+template <int S>
+__global__ __launch_bounds__(kT) void adds_points_kernel(const float* __restrict__ pred_r, const float* __restrict__ pred_t,
+                                                         const float* __restrict__ model, const float* __restrict__ target, int M,
+                                                         int symmetric, float* __restrict__ dist_out)
+{
+    extern __shared__ float4 tgt[];   // this object's M targets
+    const int b = blockIdx.y;
+    model += (size_t)b * M * 3;
+    target += (size_t)b * M * 3;
+    for (int m = threadIdx.x; m < M; m += kT) tgt[m] = make_float4(target[m * 3], target[m * 3 + 1], target[m * 3 + 2], 0.f);
+    float q[4], R[9];
+    normalise4(pred_r + (size_t)b * 4, q);
+    quat_base(q[0], q[1], q[2], q[3], R);
+    const float tx = pred_t[b * 3], ty = pred_t[b * 3 + 1], tz = pred_t[b * 3 + 2];
+    __syncthreads();
+    const int s = threadIdx.x % S;
+    const int m = blockIdx.x * (kT / S) + threadIdx.x / S;
+    const int mc = m < M ? m : M - 1;
+    const float mx = model[mc * 3], my = model[mc * 3 + 1], mz = model[mc * 3 + 2];
+    const float px = ((mx * R[0] + my * R[1]) + mz * R[2]) + tx;
+    const float py = ((mx * R[3] + my * R[4]) + mz * R[5]) + ty;
+    const float pz = ((mx * R[6] + my * R[7]) + mz * R[8]) + tz;
+    int bi = mc;
+    if (symmetric) {
+        float best = __builtin_inff();
+        bi = s;
+        for (int r = s; r < M; r += S) {
+            const float4 c = tgt[r];
+            const float dx = c.x - px, dy = c.y - py, dz = c.z - pz;
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (d < best) { best = d; bi = r; }
+        }
+#pragma unroll
+        for (int off = S / 2; off > 0; off >>= 1) {
+            const float od = __shfl_xor(best, off);
+            const int oi = __shfl_xor(bi, off);
+            if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+        }
+        if (bi >= M) bi = M - 1;        // (only when M < S: lanes without a ref keep their start index)
+    }
+    if (s == 0 && m < M) {
+        const float4 t = tgt[bi];
+        const float dx = px - t.x, dy = py - t.y, dz = pz - t.z;
+        dist_out[(size_t)b * M + m] = sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
+}
+
+__global__ __launch_bounds__(kT) void adds_mean_kernel(const float* __restrict__ dist, int M, float* __restrict__ dis)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += kT) s += dist[(size_t)b * M + m];
+    const float mean = block_sum(s, red) / (float)M;
+    if (threadIdx.x == 0) dis[b] = mean;
+}
+
 }  // namespace
 
 extern "C" int ape_adds_dis_f32(const float* pred_r, const float* pred_t, const float* points, const float* model,
@@ -278,6 +339,27 @@ extern "C" int ape_adds_dis_f32(const float* pred_r, const float* pred_t, const 
     hipLaunchKernelGGL(adds_dis_kernel, dim3(N), dim3(kT), (size_t)M * sizeof(float4), (hipStream_t)stream, pred_r, pred_t, points,
                        model, target, M, symmetric, pred_out, dis, stdv);
     return ape::check_launch("ape_adds_dis_f32");
+}
+
+extern "C" int ape_adds_dis_batched_f32(const float* pred_r, const float* pred_t, const float* model, const float* target, int B, int M,
+                                        int symmetric, float* workspace, float* dis, void* stream)
+{
+    if (!pred_r || !pred_t || !model || !target || !workspace || !dis || B < 0 || M < 1 || M > 8192) return APE_EINVAL;   // 16 B * M of LDS
+    if (B == 0) return APE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // lanes per predicted point: enough wavefronts to fill 256 CUs (as ape_knn_f32 chooses S)
+    int S = 1;
+    while (S < 64 && (long)B * M * S < 256L * 8 * 64 && S * 4 <= M) S *= 4;
+    const size_t lds = (size_t)M * sizeof(float4);
+    dim3 grid(ape::ceil_div(M, kT / S), B);
+    switch (S) {
+        case 1: hipLaunchKernelGGL(adds_points_kernel<1>, grid, dim3(kT), lds, st, pred_r, pred_t, model, target, M, symmetric, workspace); break;
+        case 4: hipLaunchKernelGGL(adds_points_kernel<4>, grid, dim3(kT), lds, st, pred_r, pred_t, model, target, M, symmetric, workspace); break;
+        case 16: hipLaunchKernelGGL(adds_points_kernel<16>, grid, dim3(kT), lds, st, pred_r, pred_t, model, target, M, symmetric, workspace); break;
+        default: hipLaunchKernelGGL(adds_points_kernel<64>, grid, dim3(kT), lds, st, pred_r, pred_t, model, target, M, symmetric, workspace); break;
+    }
+    hipLaunchKernelGGL(adds_mean_kernel, dim3(B), dim3(kT), 0, st, workspace, M, dis);
+    return ape::check_launch("ape_adds_dis_batched_f32");
 }
 
 extern "C" int ape_adds_select_f32(const float* dis, const float* stdv, const float* pred_c, const float* pred_r,

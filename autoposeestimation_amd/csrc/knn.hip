@@ -10,6 +10,13 @@
 //       wavefronts to fill 256 CUs even for 1000 queries); lane s scans refs s, s+S, ... in ascending
 //       order with a strict '<', then the S partial minima are merged by wave shuffles with the
 //       (distance, index) lexicographic rule -> exactly "lowest index wins ties" (knn_cpu.cpp:30).
+//   knn1_d3_q<Q>  (the same, for query counts that fill the chip many times over -- the training loss's 10^6 queries, loss.py:38-47): one
+//     lane owns Q queries, so one (broadcast) ds_read_b128 of a ref feeds Q pair evaluations.  knn1_d3<1> reads 16 B from LDS per pair:
+//     4 LDS cycles per wave and pair against 22 VALU cycles per SIMD, four SIMDs on one LDS -- the LDS port is ~3/4 as busy as the
+//     vector units and the two limits meet (0.48 of the fp32 VALU rate, round 1); with Q = 4 the LDS share falls to a fifth of that.
+//     Same arithmetic per pair, same ascending scan with a strict '<' => the same indices bit for bit.  (Packed fp32 instructions do not
+//     help: v_pk_mul_f32 / v_pk_add_f32 issue at half the rate of their scalar forms on gfx950 -- two results per instruction, four
+//     cycles per wave -- MI355X_MICROARCH.md "price of one filler beside MFMAs".)
 //   knn_general  (any dim, any k <= ref_nb): one query per lane, stable insertion into a 64-entry list, ceil(k / 64) passes.
 //
 // Bit-exactness: d = ((dx*dx) + (dy*dy)) + (dz*dz) with __fmul_rn/__fadd_rn (no FMA contraction), the
@@ -67,6 +74,51 @@ __global__ __launch_bounds__(kBlock) void knn1_d3(const float* __restrict__ ref,
     if (valid && s == 0) idx[q] = (int64_t)besti + 1;
 }
 
+template <int Q>
+__global__ __launch_bounds__(kBlock) void knn1_d3_q(const float* __restrict__ ref, const float* __restrict__ query,
+                                                    int64_t* __restrict__ idx, int ref_nb, int query_nb)
+{
+    __shared__ float4 tile[kTile];
+    const int b = blockIdx.y;
+    ref += (size_t)b * 3 * ref_nb;
+    query += (size_t)b * 3 * query_nb;
+    idx += (size_t)b * query_nb;
+    // query j of this lane: blockIdx.x * Q * kBlock + j * kBlock + threadIdx.x (consecutive lanes = consecutive queries: coalesced)
+    const int q0 = blockIdx.x * (Q * kBlock) + threadIdx.x;
+    float qx[Q], qy[Q], qz[Q], best[Q];
+    int besti[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int q = q0 + j * kBlock;
+        const int qc = q < query_nb ? q : query_nb - 1;
+        qx[j] = query[qc]; qy[j] = query[query_nb + qc]; qz[j] = query[2 * (size_t)query_nb + qc];
+        best[j] = __builtin_inff();
+        besti[j] = 0;
+    }
+    for (int t0 = 0; t0 < ref_nb; t0 += kTile) {
+        const int n = min(kTile, ref_nb - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock)
+            tile[i] = make_float4(ref[t0 + i], ref[ref_nb + t0 + i], ref[2 * (size_t)ref_nb + t0 + i], 0.f);
+        __syncthreads();
+#pragma unroll 2
+        for (int r = 0; r < n; ++r) {
+            const float4 p = tile[r];               // every lane reads the same address: one broadcast
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
+                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                if (d < best[j]) { best[j] = d; besti[j] = t0 + r; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        const int q = q0 + j * kBlock;
+        if (q < query_nb) idx[q] = (int64_t)besti[j] + 1;
+    }
+}
+
 constexpr int kMaxK = 64;
 
 __global__ __launch_bounds__(kBlock) void knn_general(const float* __restrict__ ref, const float* __restrict__ query,
@@ -114,6 +166,8 @@ __global__ __launch_bounds__(kBlock) void knn_general(const float* __restrict__ 
     }
 }
 
+int g_knn_q = 0;        // ape_knn_debug: 1 = never the four-queries-per-lane form (A/B and bitwise tests)
+
 template <int S>
 void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, int ref_nb, int query_nb, hipStream_t st)
 {
@@ -122,6 +176,8 @@ void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, 
 }
 
 }  // namespace
+
+extern "C" int ape_knn_debug(int one_query_per_lane) { g_knn_q = one_query_per_lane ? 1 : 0; return APE_OK; }
 
 extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
                            int batch, int dim, int ref_nb, int query_nb, int k, void* stream)
@@ -136,6 +192,12 @@ extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
         const long total = (long)batch * query_nb;
         int s = 1;
         while (s < 64 && total * s < target && s * 4 <= ref_nb) s *= 4;
+        // enough queries to give every lane four of them and still fill the chip (8 waves per CU): the Q = 4 form
+        if (s == 1 && g_knn_q != 1 && total >= 4 * target && query_nb >= 4 * kBlock) {
+            dim3 grid(ape::ceil_div(query_nb, 4 * kBlock), batch);
+            hipLaunchKernelGGL(knn1_d3_q<4>, grid, dim3(kBlock), 0, st, ref, query, idx, ref_nb, query_nb);
+            return ape::check_launch("ape_knn_f32");
+        }
         switch (s) {
             case 1: launch_knn1<1>(ref, query, idx, batch, ref_nb, query_nb, st); break;
             case 4: launch_knn1<4>(ref, query, idx, batch, ref_nb, query_nb, st); break;

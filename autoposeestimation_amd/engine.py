@@ -811,6 +811,17 @@ def adds_dis(pred_r, pred_t, points, model, target, symmetric, want_pred=False, 
     return dis, std, pred
 
 
+def adds_dis_batched(pred_r, pred_t, model, target, symmetric):
+    """pred_r[B,4], pred_t[B,3], model[B,M,3], target[B,M,3] -> dis[B]: ADD / ADD-S of B objects, each against its own clouds, in one launch"""
+    b, m = model.shape[0], model.shape[1]
+    dis = torch.empty(b, dtype=torch.float32, device=model.device)
+    ws = torch.empty(b, m, dtype=torch.float32, device=model.device)          # per-point distances (the mean is a second launch)
+    rc = _lib.lib().ape_adds_dis_batched_f32(_lib.dptr(pred_r, torch.float32), _lib.dptr(pred_t, torch.float32), _lib.dptr(model, torch.float32),
+                                             _lib.dptr(target, torch.float32), b, m, int(bool(symmetric)), _lib.dptr(ws), _lib.dptr(dis), _st())
+    _lib.check(rc, "ape_adds_dis_batched_f32")
+    return dis
+
+
 def adds_select(dis, std, pred_c, pred_r, pred_t, points, w):
     """-> out9 (loss, dis[which], q[4], t[3]) f32 on device, which i32[1]"""
     out = torch.empty(9, dtype=torch.float32, device=dis.device)

@@ -558,6 +558,217 @@ def label_main(args, rank, world, device, dist):
         dist.destroy_process_group()
 
 
+PEAK_F32_LANE_OPS = 256 * 4 * 32 * 2.4e9 / 1e12     # T lane-operations/s: 256 CUs x 4 SIMD-32 at 2.4 GHz, one fp32 VALU operation per lane and cycle
+KNN_LANE_OPS_PER_PAIR = 11                           # 3 sub, 3 mul, 2 add, 1 compare, 2 selects (csrc/knn.hip; the reference's arithmetic, no FMA)
+
+
+def pose_main(args, rank, world, device, dist):
+    """BASELINE configs[1]: PoseNet + 2 x PoseRefineNet on --crops 160x160 crops per GPU and step (N = 1000 points), then ADD-S of every
+    refined pose against its ground-truth cloud through the hand-written k-NN / ADD-S kernel (1000 x 1000 pair evaluations per crop,
+    eval_linemod.py:118-130).  A step = FramePipeline.poses (choose / back-projection / crop normalisation / PoseNet / pose selection /
+    two refiner passes / float64 composition) + ape_adds_dis_batched_f32 + the single all_gather of (class, q, t, ADD-S) per crop.
+    Inputs (u8 frames, u16 depth, the object map and its detections) are resident in HBM; crops shard over the ranks (weak scaling).
+    Secondary object `knn_training_size`: ape_knn_f32 at the training loss's size, 10^6 queries x 1000 refs (loss.py:38-47)."""
+    from autoposeestimation_amd.pipeline.utils import FramePipeline
+    from autoposeestimation_amd.DenseFusion.lib.network import PoseNet, PoseRefineNet
+    from autoposeestimation_amd.DenseFusion.lib.knn import KNearestNeighbor
+    from autoposeestimation_amd.sharding import gather_results
+    n = args.crops
+    est_sd, ref_sd = S.posenet_state_dict(12, 0), S.refiner_state_dict(12, 0)
+    est, ref = PoseNet(N_POINTS, 12), PoseRefineNet(N_POINTS, 12)
+    est.load_state_dict(est_sd)
+    ref.load_state_dict(ref_sd)
+    est, ref = est.to(device).eval().set_precision(args.pose_precision), ref.to(device).eval().set_precision(args.pose_precision)
+    frames = make_frames(n, rank)
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).to(device)
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).to(device)
+    label = torch.from_numpy(np.stack([f[2] for f in frames]).astype(np.uint8)).to(device)
+    pipe = FramePipeline(None, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat")
+    # detections of the painted objects from the label maps themselves (the product's own component / bbox kernels; no segmentor here)
+    objmap, det = E.seg_components(label, torch.ones(label.shape, dtype=torch.float32, device=device), len(CLASSES) + 1, 100)
+    det_h = det.cpu().numpy()
+    fb, fc = np.nonzero(det_h[:, 1:, 0])
+    objects = [(int(b), int(c) + 1, *map(int, det_h[b, c + 1, 1:5])) for b, c in zip(fb, fc)]
+    assert len(objects) == n and all((o[3] - o[2], o[5] - o[4]) == (160, 160) for o in objects), "one 160x160 crop per frame expected"
+    cls_t = torch.tensor([o[1] for o in objects], dtype=torch.float32, device=device)
+    model = torch.from_numpy(np.stack([S.model_cloud(o[1]) for o in objects])).to(device)           # [n, 1000, 3] (0.1 m cubes, per class)
+
+    def step(seed, target, timed=None):
+        pose, n_cand, choose = pipe.poses(rgb, depth, objmap, objects, S.REALSENSE_META, seed=seed)
+        q, t = pose[:, :4].float().contiguous(), pose[:, 4:].float().contiguous()
+        if timed is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dis = E.adds_dis_batched(q, t, model, target, True)
+        if timed is not None:
+            e1.record()
+            timed.append((e0, e1))
+        block = torch.cat([cls_t[:, None], pose.float(), dis[:, None]], 1)[:, None, :]            # [n, 1, 9]
+        return pose, choose, dis, gather_results(block, dist)
+
+    # ground truth of every crop: the first run's pose turned by 3 degrees about a seeded axis and moved by 3 mm (ADD-S in millimetres)
+    pose0, _, _, _ = step(0, model)
+    p0 = pose0.cpu().numpy()
+    targets = []
+    for k, o in enumerate(objects):
+        rng = np.random.default_rng([77, rank, k])
+        axis = rng.standard_normal(3)
+        axis /= np.linalg.norm(axis)
+        half = np.deg2rad(3.0) / 2
+        R_gt = _quat_matrix(p0[k, :4]) @ _quat_matrix(np.concatenate([[np.cos(half)], np.sin(half) * axis]))
+        stp = rng.standard_normal(3)
+        t_gt = p0[k, 4:] + 0.003 * stp / np.linalg.norm(stp)
+        targets.append((S.model_cloud(o[1]).astype(np.float64) @ R_gt.T + t_gt).astype(np.float32))
+    target = torch.from_numpy(np.stack(targets)).to(device)
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, target)
+    fence()
+    timed = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pose, choose, dis, gathered = step(args.warmup + i, target, timed)
+    fence()
+    dt = time.perf_counter() - t0
+    adds_ms = sum(a.elapsed_time(b) for a, b in timed) / max(len(timed), 1)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+    if rank == 0:
+        m = model.shape[1]
+        pairs = n * m * m
+        ach = pairs * KNN_LANE_OPS_PER_PAIR / (adds_ms * 1e-3) / 1e12
+        # after the timed region: every conv launch of one step timed (the MFMA side of the workload), and the k-NN kernel at training size
+        prof = E.LaunchProfile()
+        E.PROFILE = prof
+        step(args.warmup + args.steps, target)
+        torch.cuda.synchronize()
+        E.PROFILE = None
+        top = sorted(prof.summary().items(), key=lambda kv: -kv[1]["ms"])[:3]
+        mfma = []
+        for lab, d in top:
+            bound, peak, unit = kernel_peak(lab)
+            a_ = (d["bytes"] / (d["ms"] * 1e-3) / 1e9) if bound == "hbm" else (d["flop"] / (d["ms"] * 1e-3) / 1e12)
+            mfma.append({"kernel": lab, "bound": bound, "launches": d["launches"], "ms_per_step": round(d["ms"], 3), "achieved": round(a_, 2),
+                         "peak": round(peak, 1), "unit": unit, "frac": round(a_ / peak, 4)})
+        knn = KNearestNeighbor(1)
+        kref, kqry = torch.randn(1, 3, 1000, device=device), torch.randn(1, 3, 1_000_000, device=device)
+        knn(kref, kqry)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            knn(kref, kqry)
+        e1.record()
+        torch.cuda.synchronize()
+        knn_ms = e0.elapsed_time(e1) / 10
+        knn_ach = 1e9 * KNN_LANE_OPS_PER_PAIR / (knn_ms * 1e-3) / 1e12
+        line = {"metric": "crops/sec (PoseNet + 2 x PoseRefineNet + ADD-S via the HIP k-NN / ADD-S kernel), 160x160 crops, N=1000",
+                "value": round(n * world * args.steps / dt, 2), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.pose_precision, "data": "synthetic",
+                "config": {"workload": "configs[1]: PoseNet + PoseRefineNet (2 iterations) on %d crops of 160x160 per GPU and step, N = 1000 points, "
+                                       "ADD-S of every refined pose against a 1000-point ground-truth cloud" % n,
+                           "inputs": "u8 frames, u16 depth, object map and detections resident in HBM, the same crops every step",
+                           "parallelism": "dp%d (crops shard over the ranks, one all_gather of [crops, 1, 9] per step)" % world},
+                "ranks_seen": args.ranks_seen, "distinct_gpus": len({tuple(r[1:3]) for r in args.ranks_seen}),
+                "roofline": {"kernel": "adds_points_kernel + adds_mean_kernel (symmetric: the k-NN kernel's pair evaluation, M x M per object)", "bound": "valu",
+                             "achieved": round(ach, 3), "peak": round(PEAK_F32_LANE_OPS, 1), "unit": "T lane-op/s", "frac": round(ach / PEAK_F32_LANE_OPS, 4),
+                             "traffic": None, "avg_launch_us": round(adds_ms * 1e3, 1), "pairs_per_launch": pairs,
+                             "share_of_step_time": round(adds_ms * 1e-3 / (dt / args.steps), 4),
+                             "note": "algorithmic work = objects x M x M pair evaluations x %d fp32 lane-operations (3 sub, 3 mul, 2 add, compare, 2 "
+                                     "selects: the reference's arithmetic, which the bit-exact index contract fixes); peak = 256 CUs x 4 SIMD-32 x 2.4 GHz; "
+                                     "time = HIP events around the two launches, every step of the timed region, on their stream.  %d objects x "
+                                     "10^6 pairs are ~10 us of vector work for the whole chip: the pair of launches is latency-bound -- "
+                                     "`knn_training_size` is the same arithmetic at a size that fills the chip"
+                                     % (KNN_LANE_OPS_PER_PAIR, n),
+                             "kernels": mfma},
+                "knn_training_size": {"kernel": "knn1_d3_q<4>", "refs": 1000, "queries": 1000000, "ms": round(knn_ms, 4),
+                                      "pairs_per_s": round(1e9 / (knn_ms * 1e-3), 0), "bound": "valu", "achieved": round(knn_ach, 3),
+                                      "peak": round(PEAK_F32_LANE_OPS, 1), "unit": "T lane-op/s", "frac": round(knn_ach / PEAK_F32_LANE_OPS, 4)},
+                "adds_mean_m": round(float(dis.mean()), 6)}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"], line["parity"] = pose_cpu_baseline(frames, objects, est_sd, ref_sd, choose.cpu().numpy(), pose.cpu().numpy(),
+                                                                     dis.cpu().numpy(), targets, device)
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _quat_matrix(q):
+    """3x3 rotation of a wxyz quaternion (transformations.py:1254-1278), float64"""
+    from autoposeestimation_amd.DenseFusion.lib.transformations import quaternion_matrix
+    return quaternion_matrix(np.asarray(q, np.float64))[:3, :3]
+
+
+def pose_cpu_baseline(frames, objects, est_sd, ref_sd, choose, pose_gpu, dis_gpu, targets, device, n_crops=4):
+    """The oracle on the first `n_crops` crops of the same workload, one thread: PoseNet + 2 refiner forwards + composition
+    (oracle/densefusion_oracle.py, pinned by the reference goldens) + ADD-S with the nearest neighbours from oracle/liboracle_knn.so (the
+    plain-C restatement of knn_cpu.cpp, pinned by the reference object).  Doubles as the checker: pose within 1e-4, the HIP k-NN's
+    indices bit for bit the oracle's, ADD-S within 1e-4 m."""
+    import ctypes
+    from oracle import densefusion_oracle as O
+    from autoposeestimation_amd.DenseFusion.lib.knn import KNearestNeighbor
+    model_name, phys, usable = _cpu_info()
+    olib = ctypes.CDLL(os.path.join(REPO, "oracle", "liboracle_knn.so"))
+    olib.oracle_knn.restype = ctypes.c_int
+    olib.oracle_knn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_long] * 5
+    old = torch.get_num_threads()
+    torch.set_num_threads(1)
+    n_crops = min(n_crops, len(objects))
+    max_dq = max_dt = adds_delta = 0.0
+    knn_equal = True
+    t0 = time.time()
+    for k in range(n_crops):
+        fi, cls, rmin, rmax, cmin, cmax = objects[k]
+        rgb, depth, _ = frames[fi]
+        ch = choose[k].astype(np.int64)
+        pts = torch.from_numpy(O.backproject(depth, ch, rmin, rmax, cmin, cmax, S.REALSENSE_META)).unsqueeze(0)
+        img = O.crop_image(rgb, rmin, rmax, cmin, cmax)
+        cht = torch.from_numpy(ch).view(1, 1, -1)
+        idx = torch.tensor([[cls - 1]])
+        with torch.no_grad():
+            pr, pt, pc, emb = O.posenet_forward(est_sd, img, pts, cht, idx, 12)
+            newp = O.get_new_points(pr, pt, pc, pts)
+            _, my_r, my_t = O.estimator_prediction(pr, pt, pc, N_POINTS, 1, pts)
+            for _ in range(2):
+                rr, rt = O.refiner_forward(ref_sd, newp, emb, idx, 12)
+            _, want_r, want_t = O.refined_prediction(rr, rt, my_r, my_t)
+        want_r, want_t = np.asarray(want_r, np.float64), np.asarray(want_t, np.float64)
+        # ADD-S of the oracle's pose, neighbours from the C restatement of the reference's k-NN
+        mc = S.model_cloud(cls)
+        pred = (mc.astype(np.float64) @ O.quaternion_matrix(want_r)[:3, :3].T + want_t).astype(np.float32)
+        tgt = targets[k]
+        ref_a, qry_a = np.ascontiguousarray(tgt.T[None]), np.ascontiguousarray(pred.T[None])
+        inds = np.zeros((1, 1, pred.shape[0]), np.int64)
+        assert olib.oracle_knn(ref_a.ctypes.data, qry_a.ctypes.data, inds.ctypes.data, 1, 3, tgt.shape[0], pred.shape[0], 1) == 1
+        c_dis = float(np.mean(np.linalg.norm(pred - tgt[inds[0, 0] - 1], axis=1)))
+        if k == 0:
+            dt_first = time.time() - t0
+        # the checker half (not part of the CPU timing's meaning, but cheap): HIP k-NN on the same clouds, pose and ADD-S deltas
+        got = KNearestNeighbor(1)(torch.from_numpy(ref_a).to(device), torch.from_numpy(qry_a).to(device)).cpu().numpy()
+        knn_equal = knn_equal and bool(np.array_equal(got, inds))
+        q = pose_gpu[k, :4] if np.dot(pose_gpu[k, :4], want_r) >= 0 else -pose_gpu[k, :4]
+        max_dq = max(max_dq, float(np.abs(q - want_r).max()))
+        max_dt = max(max_dt, float(np.abs(pose_gpu[k, 4:] - want_t).max()))
+        adds_delta = max(adds_delta, abs(float(dis_gpu[k]) - c_dis))
+    dt = time.time() - t0
+    torch.set_num_threads(old)
+    base = {"value": round(n_crops / dt, 4), "unit": "crops/s", "cores": 1, "kind": "port", "cpu_model": model_name, "physical_cores": phys,
+            "sample": "%d of the benchmark's crops through oracle/densefusion_oracle (PoseNet + 2 refiner forwards + composition, torch CPU fp32, one "
+                      "thread) + ADD-S with oracle/liboracle_knn.so's neighbours (includes the checker's HIP k-NN call per crop)" % n_crops}
+    parity = {"crops": n_crops, "max_dq": max_dq, "max_dt": max_dt, "tolerance": 1e-4, "adds_delta_m": adds_delta,
+              "knn_indices_bit_exact": knn_equal, "checker": "oracle/densefusion_oracle + oracle/liboracle_knn.so on the cpu_baseline sample"}
+    return base, parity
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -568,10 +779,12 @@ def main():
                     help="BASELINE configs[3]: a step = this many frames in TOTAL, sharded over the ranks (strong scaling; each rank "
                          "walks its share in sub-batches of --batch) with one all_gather of all poses per step.  0 = configs[2], "
                          "--batch frames per GPU per step (weak scaling)")
-    ap.add_argument("--workload", default="frames", choices=["frames", "label"],
+    ap.add_argument("--workload", default="frames", choices=["frames", "label", "pose"],
                     help="frames: the live path (BASELINE metric).  label: configs[4], pose-label generation -- multi-view depth -> "
-                         "point-cloud fusion + point-to-plane ICP over --views synthetic views, sharded across the ranks")
+                         "point-cloud fusion + point-to-plane ICP over --views synthetic views, sharded across the ranks.  pose: configs[1], "
+                         "PoseNet + 2 x PoseRefineNet + ADD-S (HIP k-NN / ADD-S kernel) on --crops 160x160 crops per GPU")
     ap.add_argument("--views", type=int, default=200, help="--workload label: views per step (one (object, direction) chain)")
+    ap.add_argument("--crops", type=int, default=32, help="--workload pose (BASELINE configs[1]): 160x160 crops per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfiltered-frames", action="store_true",
                     help="time the first --batch random frames of each rank as they come (about 1 in 100 carries a stray blob or a clipped "
@@ -629,6 +842,8 @@ def main():
     args.ranks_seen = ranks_seen(rank, device, dist)
     if args.workload == "label":
         return label_main(args, rank, world, device, dist)
+    if args.workload == "pose":
+        return pose_main(args, rank, world, device, dist)
 
     from autoposeestimation_amd.pipeline.utils import FramePipeline
     if args.frames:

@@ -44,6 +44,7 @@ const char* ape_last_error(void);
  * Returns APE_OK (the reference returns 1; the Python wrapper keeps that convention). */
 int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
                 int batch, int dim, int ref_nb, int query_nb, int k, void* stream);
+int ape_knn_debug(int one_query_per_lane);   /* 1: never the four-queries-per-lane kernel of the large-query case (tests / A-B); same indices either way */
 
 /* ---- dense contractions: conv2d / 1x1 / Linear, exact fp32 on the matrix cores ---------------------------
  * One entry point replaces every torch.nn.Conv2d / Conv1d(k=1) / Linear forward on the path:
@@ -253,6 +254,12 @@ int ape_pose_recentre_f32(const float* points4, const double* pose, float* new_p
 int ape_adds_dis_f32(const float* pred_r, const float* pred_t, const float* points, const float* model,
                      const float* target, int N, int M, int symmetric, float* pred_out, float* dis, float* stdv,
                      void* stream);
+/* The evaluation form (DenseFusion/tools/eval_linemod.py:118-130, experiments/eval.py:75-95) for a BATCH of objects in one launch: pose b
+ * (pred_r[b] unnormalised wxyz, pred_t[b]) places ITS model cloud model[b][M][3] and is scored against ITS target[b][M][3]; symmetric:
+ * every predicted point against its nearest target (the k-NN kernel's arithmetic and tie rule, several lanes per point like ape_knn_f32).
+ * dis[b] = ADD / ADD-S in the clouds' unit, bit for bit ape_adds_dis_f32's value for that object alone. */
+int ape_adds_dis_batched_f32(const float* pred_r, const float* pred_t, const float* model, const float* target, int B, int M, int symmetric,
+                             float* workspace /* B * M floats */, float* dis, void* stream);
 /* loss = mean((dis + 2 std) c - w log c), which = argmax c (first), out9 = (loss, dis[which], pred_r[which][0..3],
  * pred_t[which] + points[which])   loss.py:50-59 */
 int ape_adds_select_f32(const float* dis, const float* stdv, const float* pred_c, const float* pred_r,

@@ -107,6 +107,26 @@ def test_label_line():
     assert d["parity"]["gpu_points"] == d["parity"]["oracle_points"] and d["parity"]["max_nn_distance_mm"] < 1e-6
 
 
+def test_pose_line():
+    """BASELINE configs[1]: PoseNet + 2 refiner passes + ADD-S through the HIP k-NN / ADD-S kernel on 32 crops; the line prices the pair
+    evaluations against the fp32 vector rate, carries the k-NN kernel at the training loss's size, a CPU baseline and the parity block"""
+    d = _run("--workload", "pose", "--steps", "3", "--warmup", "1")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "parity", "knn_training_size"):
+        assert k in d, k
+    assert d["unit"] == "crops/s" and d["scaling"] == "weak" and d["steps"] == 3 and "configs[1]" in d["config"]["workload"] and "inputs" in d["config"]
+    assert abs(d["value"] - 32 * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["pairs_per_launch"] == 32 * 1000 * 1000 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
+    assert r["kernels"] and all(0 < k["frac"] < 1 for k in r["kernels"])
+    kn = d["knn_training_size"]
+    assert kn["queries"] == 1000000 and kn["refs"] == 1000 and 0.3 < kn["frac"] < 1
+    p = d["parity"]
+    assert p["knn_indices_bit_exact"] is True and p["max_dq"] <= 1e-4 and p["max_dt"] <= 1e-4 and p["adds_delta_m"] <= 1e-4
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["unit"] == "crops/s" and d["cpu_baseline"]["value"] > 0
+    assert 1e-3 < d["adds_mean_m"] < 2e-2
+
+
 def test_bench_under_torch_distributed_run_exercises_rccl():
     """the launch line the driver uses for N > 1, here with one rank: init_process_group('nccl'), the per-step all_gather of the poses,
     the barrier + all_reduce(MAX) of the timing"""

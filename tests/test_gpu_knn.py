@@ -73,6 +73,28 @@ def test_knn_full_size_property():
     assert torch.equal(idx, besti)
 
 
+@pytest.mark.parametrize("b,nr,nq,qz", [(1, 1000, 600_001, 0.25), (2, 5000, 300_000, 0.5), (1, 3, 1_000_003, 0.5), (1, 2049, 524_288, 0)])
+def test_knn_four_queries_per_lane_equals_one_query_per_lane(b, nr, nq, qz):
+    """the large-query kernel (knn1_d3_q<4>: one LDS read of a ref feeds four pair evaluations) against the one-query-per-lane kernel that
+    the oracle tests pin: ragged query counts, several ref tiles, batches, exact ties -- identical indices"""
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd.DenseFusion.lib.knn import KNearestNeighbor
+    g = torch.Generator().manual_seed(nr + nq)
+    ref = torch.randn(b, 3, nr, generator=g).cuda()
+    qry = torch.randn(b, 3, nq, generator=g).cuda()
+    if qz:
+        ref, qry = (ref / qz).round() * qz, (qry / qz).round() * qz
+    knn = KNearestNeighbor(1)
+    got = knn(ref, qry)
+    try:
+        assert _lib.lib().ape_knn_debug(1) == 0
+        want = knn(ref, qry)
+    finally:
+        _lib.lib().ape_knn_debug(0)
+    assert torch.equal(got, want)
+    assert int(got.min()) >= 1 and int(got.max()) <= nr
+
+
 def test_knn_rejects_host_tensor_and_bad_k():
     from autoposeestimation_amd.DenseFusion.lib.knn import knn_pytorch
     from autoposeestimation_amd._lib import ApeError

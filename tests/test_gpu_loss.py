@@ -50,3 +50,20 @@ def test_adds_full_size_against_knn_kernel():
     d = torch.norm(pred - nn, dim=2)
     np.testing.assert_allclose(dis.cpu().numpy(), d.mean(1).cpu().numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(std.cpu().numpy(), d.std(1).cpu().numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("b,m,sym", [(32, 1000, True), (5, 500, True), (3, 1000, False), (64, 3, True), (2, 2049, True), (300, 100, True)])
+def test_batched_adds_equals_one_object_at_a_time_bitwise(b, m, sym):
+    """ape_adds_dis_batched_f32 (eval_linemod.py:118-130 for a batch of objects: several lanes per predicted point, the k-NN kernel's merge,
+    the mean as a second launch in ape_adds_dis_f32's own summation order) == ape_adds_dis_f32 object by object, bit for bit; exact ties
+    in the clouds (quantised coordinates) exercise the lowest-index rule across lanes"""
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(b * 1000 + m)
+    q = torch.randn(b, 4, generator=g).cuda()
+    t = (torch.randn(b, 3, generator=g) * 0.1).cuda()
+    model = ((torch.rand(b, m, 3, generator=g) - 0.5) * 0.1 * 64).round().div(64).cuda()
+    target = (model + (torch.randn(b, m, 3, generator=g) * 0.004).cuda() * 64).round().div(64) if False else ((torch.rand(b, m, 3, generator=g) - 0.5) * 0.1 * 64).round().div(64).cuda()
+    got = E.adds_dis_batched(q, t, model, target, sym)
+    want = torch.cat([E.adds_dis(q[i:i + 1], t[i:i + 1], None, model[i], target[i], sym, want_std=False)[0] for i in range(b)])
+    assert torch.equal(got, want)
+    assert bool(torch.isfinite(got).all()) and float(got.min()) >= 0
