@@ -96,6 +96,7 @@ SIGNATURES = {
     "ape_conv2d_wgrad_param_f32": [_P, _P, _P, _P, _I, _P, _c.c_size_t, _P],
     "ape_label_trust_counts": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "ape_choose_points": [_P, _P, _P, _I, _I, _I, _I, _c.c_uint, _P, _c.c_long, _P, _P, _P],
+    "ape_choose_points_dseed": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _c.c_long, _P, _P, _P],
     "ape_backproject_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
     "ape_preprocess_u8_nhwc4": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ape_pc_workspace_bytes": [_I],

@@ -723,9 +723,12 @@ def seg_head(feat, w, bias, double_softmax=True):
 
 
 _ws_cache = {}
+CAPTURING = False       # set while a HIP graph is being captured (pipeline.FramePipeline pose graphs): workspaces then come from the graph's own pool
 
 
 def _workspace(nbytes, device):
+    if CAPTURING:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
     key = (str(device), "seg", torch.cuda.current_stream().cuda_stream)   # one workspace per stream: sub-batches may overlap
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -771,16 +774,22 @@ def bgsub_features(f_rgb, b_rgb, f_depth, b_depth, gate, mean, std, want_diff=Fa
 
 
 def choose_points(objmap, depth, objects, n_points, seed=0):
-    """objects[n,6] i32 (frame,cls,rmin,rmax,cmin,cmax) -> choose[n,N] i64, n_cand[n] i32"""
+    """objects[n,6] i32 (frame,cls,rmin,rmax,cmin,cmax) -> choose[n,N] i64, n_cand[n] i32.  `seed`: an int, or a device tensor (int32[1]) that the
+    kernel reads when it runs -- the form a captured launch needs to follow a seed that changes between replays"""
     b, h, w = objmap.shape
     n = objects.shape[0]
     choose = torch.zeros(n, n_points, dtype=torch.int64, device=objmap.device)
     n_cand = torch.zeros(n, dtype=torch.int32, device=objmap.device)
     stride = h * w
     cand = torch.empty(n, stride, dtype=torch.int32, device=objmap.device)
-    rc = _lib.lib().ape_choose_points(_lib.dptr(objmap, torch.uint8), _lib.dptr(depth, torch.uint16), _lib.dptr(objects, torch.int32),
-                                      n, h, w, n_points, seed & 0xFFFFFFFF, _lib.dptr(cand), stride, _lib.dptr(choose),
-                                      _lib.dptr(n_cand), _st())
+    if isinstance(seed, torch.Tensor):
+        rc = _lib.lib().ape_choose_points_dseed(_lib.dptr(objmap, torch.uint8), _lib.dptr(depth, torch.uint16), _lib.dptr(objects, torch.int32),
+                                                n, h, w, n_points, _lib.dptr(seed, torch.int32), _lib.dptr(cand), stride, _lib.dptr(choose),
+                                                _lib.dptr(n_cand), _st())
+    else:
+        rc = _lib.lib().ape_choose_points(_lib.dptr(objmap, torch.uint8), _lib.dptr(depth, torch.uint16), _lib.dptr(objects, torch.int32),
+                                          n, h, w, n_points, seed & 0xFFFFFFFF, _lib.dptr(cand), stride, _lib.dptr(choose),
+                                          _lib.dptr(n_cand), _st())
     _lib.check(rc, "ape_choose_points")
     return choose, n_cand
 

@@ -33,7 +33,7 @@ def _pose_stream():
 
 class FramePipeline:
     def __init__(self, segmentor, estimator, refiner, class_names, num_points=1000, refine_mode="live_compat",
-                 min_pixels=100, iterations=2, pose_stream=False):
+                 min_pixels=100, iterations=2, pose_stream=False, pose_graphs=False):
         if refine_mode not in ("live_compat", "iterative"):
             raise ValueError(refine_mode)
         self.segmentor, self.estimator, self.refiner = segmentor, estimator, refiner
@@ -48,6 +48,20 @@ class FramePipeline:
         # The pose stream gets the LOWEST HIP stream priority the device offers: its small launches then take the CUs the segmentation
         # kernels leave idle instead of competing with them for every slot (APE_POSE_STREAM_PRIORITY=default turns that off).
         self.side = _pose_stream() if pose_stream else None
+        # pose_graphs: frames with several objects of different sizes give one pose-stage pass (~90 launches) per crop-size bucket, and
+        # the host's launch rate, not the GPU, bounds the step (bench.py --mixed: 19 buckets, ~1700 launches, 78 ms).  With this switch
+        # the launches of a bucket (crop size, object count) are captured ONCE in a HIP graph -- on the bucket's second occurrence; the
+        # first runs eagerly and does the lazy set-up -- and later steps replay it: one graph launch per bucket.  The graph reads the
+        # batch through fixed buffers (the caller's rgb / depth tensors by address: new tensors mean a new capture; the object map,
+        # the bucket's object table and the sampling seed through the pipeline's own static copies) and leaves pose / n_cand / choose in
+        # static outputs that the caller copies from.  Results are those of the eager launches, kernel for kernel.
+        # Replays of different buckets are independent and each fills a small part of the chip (a bucket holds 1..10 crops): they go out on
+        # a few side streams side by side and the caller's stream joins them before it scatters the results.
+        self.pose_graphs = bool(pose_graphs)
+        self._bucket_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("APE_BUCKET_STREAMS", "4")))] if pose_graphs else []
+        self._graphs = {}
+        self._seen = set()
+        self._static_objmap = None
 
     # -- stage 1: segmentation + components, all on device ---------------------------------------------------------
     def segment(self, rgb, inject_logits=None):
@@ -82,32 +96,41 @@ class FramePipeline:
             pose_all = torch.zeros(n, 7, dtype=torch.float64, device=dev)
             ncand_all = torch.zeros(n, dtype=torch.int32, device=dev)
             choose_all = torch.zeros(n, self.num_points, dtype=torch.int64, device=dev)
+        use_graphs = self.pose_graphs and choose_override is None and E.PROFILE is None and not torch.cuda.is_current_stream_capturing()
+        if use_graphs:
+            if self._static_objmap is None or self._static_objmap.shape != objmap.shape:
+                self._static_objmap = torch.empty_like(objmap)
+                self._graphs.clear()
+            self._static_objmap.copy_(objmap, non_blocking=True)
+        cur = torch.cuda.current_stream()
+        fan = use_graphs and not single and len(self._bucket_streams) > 1
+        if fan:
+            start = torch.cuda.Event()
+            start.record(cur)
+            joins = []
         for k, (hc, wc) in enumerate(uniq.tolist()):
             ids = np.nonzero(inv == k)[0]
             sub = obj_np[ids]
             # one small H2D, from pinned memory and non-blocking: a pageable copy would park the host until the stream (the pose stream
             # still busy with the previous batch) reaches it
-            both = torch.from_numpy(np.ascontiguousarray(np.concatenate([sub, sub[:, [0, 2, 4]]], 1))).pin_memory().to(dev, non_blocking=True)
-            objs, rects = both[:, :6].contiguous(), both[:, 6:9].contiguous()
-            choose, n_cand = E.choose_points(objmap, depth, objs, self.num_points, seed)
-            if choose_override is not None:
-                for j, i in enumerate(ids.tolist()):
-                    if choose_override.get(i) is not None:
-                        choose[j] = torch.as_tensor(choose_override[i], dtype=torch.int64).to(dev)
-            pts4 = E.backproject(depth, objs, choose, meta["intr"], meta["depth_scale"])
-            img4 = E.preprocess_u8(rgb, rects, hc, wc, div255=False)
-            obj_idx = (objs[:, 1].to(torch.int64) - 1).contiguous()         # class_names.index(cls) (pipeline/utils.py:561)
-            heads, emb = self.estimator.forward_batch(img4, pts4, choose, obj_idx)
-            if self.refine_mode == "live_compat":
-                pose, _, newp = E.pose_select(heads, pts4)
-                for _ in range(self.iterations):
-                    out = self.refiner.forward_batch(newp, emb, obj_idx)
-                E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+            both_h = torch.from_numpy(np.ascontiguousarray(np.concatenate([sub, sub[:, [0, 2, 4]]], 1))).pin_memory()
+            if use_graphs:
+                side = self._bucket_streams[k % len(self._bucket_streams)] if fan and self._has_graph(rgb, depth, both_h.shape[0], hc, wc, meta, cur) else None
+                if side is not None:            # a replay: on one of the bucket streams, beside the other buckets' replays
+                    side.wait_event(start)
+                    with torch.cuda.stream(side):
+                        pose, n_cand, choose = self._bucket_replay(rgb, depth, both_h, hc, wc, meta, seed, key_stream=cur)
+                        for t in (pose, n_cand, choose):
+                            t.record_stream(cur)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    joins.append(ev)
+                    cur.wait_event(ev)
+                else:
+                    pose, n_cand, choose = self._bucket_replay(rgb, depth, both_h, hc, wc, meta, seed)
             else:
-                pose, _, _ = E.pose_select(heads, pts4, want_new_points=False)
-                for _ in range(self.iterations):
-                    out = self.refiner.forward_batch(E.pose_recentre(pts4, pose), emb, obj_idx)
-                    E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+                pose, n_cand, choose = self._bucket(rgb, depth, objmap, both_h.to(dev, non_blocking=True), hc, wc, meta, seed,
+                                                    None if choose_override is None else {j: choose_override.get(i) for j, i in enumerate(ids.tolist())})
             if single:
                 return pose, n_cand, choose
             ids_t = torch.from_numpy(ids.astype(np.int64)).pin_memory().to(dev, non_blocking=True)
@@ -115,6 +138,69 @@ class FramePipeline:
             ncand_all.index_copy_(0, ids_t, n_cand)
             choose_all.index_copy_(0, ids_t, choose)
         return pose_all, ncand_all, choose_all
+
+    def _bucket(self, rgb, depth, objmap, both, hc, wc, meta, seed, override=None):
+        """the pose stage of ONE crop-size bucket: both[n,9] i32 on the device = (frame, cls, rmin, rmax, cmin, cmax | frame, rmin, cmin);
+        -> pose[n,7] f64, n_cand[n] i32, choose[n,N] i64"""
+        dev = rgb.device
+        objs, rects = both[:, :6].contiguous(), both[:, 6:9].contiguous()
+        choose, n_cand = E.choose_points(objmap, depth, objs, self.num_points, seed)
+        if override is not None:
+            for j, ch in override.items():
+                if ch is not None:
+                    choose[j] = torch.as_tensor(ch, dtype=torch.int64).to(dev)
+        pts4 = E.backproject(depth, objs, choose, meta["intr"], meta["depth_scale"])
+        img4 = E.preprocess_u8(rgb, rects, hc, wc, div255=False)
+        obj_idx = (objs[:, 1].to(torch.int64) - 1).contiguous()         # class_names.index(cls) (pipeline/utils.py:561)
+        heads, emb = self.estimator.forward_batch(img4, pts4, choose, obj_idx)
+        if self.refine_mode == "live_compat":
+            pose, _, newp = E.pose_select(heads, pts4)
+            for _ in range(self.iterations):
+                out = self.refiner.forward_batch(newp, emb, obj_idx)
+            E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+        else:
+            pose, _, _ = E.pose_select(heads, pts4, want_new_points=False)
+            for _ in range(self.iterations):
+                out = self.refiner.forward_batch(E.pose_recentre(pts4, pose), emb, obj_idx)
+                E.pose_compose(pose, out[:, 0:4], out[:, 4:7])
+        return pose, n_cand, choose
+
+    def _graph_key(self, rgb, depth, n, hc, wc, meta, stream):
+        intr = meta["intr"]
+        return (hc, wc, n, rgb.data_ptr(), depth.data_ptr(), float(intr["fx"]), float(intr["fy"]), float(intr["ppx"]), float(intr["ppy"]),
+                float(meta["depth_scale"]), stream.cuda_stream)
+
+    def _has_graph(self, rgb, depth, n, hc, wc, meta, stream):
+        return self._graph_key(rgb, depth, n, hc, wc, meta, stream) in self._graphs
+
+    def _bucket_replay(self, rgb, depth, both_h, hc, wc, meta, seed, key_stream=None):
+        """the same through a HIP graph per (crop size, object count, input buffers): see `pose_graphs` in __init__"""
+        n = both_h.shape[0]
+        key = self._graph_key(rgb, depth, n, hc, wc, meta, key_stream or torch.cuda.current_stream())
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._seen:                   # first occurrence: eager (weight plans, function attributes, lazy operands)
+                self._seen.add(key)
+                return self._bucket(rgb, depth, self._static_objmap, both_h.to(rgb.device, non_blocking=True), hc, wc, meta, seed)
+            if len(self._graphs) >= 256:
+                self._graphs.clear()
+            both = torch.empty(n, 9, dtype=torch.int32, device=rgb.device)
+            seed_d = torch.zeros(1, dtype=torch.int32, device=rgb.device)
+            both.copy_(both_h, non_blocking=True)
+            torch.cuda.current_stream().synchronize()   # (capture starts from a quiet stream; once per bucket shape)
+            graph = torch.cuda.CUDAGraph()
+            E.CAPTURING = True                          # (no cached workspaces from inside a graph's private pool)
+            try:
+                with torch.cuda.graph(graph):
+                    outs = self._bucket(rgb, depth, self._static_objmap, both, hc, wc, meta, seed_d)
+            finally:
+                E.CAPTURING = False
+            g = self._graphs[key] = (graph, both, seed_d, outs)
+        graph, both, seed_d, outs = g
+        both.copy_(both_h, non_blocking=True)
+        seed_d.fill_(int(seed) & 0x7FFFFFFF)
+        graph.replay()
+        return tuple(o.clone() for o in outs)           # (the static outputs are overwritten by the bucket's next replay)
 
     def begin(self, rgb, inject_logits=None, asynchronous=True):
         """Enqueue the segmentation stage of a batch and the (pinned, non-blocking) copy of its detections; returns a handle for

@@ -305,7 +305,8 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
     mframes = [S.mixed_frame(rank * 100003 + i) for i in range(n)]
     rgb = torch.from_numpy(np.stack([f[0] for f in mframes])).to(device)
     depth = torch.from_numpy(np.stack([f[1] for f in mframes])).to(device)
-    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap)
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap,
+                         pose_graphs=not args.no_pose_graphs)
 
     def tail(out):
         with torch.cuda.stream(out.get("stream") or torch.cuda.current_stream()):
@@ -361,10 +362,11 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
              "ms_per_step": round(dt / args.mixed_steps * 1e3, 3), "steps": args.mixed_steps, "frames_per_gpu_per_step": n,
              "objects_per_step_rank0": len(out["objects"]), "objects_painted_rank0": sum(len(f[3]) for f in mframes),
              "crop_buckets_last_step": dict(sorted(buckets.items())), "painted_sizes_rank0": dict(sorted(painted.items())),
-             "overlap": bool(args.overlap),
+             "overlap": bool(args.overlap), "pose_graphs": not args.no_pose_graphs,
              "note": "synthetic.mixed_frame: 1-3 painted objects of distinct classes per 640x480 frame, sizes drawn from {70x70, 110x150, 150x150, "
-                     "230x230, 310x390} (crops 80x80 .. 320x400, SURVEY.md 8d); one pose-stage pass per distinct crop size of the batch; run after "
-                     "the timed region, never part of `value`"}
+                     "230x230, 310x390} (crops 80x80 .. 320x400, SURVEY.md 8d); one pose-stage pass per distinct crop size of the batch, each "
+                     "replayed as ONE captured HIP graph (FramePipeline(pose_graphs=True): the ~90 launches of a bucket are captured on its second "
+                     "occurrence; --no-pose-graphs enqueues them one by one); run after the timed region, never part of `value`"}
     if not args.no_cpu_baseline and world == 1:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import densefusion_oracle as O
@@ -798,12 +800,15 @@ def main():
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="one stream, segmentation and pose stage back to back")
     ap.add_argument("--dump-launches", default="", help="write [[kernel label, layer shape], ...] of ONE step's profiled launches in launch order "
                     "(for tools/pmc_summary.py --shapes: per-shape HBM traffic from the rocprofv3 PMC passes; use with --no-overlap)")
+    ap.add_argument("--no-staged", action="store_true", help="skip the secondary `staged` leg (the same loop fed from pinned host memory through a copy stream)")
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary `modes` leg (two steps of the exact-fp32 operand mode after the timed region)")
     ap.add_argument("--mixed", action="store_true",
                     help="add a secondary `sweep` object to the line: --batch frames with 1-3 painted objects each, sizes drawn from SURVEY.md 8d's crop "
                          "sweep {80x80, 120x160, 160x160, 240x240, 320x400}, through the same path (several crop-size buckets per step); run after the "
                          "timed region, never part of `value`")
     ap.add_argument("--mixed-steps", type=int, default=5)
+    ap.add_argument("--no-pose-graphs", action="store_true",
+                    help="--mixed: enqueue every crop-size bucket's ~90 pose-stage launches one by one instead of replaying one captured HIP graph per bucket")
     ap.add_argument("--latency", action="store_true",
                     help="add a secondary `latency` object: ONE resident 640x480 frame with one object through the whole path (what the reference's live "
                          "loop does per frame, main.py:517-553), host wall clock from the call to the pose on the host, p50 / p99 over --latency-runs "
@@ -1012,6 +1017,67 @@ def main():
         ref.set_precision(args.pose_precision)
         del pipe_f
 
+    # Secondary, AFTER the timed region (not part of `value`): the live loop receives its frames on the HOST (main.py:517-553,
+    # pipeline/utils.py:421-427,556-560).  `staged`: every step takes a batch from pinned host memory through a COPY stream into one of two
+    # device buffer pairs while the previous batch is being segmented (1.5 MB per frame: 98 MB per 64-frame step), then runs the same
+    # software-pipelined loop on it.  value is the resident-input rate; this leg shows what the staging costs beside it.
+    staged = None
+    if not args.no_staged and not args.frames:
+        copy_stream = torch.cuda.Stream()
+        host = [(torch.from_numpy(np.stack([f[0] for f in frames])).pin_memory(), torch.from_numpy(np.stack([f[1] for f in frames])).pin_memory())]
+        host.append((host[0][0].flip(0).contiguous().pin_memory(), host[0][1].flip(0).contiguous().pin_memory()))        # a second, different batch
+        dev = [(torch.empty_like(rgb[0]), torch.empty_like(depth[0])) for _ in range(2)]
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        pipe_s = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap)
+
+        def stage(i):
+            slot = i % 2
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(freed[slot])                      # the batch that used this buffer pair two steps ago has been consumed
+                dev[slot][0].copy_(host[i % 2][0], non_blocking=True)
+                dev[slot][1].copy_(host[i % 2][1], non_blocking=True)
+                ready[slot].record(copy_stream)
+
+        def run_staged(count):
+            for slot in range(2):
+                freed[slot].record()
+            stage(0)
+            torch.cuda.current_stream().wait_event(ready[0])
+            h = pipe_s.begin(dev[0][0])
+            for i in range(count):
+                slot = i % 2
+                if i + 1 < count:
+                    stage(i + 1)
+                    torch.cuda.current_stream().wait_event(ready[(i + 1) % 2])
+                    h_next = pipe_s.begin(dev[(i + 1) % 2][0])
+                else:
+                    h_next = None
+                o = tail(pipe_s.finish(h, dev[slot][0], dev[slot][1], S.REALSENSE_META, seed=i), (3 * 10 ** 6 + i, 0))
+                # the pose stage (on its own stream when the loop is software-pipelined) is the last reader of the batch's buffers
+                with torch.cuda.stream(o.get("stream") or torch.cuda.current_stream()):
+                    freed[slot].record()
+                h = h_next
+            return o
+
+        run_staged(2)
+        fence()
+        ts = time.perf_counter()
+        staged_steps = max(4, min(args.steps, 10))
+        o = run_staged(staged_steps)
+        fence()
+        dts = time.perf_counter() - ts
+        if dist:
+            t = torch.tensor([dts], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t[0])
+        staged = {"value": round(per_rank * world * staged_steps / dts, 2), "unit": "frames/s", "ms_per_step": round(dts / staged_steps * 1e3, 3),
+                  "steps": staged_steps, "host_bytes_per_step": int(host[0][0].numel() + 2 * host[0][1].numel()),
+                  "objects_found_last_step": len(o["objects"]),
+                  "note": "every step's frames come from pinned host memory over PCIe on a copy stream, double-buffered against the previous "
+                          "batch's segmentation; same loop otherwise; after the timed region, never part of `value`"}
+        del pipe_s
+
     # Secondary, AFTER the timed region (not part of `value`): what real frames look like (pipeline/utils.py:444-470, 522-561: every detected
     # class of a frame gets its own crop, crops of one size go through the pose stage together) -- 1-3 objects per frame, five crop sizes.
     sweep = None
@@ -1124,6 +1190,8 @@ def main():
                                     "one RCCL all_gather of all poses per step; per frame as configs[2]" % (args.frames, args.batch)) if args.frames else
                                    ("configs[2]: end-to-end PSPNet-resnet18 segmentation -> mask/CCL/bbox -> 160x160 crop -> "
                                     "PoseNet(N=1000) -> 2x PoseRefineNet, batch=%d 640x480 frames per GPU" % args.batch),
+                       "inputs": "u8 RGB + u16 depth resident in HBM when the timed region starts, the same batch every step (`staged` = the "
+                                 "same loop fed from pinned host memory)",
                        "frames_per_gpu_per_step": per_rank, "objects_found_last_step": n_found,
                        "crop_buckets_last_step": crop_hist,
                        "frame_selection": ("the rank's first %d random synthetic frames as they come" % per_rank) if args.unfiltered_frames else
@@ -1136,6 +1204,7 @@ def main():
             "ranks_seen": args.ranks_seen, "distinct_gpus": len({tuple(r[1:3]) for r in args.ranks_seen}),
             "roofline": roofline,
             "modes": modes,
+            "staged": staged,
         }
         if sweep is not None:
             line["sweep"] = sweep

@@ -319,6 +319,10 @@ int ape_label_trust_counts(const uint8_t* objmap, int cls, const uint8_t* bs_lab
  * choose[n][N] i64 indices inside the crop; n_cand[n] (0 => object dropped, :530-531); cand: scratch [n][cand_stride]. */
 int ape_choose_points(const uint8_t* objmap, const uint16_t* depth, const int* objects, int n, int H, int W, int N,
                       unsigned int seed, int* cand, long cand_stride, int64_t* choose, int* n_cand, void* stream);
+/* the same with the sampling seed read from DEVICE memory when the kernel runs: a launch captured in a HIP graph then follows a seed that
+ * the host updates between replays (pipeline/utils.py FramePipeline(pose_graphs=True)) */
+int ape_choose_points_dseed(const uint8_t* objmap, const uint16_t* depth, const int* objects, int n, int H, int W, int N,
+                            const unsigned int* seed_device, int* cand, long cand_stride, int64_t* choose, int* n_cand, void* stream);
 /* float32 pin-hole back-projection          pipeline/utils.py:542-553.  points4[n][N][4] = (x, y, z, 0) */
 int ape_backproject_f32(const uint16_t* depth, const int* objects, const int64_t* choose, float* points4, int n,
                         int H, int W, int N, float fx, float fy, float ppx, float ppy, float depth_scale, void* stream);

@@ -191,3 +191,40 @@ def test_get_prediction_models_from_a_dataset_tree(tmp_path):
     os.rename(os.path.join(seg_dir, "PsPNet_resnet34.ckpt"), os.path.join(seg_dir, "Unet_resnet34.ckpt"))
     with pytest.raises(FileNotFoundError, match="segmentation_models_pytorch"):
         get_prediction_models(root, ds)
+
+
+@pytest.mark.parametrize("pose_stream", [False, True])
+def test_pose_buckets_replayed_as_hip_graphs_equal_the_eager_launches(pose_stream):
+    """FramePipeline(pose_graphs=True): frames with several objects of different sizes (pipeline/utils.py:444-470,522-561 loops over every
+    detected class) give one pose-stage pass per crop-size bucket; each bucket's launches are captured in a HIP graph on its second
+    occurrence and replayed afterwards.  Objects come from painted label maps (the product's own component / bbox kernels), the sampling
+    seed changes every step (it reaches the captured launch through device memory): poses, candidate counts and chosen pixels of the
+    eager step, the capturing step and two replays are those of a pipeline that never uses graphs, bit for bit."""
+    from autoposeestimation_amd import engine as E
+    from autoposeestimation_amd.pipeline.utils import FramePipeline
+    _, est, ref, *_ = _models()
+    for m in (est, ref):
+        m.set_precision("bf16x3")
+    frames = [S.mixed_frame(7000 + i) for i in range(6)]
+    rgb = torch.from_numpy(np.stack([f[0] for f in frames])).cuda()
+    depth = torch.from_numpy(np.stack([f[1] for f in frames])).cuda()
+    label = torch.from_numpy(np.stack([f[2] for f in frames]).astype(np.uint8)).cuda()
+    objmap, det = E.seg_components(label, torch.ones(label.shape, dtype=torch.float32, device="cuda"), 13, 100)
+    handle = {"objmap": objmap, "det": det, "det_h": None, "event": None}
+    plain = FramePipeline(None, est, ref, CLASSES, pose_stream=False)
+    graphs = FramePipeline(None, est, ref, CLASSES, pose_stream=pose_stream, pose_graphs=True)
+    sizes = set()
+    for step in range(4):
+        want = plain.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=step)
+        got = graphs.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=step)
+        torch.cuda.synchronize()
+        assert got["objects"] == want["objects"] and len(want["objects"]) >= 8
+        sizes |= {(o[3] - o[2], o[5] - o[4]) for o in want["objects"]}
+        for k in ("pose", "n_cand", "choose"):
+            assert torch.equal(got[k], want[k]), (step, k)
+    assert len(sizes) >= 3 and len(graphs._graphs) == len(sizes)          # several buckets, one graph each
+    # a seed that changes the sampled pixels really reaches the replayed launch
+    a = graphs.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=11)["choose"].clone()
+    b = graphs.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=12)["choose"].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b)
