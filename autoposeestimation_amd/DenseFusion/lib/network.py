@@ -459,7 +459,7 @@ class PoseNet(_HipModule):
         """img4[B,Hc,Wc,4] f32 (normalised RGB + 0), points4[B,N,4], choose[B,N] i64, obj[B] i64
         -> heads[B,N,8] (qw,qx,qy,qz,tx,ty,tz,c), emb[B,N,32]"""
         pl = self.plan()
-        for t, name in ((img4, "img"), (points4, "points"), (choose, "choose"), (obj, "obj")):
+        for t, name in ((img4, "img"), (points4, "points"), (choose, "choose"), (obj, "obj")):      # (img4: the normalised crops or engine.U8Frames)
             _need_cuda(t, name)
         b, hc, wc, _ = img4.shape
         n = points4.shape[1]

@@ -48,6 +48,7 @@ SIGNATURES = {
     "ape_conv3x3_halo_s32_supported": [_P],
     "ape_conv3x3_halo_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
     "ape_stem_conv_pool_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "ape_stem_conv_pool_u8": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ape_conv3x3_halo_supported": [_P],
     "ape_conv3x3_halo_bf16": [_P, _P, _P, _P, _P, _P, _I, _P],
     "ape_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],

@@ -11,6 +11,11 @@
 // ADJACENT input pixels of one patch row, i.e. 16 contiguous bytes of the patch: the A fragments are ds_read_b128s of the
 // patch itself (no im2col image), and lanes that share a pixel pair read the same address (broadcast, conflict-free).
 // The 7 x 2 weight fragments of a wave's 16 output channels stay in registers for the whole (persistent) kernel.
+//
+// U8 form (ape_stem_conv_pool_u8): the patch is read from the uint8 RGB frames themselves -- crop o = the Hc x Wc window of frame
+// rects[o][0] at (rects[o][1], rects[o][2]); NULL rects: whole frames -- and ToTensor / Normalize (pipeline/utils.py:421-427, 556-560)
+// run on the way into LDS with ape_preprocess_u8_nhwc4's own expressions, so the results are bit for bit those of the two launches
+// while the fp32 NHWC4 image (16 B per pixel: 315 MB written and read back per 64 frames) never exists.
 #include "common.h"
 
 namespace {
@@ -28,11 +33,26 @@ constexpr int NPATCH = PR * PC;                 // 920 pixels
 constexpr int ELD = 68;                         // floats per staged conv pixel (64 channels + pad)
 constexpr int PITEMS = (NPATCH + 255) / 256;    // patch pixels per thread (4)
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float4* __restrict__ x, const float* __restrict__ w,
+template <int NSPLIT, bool U8>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restrict__ xin, const int* __restrict__ rects, int Hf, int Wf, long npix, int div255,
+                                                           const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
                                                            int Ho, int Wo, int Hp, int Wp, int tiles_y, int tiles_x)
 {
+    const float4* const x = reinterpret_cast<const float4*>(xin);
+    const uint8_t* const x8 = reinterpret_cast<const uint8_t*>(xin);
+    // U8: the 3 x 256 possible normalised values, computed once with crop_normalize_kernel's own expressions (six fp32 divisions per pixel
+    // in the patch load cost more than the launch they replace)
+    __shared__ float lut[U8 ? 768 : 1];
+    if (U8) {
+        for (int i = threadIdx.x; i < 768; i += 256) {
+            const int c = i >> 8;
+            float v0 = (float)(i & 255);
+            if (div255) v0 = v0 / 255.f;                                                        // torchvision ToTensor
+            lut[i] = c == 0 ? (v0 - 0.485f) / 0.229f : c == 1 ? (v0 - 0.456f) / 0.224f : (v0 - 0.406f) / 0.225f;
+        }
+        __syncthreads();
+    }
     constexpr int NPL = NSPLIT == 3 ? 2 : 1;
     __shared__ __attribute__((aligned(16))) char smem[NPL * NPATCH * 8 + NCV * ELD * 4];
     __bf16* const patch = reinterpret_cast<__bf16*>(smem);                 // [NPL][NPATCH][4]
@@ -77,7 +97,18 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float4* __restr
             const int iy = iy0 + pr, ix = ix0 + pc;
             const bool ok = e < NPATCH && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const int cyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cxc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            const float4 v = x[((long)b * H + cyc) * W + cxc];              // unconditional (clamped), zeroed below: conv zero padding
+            float4 v;
+            if (U8) {
+                const int fb = rects ? rects[b * 3] : b, fr = (rects ? rects[b * 3 + 1] : 0) + cyc, fc = (rects ? rects[b * 3 + 2] : 0) + cxc;
+                // the pixel's three bytes by ONE (unaligned) 32-bit load; the very last pixel of the buffer is read one byte early and shifted
+                const long pi = ((long)fb * Hf + fr) * Wf + fc;
+                const int last = pi == npix - 1 ? 1 : 0;
+                typedef unsigned int u32_unaligned __attribute__((aligned(1)));
+                const unsigned int u = *reinterpret_cast<const u32_unaligned*>(x8 + pi * 3 - last) >> (8 * last);
+                v = make_float4(lut[u & 255u], lut[256 + ((u >> 8) & 255u)], lut[512 + ((u >> 16) & 255u)], 0.f);
+            } else {
+                v = x[((long)b * H + cyc) * W + cxc];                       // unconditional (clamped), zeroed below: conv zero padding
+            }
             preg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -164,10 +195,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float4* __restr
 
 }  // namespace
 
-/* x[B][H][W][4] f32 (RGB + zero pad), w[64][7][7][4] f32, bias[64] or NULL -> y[B][Hp][Wp][64],
- * Hp = ((H + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1 (the 7x7/s2/p3 conv followed by ReLU and the 3x3/s2/p1 max-pool) */
-extern "C" int ape_stem_conv_pool_bf16(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int nsplit,
-                                       void* stream)
+static int stem_run(const void* x, bool u8, const int* rects, int Hf, int Wf, long npix, int div255, const float* w, const float* bias, float* y,
+                    int B, int H, int W, int nsplit, void* stream)
 {
     if (!x || !w || !y || B < 0 || H < 1 || W < 1 || (nsplit != 1 && nsplit != 3)) return APE_EINVAL;
     if (B == 0) return APE_OK;
@@ -178,11 +207,29 @@ extern "C" int ape_stem_conv_pool_bf16(const float* x, const float* w, const flo
     const long ntiles = (long)B * tiles_y * tiles_x;
     if (ntiles >= (1L << 31) || (long)B * H * W >= (1L << 31)) return APE_EINVAL;
     const int grid = (int)(ntiles < 512 ? ntiles : 512);        // persistent: two workgroups per CU walk the tiles
-    if (nsplit == 3)
-        hipLaunchKernelGGL(stem_pool_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)x, w, bias, y, B, H, W, Ho,
-                           Wo, Hp, Wp, tiles_y, tiles_x);
-    else
-        hipLaunchKernelGGL(stem_pool_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)x, w, bias, y, B, H, W, Ho,
-                           Wo, Hp, Wp, tiles_y, tiles_x);
-    return ape::check_launch("ape_stem_conv_pool_bf16");
+    hipStream_t st = (hipStream_t)stream;
+#define APE_STEM_LAUNCH(NS, U)                                                                                                              \
+    hipLaunchKernelGGL((stem_pool_kernel<NS, U>), dim3(grid), dim3(256), 0, st, x, rects, Hf, Wf, npix, div255, w, bias, y, B, H, W, Ho, Wo, Hp, Wp, \
+                       tiles_y, tiles_x)
+    if (u8) { if (nsplit == 3) APE_STEM_LAUNCH(3, true); else APE_STEM_LAUNCH(1, true); }
+    else { if (nsplit == 3) APE_STEM_LAUNCH(3, false); else APE_STEM_LAUNCH(1, false); }
+#undef APE_STEM_LAUNCH
+    return ape::check_launch("ape_stem_conv_pool");
+}
+
+/* x[B][H][W][4] f32 (RGB + zero pad), w[64][7][7][4] f32, bias[64] or NULL -> y[B][Hp][Wp][64],
+ * Hp = ((H + 6 - 7) / 2 + 1 + 2 - 3) / 2 + 1 (the 7x7/s2/p3 conv followed by ReLU and the 3x3/s2/p1 max-pool) */
+extern "C" int ape_stem_conv_pool_bf16(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int nsplit,
+                                       void* stream)
+{
+    return stem_run(x, false, nullptr, H, W, 0, 0, w, bias, y, B, H, W, nsplit, stream);
+}
+
+/* the same on the uint8 frames: rgb[n_frames][Hf][Wf][3], crop o = the Hc x Wc window of frame rects[o][0] at row rects[o][1], column
+ * rects[o][2] (rects NULL: n whole frames, Hc = Hf, Wc = Wf), ToTensor (div255) + Normalize fused into the patch load */
+extern "C" int ape_stem_conv_pool_u8(const uint8_t* rgb, int n_frames, const int* rects, const float* w, const float* bias, float* y, int n, int Hf,
+                                     int Wf, int Hc, int Wc, int div255, int nsplit, void* stream)
+{
+    if (n_frames < 1 || Hf < 1 || Wf < 1 || Hc > Hf || Wc > Wf || (!rects && (Hc != Hf || Wc != Wf || n != n_frames))) return APE_EINVAL;
+    return stem_run(rgb, true, rects, Hf, Wf, (long)n_frames * Hf * Wf, div255, w, bias, y, n, Hc, Wc, nsplit, stream);
 }

@@ -399,11 +399,54 @@ def conv_seg_head(conv, x, head_w, head_b, double_softmax=True, upsample2x=False
 
 
 USE_FUSED_STEM = os.environ.get("APE_USE_FUSED_STEM", "1") != "0"
+USE_U8_STEM = os.environ.get("APE_USE_U8_STEM", "1") != "0"      # the stem reads the uint8 frames itself (ToTensor / Normalize fused into its patch load)
+
+
+class U8Frames:
+    """The network input `ToTensor + Normalize` of uint8 frames or crops (pipeline/utils.py:421-427, 556-560), NOT yet materialised:
+    crop o = the hc x wc window of frame rects[o,0] at (rects[o,1], rects[o,2]) of rgb[F,H,W,3] u8.  `stem_pool` consumes it directly (the
+    fp32 NHWC4 image -- 16 bytes per pixel -- is then never written); `materialise()` gives the tensor `preprocess_u8` would."""
+    __slots__ = ("rgb", "rects", "hc", "wc", "div255", "_x4")
+
+    def __init__(self, rgb, rects, hc, wc, div255):
+        self.rgb, self.rects, self.hc, self.wc, self.div255, self._x4 = rgb, rects, int(hc), int(wc), bool(div255), None
+
+    @property
+    def shape(self):
+        return (self.rects.shape[0], self.hc, self.wc, 4)
+
+    @property
+    def is_cuda(self):
+        return self.rgb.is_cuda
+
+    @property
+    def device(self):
+        return self.rgb.device
+
+    def __getitem__(self, idx):          # batch slicing only
+        return U8Frames(self.rgb, self.rects[idx].contiguous(), self.hc, self.wc, self.div255)
+
+    def materialise(self):
+        if self._x4 is None:
+            self._x4 = preprocess_u8(self.rgb, self.rects, self.hc, self.wc, self.div255)
+        return self._x4
 
 
 def stem_pool(conv, x):
     """maxpool3x3s2(conv(x)) for the ResNet stem (7x7 / stride 2 / pad 3, 4 -> 64 channels, ReLU): one fused kernel on the bf16
-    paths (the half-resolution activation is never stored), the two calls otherwise."""
+    paths (the half-resolution activation is never stored), the two calls otherwise.  x: the normalised image [B,H,W,4], or `U8Frames`."""
+    if isinstance(x, U8Frames):
+        fus = (USE_U8_STEM and USE_FUSED_STEM and conv.nsplit and conv.cout == 64 and conv.cin == 4 and conv.kh == 7 and conv.kw == 7
+               and conv.stride == 2 and conv.pad == 3 and conv.dil == 1 and conv.act == ACT_RELU)
+        if not fus:
+            return stem_pool(conv, x.materialise())
+        n, h, w, _ = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty(n, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 64, dtype=torch.float32, device=x.device)
+        rc = _lib.lib().ape_stem_conv_pool_u8(_lib.dptr(x.rgb, torch.uint8), x.rgb.shape[0], _lib.dptr(x.rects, torch.int32), _lib.dptr(conv.w, torch.float32),
+                                              _lib.dptr(conv.bias), _lib.dptr(y), n, x.rgb.shape[1], x.rgb.shape[2], h, w, int(x.div255), conv.nsplit, _st())
+        _lib.check(rc, "ape_stem_conv_pool_u8")
+        return y
     b, h, w, ldx = x.shape
     fusable = (USE_FUSED_STEM and conv.nsplit and conv.cout == 64 and conv.cin == 4 and ldx == 4 and conv.kh == 7 and conv.kw == 7
                and conv.stride == 2 and conv.pad == 3 and conv.dil == 1 and conv.act == ACT_RELU)

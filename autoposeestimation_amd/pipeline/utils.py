@@ -75,7 +75,7 @@ class FramePipeline:
                 rects = torch.zeros(b, 3, dtype=torch.int32)
                 rects[:, 0] = torch.arange(b, dtype=torch.int32)
                 rects = self._full_rects[key] = rects.to(rgb.device)
-            x4 = E.preprocess_u8(rgb, rects, h, w, div255=True)
+            x4 = E.U8Frames(rgb, rects, h, w, div255=True)       # (normalised inside the stem kernel's patch load: never materialised)
             label, score = self.segmentor.label_score_nhwc(x4, double_softmax=True)
         else:
             label, score = E.seg_argmax(inject_logits, self.n_cls, double_softmax=True)
@@ -150,7 +150,7 @@ class FramePipeline:
                 if ch is not None:
                     choose[j] = torch.as_tensor(ch, dtype=torch.int64).to(dev)
         pts4 = E.backproject(depth, objs, choose, meta["intr"], meta["depth_scale"])
-        img4 = E.preprocess_u8(rgb, rects, hc, wc, div255=False)
+        img4 = E.U8Frames(rgb, rects, hc, wc, div255=False)
         obj_idx = (objs[:, 1].to(torch.int64) - 1).contiguous()         # class_names.index(cls) (pipeline/utils.py:561)
         heads, emb = self.estimator.forward_batch(img4, pts4, choose, obj_idx)
         if self.refine_mode == "live_compat":

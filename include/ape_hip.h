@@ -178,6 +178,12 @@ int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const float* bia
  * between the convolution and the pool is never written. */
 int ape_stem_conv_pool_bf16(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int nsplit,
                             void* stream);
+/* ... and straight from the uint8 frames (pipeline/utils.py:421-427,556-560: ToTensor / Normalize of the frame or of the crop): crop o = the
+ * Hc x Wc window of frame rects[o][0] at (row rects[o][1], column rects[o][2]) of rgb[n_frames][Hf][Wf][3] (rects NULL: the n = n_frames whole frames); the
+ * normalisation (ape_preprocess_u8_nhwc4's arithmetic, div255 as there) runs on the way into LDS, so y is bit for bit
+ * ape_stem_conv_pool_bf16(ape_preprocess_u8_nhwc4(...)) and the fp32 image is never written. */
+int ape_stem_conv_pool_u8(const uint8_t* rgb, int n_frames, const int* rects, const float* w, const float* bias, float* y, int n, int Hf, int Wf,
+                          int Hc, int Wc, int div255, int nsplit, void* stream);
 /* 3x3 / stride 1 / pad == dilation in {1,2,4} / Cin % 32 == 0 specialisation of ape_conv2d_nhwc_bf16: the input halo of
  * a 16x16-pixel tile is staged once per 32-channel chunk in LDS and shared by the nine taps (3x less operand traffic).
  * Same arguments, packed weights, numerics and epilogue; ape_conv3x3_halo_supported(params) says whether it applies. */

@@ -120,3 +120,28 @@ def test_adaptive_avgpool_multi(shape):
         want = F.adaptive_avg_pool2d(x, s).permute(0, 2, 3, 1)
         assert got[s].shape == want.shape
         assert (got[s].cpu() - want).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("div255", [True, False])
+@pytest.mark.parametrize("geom", [(3, 96, 128, None), (2, 480, 640, None), (5, 160, 160, "crops"), (4, 80, 120, "crops"), (3, 41, 57, "crops")])
+def test_stem_on_uint8_frames_equals_preprocess_then_stem_bitwise(geom, div255):
+    """ape_stem_conv_pool_u8 (ToTensor / Normalize fused into the stem's patch load; pipeline/utils.py:421-427, 556-560 + extractors.py:82-85,
+    111-117) against ape_preprocess_u8_nhwc4 -> ape_stem_conv_pool_bf16: whole frames and crops (windows at the frame's corners and in its
+    middle, odd sizes), bit for bit"""
+    from autoposeestimation_amd import engine as E
+    n, hc, wc, mode = geom
+    g = torch.Generator().manual_seed(hc * 1000 + wc)
+    F_, H_, W_ = (n, hc, wc) if mode is None else (3, 480, 640)
+    rgb = torch.randint(0, 256, (F_, H_, W_, 3), generator=g, dtype=torch.uint8).cuda()
+    if mode is None:
+        rects = torch.zeros(n, 3, dtype=torch.int32)
+        rects[:, 0] = torch.arange(n)
+    else:
+        corners = [(0, 0), (H_ - hc, W_ - wc), (0, W_ - wc), (H_ - hc, 0), (H_ // 3, W_ // 2 - wc // 2)]
+        rects = torch.tensor([[i % F_, *corners[i % len(corners)]] for i in range(n)], dtype=torch.int32)
+    rects = rects.cuda()
+    conv = E.Conv(torch.randn(64, 3, 7, 7, generator=g) / 12, None, 2, 3, 1, E.ACT_RELU, device="cuda", precision="bf16x3")
+    want = E.stem_pool(conv, E.preprocess_u8(rgb, rects, hc, wc, div255))
+    got = E.stem_pool(conv, E.U8Frames(rgb, rects, hc, wc, div255))
+    assert got.shape == want.shape and torch.equal(got, want)
+    assert E.U8Frames(rgb, rects, hc, wc, div255)._x4 is None          # (nothing was materialised on the way)
