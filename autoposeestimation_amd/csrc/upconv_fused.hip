@@ -153,7 +153,7 @@ __device__ __forceinline__ float lane_value(float v, int l)
 #if defined(__HIP_DEVICE_COMPILE__)
 #if APE_ASM_SRC1_BCAST
 // (the historic, FAULTY operand order: data src0, weight pair src1 -- see the note at APE_NO_ASM_MATH)
-#define APE_PK_OPS(SUF, WC, WT)                                                                                                            \
+#define APE_PK_OPS(SUF, WC, WT, VOL)                                                                                                       \
     __device__ __forceinline__ void pk_fma0_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                  \
     { asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(v), WC(w)); }                                           \
     __device__ __forceinline__ void pk_fma_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
@@ -165,21 +165,28 @@ __device__ __forceinline__ float lane_value(float v, int l)
     __device__ __forceinline__ f32x2 pk_mul_hi_##SUF(const f32x2 v, const WT w)                                                            \
     { f32x2 d; asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(v), WC(w)); return d; }
 #else
-// the weight pair is src0, the operand slot hipcc itself uses for a broadcast (products commute: bit for bit the same results)
-#define APE_PK_OPS(SUF, WC, WT)                                                                                                            \
+// the weight pair is src0, the operand slot hipcc itself uses for a broadcast (products commute: bit for bit the same results).  VOL: the row
+// interpolation's statements (SGPR weights, operands = the MFMA accumulators) are volatile, see above; the column interpolation's are NOT --
+// their data operands come from LDS loads behind the barrier statement's memory clobber, so they cannot move in front of it, and a volatile
+// statement is a scheduling barrier: hipcc then cannot issue the next taps' ds_reads while the current ones multiply (two loads in flight
+// instead of six).
+#define APE_PK_OPS(SUF, WC, WT, VOL)                                                                                                       \
     __device__ __forceinline__ void pk_fma0_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                  \
-    { asm volatile("v_pk_fma_f32 %0, %2, %1, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(v), WC(w)); }                                           \
+    { asm VOL("v_pk_fma_f32 %0, %2, %1, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(v), WC(w)); }                                                \
     __device__ __forceinline__ void pk_fma_lo_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
-    { asm volatile("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "v"(v), WC(w)); }                                          \
+    { asm VOL("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[0,1,1]" : "+v"(d) : "v"(v), WC(w)); }                                               \
     __device__ __forceinline__ void pk_fma_hi_##SUF(f32x2& d, const f32x2 v, const WT w)                                                   \
-    { asm volatile("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(v), WC(w)); }                           \
+    { asm VOL("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(d) : "v"(v), WC(w)); }                                \
     __device__ __forceinline__ f32x2 pk_mul_lo_##SUF(const f32x2 v, const WT w)                                                            \
-    { f32x2 d; asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(v), WC(w)); return d; }                             \
+    { f32x2 d; asm VOL("v_pk_mul_f32 %0, %2, %1 op_sel_hi:[0,1]" : "=v"(d) : "v"(v), WC(w)); return d; }                                  \
     __device__ __forceinline__ f32x2 pk_mul_hi_##SUF(const f32x2 v, const WT w)                                                            \
-    { f32x2 d; asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(v), WC(w)); return d; }
+    { f32x2 d; asm VOL("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(v), WC(w)); return d; }
 #endif
-APE_PK_OPS(v, "v", f32x2)
-APE_PK_OPS(s, "s", unsigned long long)
+#ifndef APE_COLS_VOLATILE
+#define APE_COLS_VOLATILE
+#endif
+APE_PK_OPS(v, "v", f32x2, APE_COLS_VOLATILE)
+APE_PK_OPS(s, "s", unsigned long long, volatile)
 #undef APE_PK_OPS
 // acc (+)= l0 * v0 + l1 * v1 for two channels, in the unfused kernel's arithmetic: FMA: fma(l1, v1, fma(l0, v0, acc)); else acc + (l0 * v0 + l1 * v1).
 // FIRST: acc is the zero the unfused kernel starts from
