@@ -56,7 +56,7 @@ struct HaloS32Args {
     int tiles_x, tiles_y, n_tiles;
     int dbg;                // ape_conv3x3_halo_s32_debug: 1 = static priority 1 for waves 4-7, 2 = one workgroup per tile instead of the
                             // persistent walk, 16 = four rows per wave-row group in every tile (results unchanged by any of them);
-                            // timing-only ablations: 4 = no epilogue stores, 8 = no residual loads
+                            // timing-only ablations: 4 = no epilogue stores, 8 = no residual loads, 32 = two of the three MFMAs per product
 };
 
 // NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah[i >> 1][i & 1][0]), al = __builtin_bit_cast(bf16x8, Ah[i >> 1][i & 1][1]);
             // weights as the row operand (D[channel 4 fc + e][pixel frow]); product order of conv3x3_halo.hip
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[i][j], 0, 0, 0);
+            if (!ABL(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[i][j], 0, 0, 0);
         }
     };

@@ -57,7 +57,7 @@ struct GemmS32Args {
     int img_tiles;          // 0: M is one flat run of rows cut into 256-row tiles; > 0: every image (rows_per_image rows) is cut into img_tiles tiles
                             // of its own -- no tile holds rows of two images -- and ...
     long w_img_stride;      // ... image i multiplies with the weights at w + i * w_img_stride bytes (0: one weight matrix for all)
-    int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads;
+    int dbg;                // timing ablations (results wrong): 1 no in-loop DMA, 2 no in-loop barrier, 4 no MFMAs, 8 no fragment reads, 512 two of the three MFMAs;
                             // 16: per-workgroup k-tile rotation (valid results; tested against L2 hot-spotting on the shared weight lines: +-0);
                             // 32: no static priority for waves 4-7; 64: one tile per workgroup (no persistent walk)
 };
@@ -277,7 +277,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, A[aset][i][0]), al = __builtin_bit_cast(bf16x8, A[aset][i][1]);
                     // weights as the row operand: D[channel 4 fc + e][pixel frow]; same products and k order as conv_gemm.hip
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, c, 0, 0, 0);
+                    if (!ABL(512)) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, c, 0, 0, 0);     // (512: two matrix instructions per product)
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, c, 0, 0, 0);
                 }
             }

@@ -295,7 +295,7 @@ def parity_block(out, oracle_results, frames, seg_sd):
                     "ground-truth placement of the 1000-point 0.1 m-cube model cloud (eval_linemod.py:118-130), bar 1e-4 m"}
 
 
-def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence):
+def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence, steps, with_parity):
     """`bench.py --mixed`: --batch frames per rank of synthetic.mixed_frame (1-3 objects, five painted sizes) through FramePipeline --
     segmentation, components, then ONE pose-stage pass per distinct crop size of the batch (FramePipeline.poses' buckets) -- and one
     all_gather of a [frames, len(CLASSES), 8] result block per step.  Returns the `sweep` object (rank 0; None elsewhere)."""
@@ -337,10 +337,10 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
             h = h_next
         return out, n_obj
 
-    run(2, 0)
+    run(3, 0)       # (a crop-size bucket runs eagerly on its first occurrence, is captured on its second and replayed from the third on)
     fence()
     t0 = time.perf_counter()
-    out, n_obj = run(args.mixed_steps, 2)
+    out, n_obj = run(steps, 3)
     fence()
     dt = time.perf_counter() - t0
     if dist:
@@ -358,8 +358,8 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
     for f in mframes:
         for _, _, (rh, rw) in f[3]:
             painted["%dx%d" % (rh, rw)] = painted.get("%dx%d" % (rh, rw), 0) + 1
-    sweep = {"value": round(n * world * args.mixed_steps / dt, 2), "unit": "frames/s", "objects_per_s": round(n_obj / dt, 2),
-             "ms_per_step": round(dt / args.mixed_steps * 1e3, 3), "steps": args.mixed_steps, "frames_per_gpu_per_step": n,
+    sweep = {"value": round(n * world * steps / dt, 2), "unit": "frames/s", "objects_per_s": round(n_obj / dt, 2),
+             "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "frames_per_gpu_per_step": n,
              "objects_per_step_rank0": len(out["objects"]), "objects_painted_rank0": sum(len(f[3]) for f in mframes),
              "crop_buckets_last_step": dict(sorted(buckets.items())), "painted_sizes_rank0": dict(sorted(painted.items())),
              "overlap": bool(args.overlap), "pose_graphs": not args.no_pose_graphs,
@@ -367,7 +367,7 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
                      "230x230, 310x390} (crops 80x80 .. 320x400, SURVEY.md 8d); one pose-stage pass per distinct crop size of the batch, each "
                      "replayed as ONE captured HIP graph (FramePipeline(pose_graphs=True): the ~90 launches of a bucket are captured on its second "
                      "occurrence; --no-pose-graphs enqueues them one by one); run after the timed region, never part of `value`"}
-    if not args.no_cpu_baseline and world == 1:
+    if with_parity and not args.no_cpu_baseline and world == 1:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import densefusion_oracle as O
         if out.get("stream") is not None:
@@ -393,10 +393,10 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
     return sweep
 
 
-def latency_leg(args, device, seg, est, ref, frame):
+def latency_leg(args, device, seg, est, ref, frame, runs):
     """`bench.py --latency`: the batch-1 live loop (main.py:517-553 -> pipeline/utils.py full_prediction): ONE frame already in HBM, one painted
     object; per run the host clock from FramePipeline.run(...) to the pose in host memory (segmentation, components, the one D2H of the
-    detections, crop, PoseNet, 2 x refiner, pose D2H: ~140 dependent launches on one stream).  p50 / p99 / min over --latency-runs runs
+    detections, crop, PoseNet, 2 x refiner, pose D2H: ~140 dependent launches on one stream).  p50 / p99 / min over `runs` runs
     behind 10 warm-up runs.  Rank 0 only (a latency, not a throughput: it does not aggregate over ranks)."""
     from autoposeestimation_amd.pipeline.utils import FramePipeline
     pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
@@ -407,7 +407,7 @@ def latency_leg(args, device, seg, est, ref, frame):
         out["pose"].cpu()
     torch.cuda.synchronize()
     ts = []
-    for i in range(args.latency_runs):
+    for i in range(runs):
         t0 = time.perf_counter()
         out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
         out["pose"].cpu()
@@ -802,15 +802,18 @@ def main():
                     "(for tools/pmc_summary.py --shapes: per-shape HBM traffic from the rocprofv3 PMC passes; use with --no-overlap)")
     ap.add_argument("--no-staged", action="store_true", help="skip the secondary `staged` leg (the same loop fed from pinned host memory through a copy stream)")
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary `modes` leg (two steps of the exact-fp32 operand mode after the timed region)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the compact secondary `sweep` leg (4 steps of the --mixed frames, no parity block)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the compact secondary `latency` leg (50 runs of the batch-1 live loop)")
     ap.add_argument("--mixed", action="store_true",
-                    help="add a secondary `sweep` object to the line: --batch frames with 1-3 painted objects each, sizes drawn from SURVEY.md 8d's crop "
+                    help="the full `sweep` leg (--mixed-steps steps + its own parity block; the default line carries a compact one: 4 steps, no "
+                         "parity block).  `sweep`: --batch frames with 1-3 painted objects each, sizes drawn from SURVEY.md 8d's crop "
                          "sweep {80x80, 120x160, 160x160, 240x240, 320x400}, through the same path (several crop-size buckets per step); run after the "
                          "timed region, never part of `value`")
     ap.add_argument("--mixed-steps", type=int, default=5)
     ap.add_argument("--no-pose-graphs", action="store_true",
                     help="--mixed: enqueue every crop-size bucket's ~90 pose-stage launches one by one instead of replaying one captured HIP graph per bucket")
     ap.add_argument("--latency", action="store_true",
-                    help="add a secondary `latency` object: ONE resident 640x480 frame with one object through the whole path (what the reference's live "
+                    help="the full `latency` leg (--latency-runs runs; the default line carries a compact one of 50 runs).  `latency`: ONE resident 640x480 frame with one object through the whole path (what the reference's live "
                          "loop does per frame, main.py:517-553), host wall clock from the call to the pose on the host, p50 / p99 over --latency-runs "
                          "runs; after the timed region, never part of `value`")
     ap.add_argument("--latency-runs", type=int, default=200)
@@ -1063,7 +1066,7 @@ def main():
         run_staged(2)
         fence()
         ts = time.perf_counter()
-        staged_steps = max(4, min(args.steps, 10))
+        staged_steps = max(4, args.steps)          # (as many as the timed region: the pipelined loop's fill and drain weigh the same in both)
         o = run_staged(staged_steps)
         fence()
         dts = time.perf_counter() - ts
@@ -1081,13 +1084,15 @@ def main():
     # Secondary, AFTER the timed region (not part of `value`): what real frames look like (pipeline/utils.py:444-470, 522-561: every detected
     # class of a frame gets its own crop, crops of one size go through the pose stage together) -- 1-3 objects per frame, five crop sizes.
     sweep = None
-    if args.mixed:
-        sweep = mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence)
+    if (args.mixed or not args.no_sweep) and not args.frames:
+        sweep = mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, ref_sd, fence,
+                            steps=args.mixed_steps if args.mixed else 4, with_parity=args.mixed)
 
     latency = None
-    if args.latency and rank == 0:
-        latency = latency_leg(args, device, seg, est, ref, frames[0])
-    if dist and args.latency:
+    want_latency = (args.latency or not args.no_latency) and not args.frames
+    if want_latency and rank == 0:
+        latency = latency_leg(args, device, seg, est, ref, frames[0], runs=args.latency_runs if args.latency else 50)
+    if dist and want_latency:
         dist.barrier()
 
     if rank == 0:

@@ -41,6 +41,11 @@ def test_default_line_has_roofline_cpu_baseline_and_parity():
     st = d["staged"]
     assert st["unit"] == "frames/s" and st["host_bytes_per_step"] == 64 * 480 * 640 * 5 and st["objects_found_last_step"] == 64
     assert st["value"] >= 0.9 * d["value"]              # the 98 MB per step hide behind the segmentation (within 3 % on a quiet box; 10 % here: short runs)
+    # compact secondary legs the plain command carries: four steps of the 1-3-objects / five-crop-sizes frames, 50 runs of the batch-1 live loop
+    sw, lat = d["sweep"], d["latency"]
+    assert sw["steps"] == 4 and sw["unit"] == "frames/s" and 0 < sw["value"] < d["value"] * 1.2 and len(sw["crop_buckets_last_step"]) >= 4
+    assert "parity" not in sw and sw["pose_graphs"] is True
+    assert lat["runs"] == 50 and lat["objects"] == 1 and 0 < lat["min_ms"] <= lat["p50_ms"] <= lat["p99_ms"] < 50
     ks = d["roofline"]["kernels"]
     assert len(ks) == 5 and d["roofline"]["kernel"] == ks[0]["kernel"]
     for k in ks:

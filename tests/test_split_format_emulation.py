@@ -1,0 +1,166 @@
+"""Go / no-go numerics for cheaper operand splits in the segmentor's dense layers, by EMULATION on
+the CPU restatement: the convolutions the product runs in its pre-split ("S32") kernels -- every conv with Cin >= 128 -- are evaluated
+with their operands rounded the way a candidate instruction mix would see them, everything else as the product does today (bf16x3),
+and the resulting class maps are compared with the exact-fp32 restatement under the bench's own mask criterion (bench.parity_block:
+a pixel may flip only where the oracle's top-2 doubly-soft-maxed probabilities are closer than 1e-4).
+
+    bf16x3    x = xh + xl, w = wh + wl (bf16 each): xh wh + xl wh + xh wl                     3 bf16 MFMAs per product: 12 passes / 32 k (today)
+    f16a      x1 = fp16(x) only, w = w1 + w2 (fp16 each): x1 w1 + x1 w2                       2 f16 MFMAs: 8 passes, activations 2 B / element
+    f16+mx8   x1 w1 exact + mx8(x1) mx8(w2) + mx8(x2) mx8(w1), x2 = x - x1, w2 = w - w1       1 f16 + 2 block-scaled e4m3 (16x16x128): 8 passes
+    f16+mx6   the same with block-scaled e2m3 cross terms                                     1 f16 + 2 block-scaled e2m3: 6 passes
+
+A block = 32 consecutive input channels of one pixel (one weight row and tap): what one lane of v_mfma_scale_f32_16x16x128_f8f6f4 holds.
+Minutes of CPU time, so it only runs when asked:  APE_EMULATE_SPLITS=1 python -m pytest tests/test_split_format_emulation.py -s
+The numbers it printed on this tree are in DESIGN.md 6e."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from autoposeestimation_amd import synthetic as S
+
+pytestmark = pytest.mark.skipif(os.environ.get("APE_EMULATE_SPLITS") != "1", reason="minutes of CPU time: set APE_EMULATE_SPLITS=1")
+
+N_CLASSES = 13
+
+
+def bf16(v):
+    return v.to(torch.bfloat16).to(torch.float32)
+
+
+def f16(v):
+    return v.to(torch.float16).to(torch.float32)
+
+
+def _blocks(v, axis):
+    """v with `axis` (a multiple of 32 long) split into (..., n / 32, 32, ...) -> (blocked view moved so that the 32 are last, undo)"""
+    v = v.movedim(axis, -1)
+    shp = v.shape
+    return v.reshape(*shp[:-1], shp[-1] // 32, 32), (lambda q: q.reshape(shp).movedim(-1, axis))
+
+
+def mx8(v, axis=1):
+    """block-scaled e4m3: one power-of-two scale per 32 elements, block maximum mapped into [256, 512) and clamped to 448"""
+    b, undo = _blocks(v, axis)
+    amax = b.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 8.0)
+    return undo((b / scale).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32) * scale)
+
+
+def mx6(v, axis=1):
+    """block-scaled e2m3 (2 exponent bits, 3 mantissa bits, maximum 7.5, subnormal step 0.125): block maximum mapped into [4, 8)"""
+    b, undo = _blocks(v, axis)
+    amax = b.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 2.0)
+    u = (b / scale).clamp(-7.5, 7.5)
+    e = torch.floor(torch.log2(u.abs().clamp_min(1.0)))         # 0, 1, 2 for |u| in [1,2), [2,4), [4,8); below 1: the subnormal step
+    step = torch.exp2(e - 3.0)
+    return undo(torch.round(u / step) * step * scale)
+
+
+def split_products(x, w, scheme):
+    """-> [(activation part, weight part), ...]: conv(x, w) ~ sum of conv(part_x, part_w)"""
+    if scheme == "f32":
+        return [(x, w)]
+    if scheme == "bf16x3":
+        xh, wh = bf16(x), bf16(w)
+        return [(xh, wh), (bf16(x - xh), wh), (xh, bf16(w - wh))]
+    x1, w1 = f16(x), f16(w)
+    if scheme == "f16a":
+        return [(x1, w1), (x1, f16(w - w1))]
+    q = {"f16+mx8": mx8, "f16+mx6": mx6}[scheme]
+    return [(x1, w1), (q(x1), q(w - w1)), (q(x - x1), q(w1))]
+
+
+class _Shim:
+    """stands in for torch.nn.functional inside the oracle module: conv2d with emulated operand rounding, the rest passed through"""
+
+    def __init__(self, scheme):
+        self.scheme = scheme
+        self.max_abs_input = 0.0
+        self.pending_up = None        # psp_upsample: the product rounds the LOW-resolution activations, then mixes, then interpolates
+
+    def __getattr__(self, name):
+        return getattr(F, name)
+
+    def interpolate(self, x, **kw):
+        # (conv(up(x)) = up-gather(mix(x)) is linear in x: remember the low-resolution tensor so that conv2d can round it BEFORE the
+        # interpolation, as the S32 kernels do)
+        out = F.interpolate(x, **kw)
+        self.pending_up = (x, kw, out)
+        return out
+
+    def conv2d(self, x, w, b=None, stride=1, padding=0, dilation=1):
+        up, self.pending_up = self.pending_up, None
+        s32_layer = w.shape[1] >= 128 and w.shape[1] % 32 == 0
+        scheme = self.scheme if s32_layer else ("f32" if self.scheme == "f32" else "bf16x3")
+        src = x
+        if up is not None and up[2] is x:
+            src = up[0]
+        if s32_layer:
+            self.max_abs_input = max(self.max_abs_input, float(src.abs().max()))
+        out = None
+        for xp, wp in split_products(src, w, scheme):
+            if src is not x:
+                xp = F.interpolate(xp, **up[1])
+            y = F.conv2d(xp, wp, None, stride, padding, dilation)
+            out = y if out is None else out + y
+        return out if b is None else out + b[None, :, None, None]
+
+
+def _logits(O, sd, frames, scheme):
+    shim = _Shim(scheme)
+    old = O.F
+    O.F = shim
+    try:
+        with torch.no_grad():
+            out = [O.pspnet_forward(sd, O.seg_input(rgb), "", "resnet18", logits_only=True)[:, :N_CLASSES] for rgb in frames]
+    finally:
+        O.F = old
+    return torch.cat(out), shim.max_abs_input
+
+
+def test_candidate_splits_against_the_mask_criterion():
+    from oracle import densefusion_oracle as O
+    torch.set_num_threads(8)
+    sd = S.pspnet_state_dict("resnet18", seed=5, stem_gain=1.0)
+    # the bench's segmentor: the final 1x1 conv fitted by least squares on frozen random features (bench.build_models), here on the oracle's
+    fit = [S.synthetic_frame(10_000 + i, cls=1 + i % 12) for i in range(4)]
+    feats, labels = [], []
+    for rgb, _, label in fit:
+        taps = {}
+        with torch.no_grad():
+            O.pspnet_forward(sd, O.seg_input(rgb), "", "resnet18", taps=taps, logits_only=True)
+        f = taps["up_3"][0].permute(1, 2, 0).reshape(-1, 64)
+        flat = label.reshape(-1)
+        fg = np.nonzero(flat)[0]
+        bg = np.random.default_rng(0).choice(np.nonzero(flat == 0)[0], size=6 * len(fg), replace=False)
+        sel = torch.from_numpy(np.concatenate([fg, bg]))
+        feats.append(f[sel])
+        labels.append(torch.from_numpy(flat.astype(np.int64))[sel])
+    w, b = S.fit_final_layer(torch.cat(feats), torch.cat(labels), N_CLASSES)
+    fw, fb = sd["final.0.weight"].clone(), sd["final.0.bias"].clone()
+    fw[:N_CLASSES, :, 0, 0], fb[:N_CLASSES] = w, b
+    sd["final.0.weight"], sd["final.0.bias"] = fw, fb
+
+    frames = [S.synthetic_frame(i, cls=1 + i % 12)[0] for i in range(int(os.environ.get("APE_EMULATE_FRAMES", "4")))]
+    exact, _ = _logits(O, sd, frames, "f32")
+    pr = F.softmax(F.softmax(exact, 1), 1)                           # what full_prediction arg-maxes (pipeline/utils.py:430 after predict's own)
+    top = torch.topk(pr, 2, dim=1).values
+    margin = top[:, 0] - top[:, 1]
+    lab = exact.argmax(1)
+    rows = {}
+    for scheme in ("bf16x3", "f16a", "f16+mx8", "f16+mx6"):
+        got, amax = _logits(O, sd, frames, scheme)
+        flips = got.argmax(1) != lab
+        dpr = (F.softmax(F.softmax(got, 1), 1) - pr).abs().max()
+        rows[scheme] = {"max_dlogit": float((got - exact).abs().max()), "rms_dlogit": float((got - exact).pow(2).mean().sqrt()),
+                        "max_dprob": float(dpr), "flips": int(flips.sum()), "flips_outside_band": int((flips & (margin >= 1e-4)).sum()),
+                        "largest_flipped_margin": float(margin[flips].max()) if flips.any() else 0.0, "max_abs_s32_input": amax}
+        print("%-8s %s" % (scheme, rows[scheme]))
+    print("pixels %d, in the 1e-4 band %d, logit range %.2f .. %.2f" % (lab.numel(), int((margin < 1e-4).sum()), float(exact.min()), float(exact.max())))
+    # today's mode must satisfy the bench's criterion in this emulation too (it does on the GPU: bench parity block)
+    assert rows["bf16x3"]["flips_outside_band"] == 0
+    assert rows["bf16x3"]["max_abs_s32_input"] < 65504.0             # (fp16 main products need the activations inside fp16's range)
