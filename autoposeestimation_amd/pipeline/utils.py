@@ -56,12 +56,15 @@ class FramePipeline:
         # the bucket's object table and the sampling seed through the pipeline's own static copies) and leaves pose / n_cand / choose in
         # static outputs that the caller copies from.  Results are those of the eager launches, kernel for kernel.
         # Replays of different buckets are independent and each fills a small part of the chip (a bucket holds 1..10 crops): they go out on
-        # a few side streams side by side and the caller's stream joins them before it scatters the results.
+        # side streams side by side (APE_BUCKET_STREAMS, default 32: one per bucket) and the caller's stream joins them before it scatters
+        # the results.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4: two chains then run side by side,
+        # not four); the process has to set that variable before its first HIP call (bench.py does: 40) for the streams to be concurrent.
         self.pose_graphs = bool(pose_graphs)
-        self._bucket_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("APE_BUCKET_STREAMS", "4")))] if pose_graphs else []
+        self._bucket_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("APE_BUCKET_STREAMS", "32")))] if pose_graphs else []
         self._graphs = {}
         self._seen = set()
         self._static_objmap = None
+        self.host_poses_s = 0.0        # host time spent inside poses() (enqueue only: nothing in there waits for the GPU once the graphs exist)
 
     # -- stage 1: segmentation + components, all on device ---------------------------------------------------------
     def segment(self, rgb, inject_logits=None):
@@ -85,6 +88,13 @@ class FramePipeline:
     def poses(self, rgb, depth, objmap, objects, meta, choose_override=None, seed=0):
         """objects: list of (frame, cls, rmin, rmax, cmin, cmax).  Returns (pose[n,7] f64 cuda, n_cand[n] i32 cuda,
         choose[n,N] i64 cuda) in the order of `objects`."""
+        t_host = time.perf_counter()
+        try:
+            return self._poses(rgb, depth, objmap, objects, meta, choose_override, seed)
+        finally:
+            self.host_poses_s += time.perf_counter() - t_host
+
+    def _poses(self, rgb, depth, objmap, objects, meta, choose_override, seed):
         n = len(objects)
         dev = rgb.device
         obj_np = np.asarray(objects, dtype=np.int32).reshape(n, 6)
@@ -108,14 +118,18 @@ class FramePipeline:
             start = torch.cuda.Event()
             start.record(cur)
             joins = []
-        for k, (hc, wc) in enumerate(uniq.tolist()):
+        # buckets in the order of falling work (crop area x objects): their replays run side by side on the bucket streams, so the longest
+        # chain should start first; results are scattered by object index, the order changes nothing else
+        work = [-(int(hc) * int(wc) * int((inv == k).sum())) for k, (hc, wc) in enumerate(uniq.tolist())]
+        for pos, k in enumerate(np.argsort(work, kind="stable").tolist()):
+            hc, wc = map(int, uniq[k])
             ids = np.nonzero(inv == k)[0]
             sub = obj_np[ids]
             # one small H2D, from pinned memory and non-blocking: a pageable copy would park the host until the stream (the pose stream
             # still busy with the previous batch) reaches it
             both_h = torch.from_numpy(np.ascontiguousarray(np.concatenate([sub, sub[:, [0, 2, 4]]], 1))).pin_memory()
             if use_graphs:
-                side = self._bucket_streams[k % len(self._bucket_streams)] if fan and self._has_graph(rgb, depth, both_h.shape[0], hc, wc, meta, cur) else None
+                side = self._bucket_streams[pos % len(self._bucket_streams)] if fan and self._has_graph(rgb, depth, both_h.shape[0], hc, wc, meta, cur) else None
                 if side is not None:            # a replay: on one of the bucket streams, beside the other buckets' replays
                     side.wait_event(start)
                     with torch.cuda.stream(side):

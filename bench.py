@@ -18,8 +18,14 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The `sweep` leg replays one captured graph per
+# crop-size bucket on its own stream (FramePipeline(pose_graphs=True)): with four queues two chains run side by side, with one queue
+# per stream all of them do (pose stage of the ragged batch 32 -> 17 ms).  Must be set before the first HIP call; no effect on `value`
+# (same-box A/B of 2 / 4 / 8 / 16 queues: 31.85 ms per step each).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "40")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -305,7 +311,11 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
     mframes = [S.mixed_frame(rank * 100003 + i) for i in range(n)]
     rgb = torch.from_numpy(np.stack([f[0] for f in mframes])).to(device)
     depth = torch.from_numpy(np.stack([f[1] for f in mframes])).to(device)
-    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=args.overlap,
+    # With the buckets' graphs fanned over their own streams the step runs as segmentation, THEN all pose chains side by side (45 ms); beside
+    # the next batch's segmentation -- persistent workgroups that own every CU -- the chains only advance at its kernel boundaries (48 ms).
+    # The eager launches (--no-pose-graphs) keep the software-pipelined loop: there the host is the bound.
+    overlap = bool(args.overlap and args.no_pose_graphs)
+    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=overlap,
                          pose_graphs=not args.no_pose_graphs)
 
     def tail(out):
@@ -324,7 +334,7 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
     def run(count, seed0):
         out = None
         n_obj = 0
-        if not args.overlap:
+        if not overlap:
             for i in range(count):
                 out = tail(pipe.run(rgb, depth, S.REALSENSE_META, seed=seed0 + i))
                 n_obj += len(out["objects"])
@@ -339,6 +349,7 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
 
     run(3, 0)       # (a crop-size bucket runs eagerly on its first occurrence, is captured on its second and replayed from the third on)
     fence()
+    pipe.host_poses_s = 0.0
     t0 = time.perf_counter()
     out, n_obj = run(steps, 3)
     fence()
@@ -362,11 +373,14 @@ def mixed_sweep(args, rank, world, device, dist, seg, est, ref, seg_sd, est_sd, 
              "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "frames_per_gpu_per_step": n,
              "objects_per_step_rank0": len(out["objects"]), "objects_painted_rank0": sum(len(f[3]) for f in mframes),
              "crop_buckets_last_step": dict(sorted(buckets.items())), "painted_sizes_rank0": dict(sorted(painted.items())),
-             "overlap": bool(args.overlap), "pose_graphs": not args.no_pose_graphs,
+             "overlap": overlap, "pose_graphs": not args.no_pose_graphs, "bucket_streams": len(pipe._bucket_streams),
+             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+             "host_pose_enqueue_ms_per_step": round(pipe.host_poses_s / steps * 1e3, 3),
              "note": "synthetic.mixed_frame: 1-3 painted objects of distinct classes per 640x480 frame, sizes drawn from {70x70, 110x150, 150x150, "
                      "230x230, 310x390} (crops 80x80 .. 320x400, SURVEY.md 8d); one pose-stage pass per distinct crop size of the batch, each "
                      "replayed as ONE captured HIP graph (FramePipeline(pose_graphs=True): the ~90 launches of a bucket are captured on its second "
-                     "occurrence; --no-pose-graphs enqueues them one by one); run after the timed region, never part of `value`"}
+                     "occurrence; --no-pose-graphs enqueues them one by one) on a stream of its own, all buckets side by side behind the batch's "
+                     "segmentation; run after the timed region, never part of `value`"}
     if with_parity and not args.no_cpu_baseline and world == 1:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import densefusion_oracle as O
