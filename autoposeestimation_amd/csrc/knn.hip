@@ -10,13 +10,15 @@
 //       wavefronts to fill 256 CUs even for 1000 queries); lane s scans refs s, s+S, ... in ascending
 //       order with a strict '<', then the S partial minima are merged by wave shuffles with the
 //       (distance, index) lexicographic rule -> exactly "lowest index wins ties" (knn_cpu.cpp:30).
-//   knn1_d3_q<Q>  (the same, for query counts that fill the chip many times over -- the training loss's 10^6 queries, loss.py:38-47): one
-//     lane owns Q queries, so one (broadcast) ds_read_b128 of a ref feeds Q pair evaluations.  knn1_d3<1> reads 16 B from LDS per pair:
-//     4 LDS cycles per wave and pair against 22 VALU cycles per SIMD, four SIMDs on one LDS -- the LDS port is ~3/4 as busy as the
-//     vector units and the two limits meet (0.48 of the fp32 VALU rate, round 1); with Q = 4 the LDS share falls to a fifth of that.
-//     Same arithmetic per pair, same ascending scan with a strict '<' => the same indices bit for bit.  (Packed fp32 instructions do not
-//     help: v_pk_mul_f32 / v_pk_add_f32 issue at half the rate of their scalar forms on gfx950 -- two results per instruction, four
-//     cycles per wave -- MI355X_MICROARCH.md "price of one filler beside MFMAs".)
+//   knn1_d3_q<Q, G>  (the same, for query counts that fill the chip many times over -- the training loss's 10^6 queries, loss.py:38-47):
+//     one lane owns Q queries, so one (broadcast) LDS read of a ref feeds Q pair evaluations (knn1_d3<1> reads 16 B from LDS per pair: the
+//     LDS port was ~3/4 as busy as the vector units, 0.48 of the fp32 lane rate in round 1), and the refs go in groups of G = 8 whose
+//     distances are reduced with v_min3_f32 before ONE compare-and-select per group: 8.9 vector operations per pair instead of 11, the
+//     index inside the winning group recovered after the scan.  Same arithmetic per pair, a strict '<' between groups, the first equal
+//     distance inside the group => the same indices bit for bit.  The file is built WITHOUT hipcc's SLP vectoriser (Makefile): it
+//     pairs the x and z terms into v_pk_add_f32 / v_pk_mul_f32, which issue at half rate on gfx950 and cost moves and s_nops on top
+//     (10.7 issue slots per pair).  10^6 queries x 1000 refs: 0.272 -> 0.18-0.19 ms (0.74-0.79 of the fp32 lane rate at 11 operations per
+//     pair; 4 x 10^6: 0.95-0.99).
 //   knn_general  (any dim, any k <= ref_nb): one query per lane, stable insertion into a 64-entry list, ceil(k / 64) passes.
 //
 // Bit-exactness: d = ((dx*dx) + (dy*dy)) + (dz*dz) with __fmul_rn/__fadd_rn (no FMA contraction), the
@@ -74,9 +76,10 @@ __global__ __launch_bounds__(kBlock) void knn1_d3(const float* __restrict__ ref,
     if (valid && s == 0) idx[q] = (int64_t)besti + 1;
 }
 
-template <int Q>
+#define ABL_SCALAR(bits) ((bits) & 2)
+template <int Q, int G>
 __global__ __launch_bounds__(kBlock) void knn1_d3_q(const float* __restrict__ ref, const float* __restrict__ query,
-                                                    int64_t* __restrict__ idx, int ref_nb, int query_nb)
+                                                    int64_t* __restrict__ idx, int ref_nb, int query_nb, int g_dbg)
 {
     __shared__ float4 tile[kTile];
     const int b = blockIdx.y;
@@ -101,9 +104,34 @@ __global__ __launch_bounds__(kBlock) void knn1_d3_q(const float* __restrict__ re
         for (int i = threadIdx.x; i < n; i += kBlock)
             tile[i] = make_float4(ref[t0 + i], ref[ref_nb + t0 + i], ref[2 * (size_t)ref_nb + t0 + i], 0.f);
         __syncthreads();
-#pragma unroll 2
-        for (int r = 0; r < n; ++r) {
-            const float4 p = tile[r];               // every lane reads the same address: one broadcast
+        // Refs in groups of G: the G distances of a group are reduced with v_min3 / v_min (exact: a minimum does not round), and only the
+        // group minimum goes through the compare-and-select against the running best -- 8 + 3/8 + 3/8 vector operations per pair instead of
+        // 11.  A strict '<' on the group minimum keeps the FIRST group that holds the overall minimum; the index inside it is recovered
+        // after the scan (below).  The refs behind the last full group of the last tile are groups of one.
+        const int ng = ABL_SCALAR(g_dbg) ? 0 : n / G * G;
+#pragma unroll 1
+        for (int r = 0; r < ng; r += G) {
+            float d[Q][G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const float4 p = tile[r + i];       // every lane reads the same address: one broadcast
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {
+                    const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
+                    d[j][i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                float m = d[j][0];
+#pragma unroll
+                for (int i = 1; i + 1 < G; i += 2) m = __builtin_fminf(__builtin_fminf(m, d[j][i]), d[j][i + 1]);
+                if (G % 2 == 0) m = __builtin_fminf(m, d[j][G - 1]);
+                if (m < best[j]) { best[j] = m; besti[j] = t0 + r; }
+            }
+        }
+        for (int r = ng; r < n; ++r) {
+            const float4 p = tile[r];
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
                 const float dx = p.x - qx[j], dy = p.y - qy[j], dz = p.z - qz[j];
@@ -112,10 +140,24 @@ __global__ __launch_bounds__(kBlock) void knn1_d3_q(const float* __restrict__ re
             }
         }
     }
+    // besti = first ref of the first group that holds the minimum: the neighbour is the first ref of refs besti .. besti + G - 1 at exactly
+    // that distance (a group of one gives itself; all-inf / NaN distances keep besti, the reference's "lowest index").
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
         const int q = q0 + j * kBlock;
-        if (q < query_nb) idx[q] = (int64_t)besti[j] + 1;
+        if (q >= query_nb) continue;
+        int found = besti[j];
+        float dd[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {          // (all 3 G loads of a query in flight together: clamped addresses, no branches)
+            const int r = besti[j] + i < ref_nb ? besti[j] + i : ref_nb - 1;
+            const float dx = ref[r] - qx[j], dy = ref[ref_nb + r] - qy[j], dz = ref[2 * (size_t)ref_nb + r] - qz[j];
+            dd[i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        }
+#pragma unroll
+        for (int i = G - 1; i >= 0; --i)
+            if (besti[j] + i < ref_nb && dd[i] == best[j]) found = besti[j] + i;
+        idx[q] = (int64_t)found + 1;
     }
 }
 
@@ -166,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void knn_general(const float* __restrict__ 
     }
 }
 
-int g_knn_q = 0;        // ape_knn_debug: 1 = never the four-queries-per-lane form (A/B and bitwise tests)
+int g_knn_q = 0;        // ape_knn_debug bits: 1 = never the several-queries-per-lane form, 2 = that form without the group minima, 4 / 8 = always four / two queries per lane (A/B and bitwise tests)
 
 template <int S>
 void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, int ref_nb, int query_nb, hipStream_t st)
@@ -177,7 +219,7 @@ void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, 
 
 }  // namespace
 
-extern "C" int ape_knn_debug(int one_query_per_lane) { g_knn_q = one_query_per_lane ? 1 : 0; return APE_OK; }
+extern "C" int ape_knn_debug(int bits) { g_knn_q = bits; return APE_OK; }
 
 extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
                            int batch, int dim, int ref_nb, int query_nb, int k, void* stream)
@@ -192,10 +234,19 @@ extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
         const long total = (long)batch * query_nb;
         int s = 1;
         while (s < 64 && total * s < target && s * 4 <= ref_nb) s *= 4;
-        // enough queries to give every lane four of them and still fill the chip (8 waves per CU): the Q = 4 form
-        if (s == 1 && g_knn_q != 1 && total >= 4 * target && query_nb >= 4 * kBlock) {
-            dim3 grid(ape::ceil_div(query_nb, 4 * kBlock), batch);
-            hipLaunchKernelGGL(knn1_d3_q<4>, grid, dim3(kBlock), 0, st, ref, query, idx, ref_nb, query_nb);
+        // enough queries to give every lane several of them and still fill the chip: the knn1_d3_q forms
+        if (s == 1 && !(g_knn_q & 1) && total >= 4 * target && query_nb >= 4 * kBlock) {
+            // two queries per lane: faster than four at every size measured (10^6 queries: 0.177 vs 0.195 ms, 4 x 10^6: 0.568 vs 0.585 --
+            // twice the waves hide the vector pipe's own latencies and the LDS reads' better than the halved LDS traffic pays); four stay
+            // selectable for A/B
+            const bool four = (g_knn_q & 4) != 0;
+            if (four && !(g_knn_q & 8)) {
+                dim3 grid(ape::ceil_div(query_nb, 4 * kBlock), batch);
+                hipLaunchKernelGGL((knn1_d3_q<4, 8>), grid, dim3(kBlock), 0, st, ref, query, idx, ref_nb, query_nb, g_knn_q);
+            } else {
+                dim3 grid(ape::ceil_div(query_nb, 2 * kBlock), batch);
+                hipLaunchKernelGGL((knn1_d3_q<2, 8>), grid, dim3(kBlock), 0, st, ref, query, idx, ref_nb, query_nb, g_knn_q);
+            }
             return ape::check_launch("ape_knn_f32");
         }
         switch (s) {

@@ -705,7 +705,7 @@ def pose_main(args, rank, world, device, dist):
                                      "`knn_training_size` is the same arithmetic at a size that fills the chip"
                                      % (KNN_LANE_OPS_PER_PAIR, n),
                              "kernels": mfma},
-                "knn_training_size": {"kernel": "knn1_d3_q<4>", "refs": 1000, "queries": 1000000, "ms": round(knn_ms, 4),
+                "knn_training_size": {"kernel": "knn1_d3_q<2, 8>", "refs": 1000, "queries": 1000000, "ms": round(knn_ms, 4),
                                       "pairs_per_s": round(1e9 / (knn_ms * 1e-3), 0), "bound": "valu", "achieved": round(knn_ach, 3),
                                       "peak": round(PEAK_F32_LANE_OPS, 1), "unit": "T lane-op/s", "frac": round(knn_ach / PEAK_F32_LANE_OPS, 4)},
                 "adds_mean_m": round(float(dis.mean()), 6)}

@@ -73,10 +73,14 @@ def test_knn_full_size_property():
     assert torch.equal(idx, besti)
 
 
-@pytest.mark.parametrize("b,nr,nq,qz", [(1, 1000, 600_001, 0.25), (2, 5000, 300_000, 0.5), (1, 3, 1_000_003, 0.5), (1, 2049, 524_288, 0)])
-def test_knn_four_queries_per_lane_equals_one_query_per_lane(b, nr, nq, qz):
-    """the large-query kernel (knn1_d3_q<4>: one LDS read of a ref feeds four pair evaluations) against the one-query-per-lane kernel that
-    the oracle tests pin: ragged query counts, several ref tiles, batches, exact ties -- identical indices"""
+@pytest.mark.parametrize("b,nr,nq,qz", [(1, 1000, 600_001, 0.25), (2, 5000, 300_000, 0.5), (1, 3, 1_000_003, 0.5), (1, 2049, 524_288, 0),
+                                        (1, 1003, 2_200_000, 0.5), (1, 1000, 1_000_000, 0)])
+def test_knn_several_queries_per_lane_equal_one_query_per_lane(b, nr, nq, qz):
+    """the large-query kernels (knn1_d3_q<Q, G>: one LDS read of a ref feeds Q pair evaluations; the G distances of a group of refs are
+    reduced with v_min3 and only the group minimum is compared with the running best, the index inside the winning group recovered after
+    the scan) against the one-query-per-lane kernel that the oracle tests pin: ragged query counts, several ref tiles, ref counts that leave
+    groups of one at the end, batches, exact ties inside a group and across groups (coordinates on a coarse lattice), a ref at infinity --
+    identical indices from every form (Q = 2, Q = 4, with and without the group minima)"""
     from autoposeestimation_amd import _lib
     from autoposeestimation_amd.DenseFusion.lib.knn import KNearestNeighbor
     g = torch.Generator().manual_seed(nr + nq)
@@ -84,15 +88,18 @@ def test_knn_four_queries_per_lane_equals_one_query_per_lane(b, nr, nq, qz):
     qry = torch.randn(b, 3, nq, generator=g).cuda()
     if qz:
         ref, qry = (ref / qz).round() * qz, (qry / qz).round() * qz
+    if nr > 8:
+        ref[:, 0, 5] = float("inf")                    # an infinite distance inside a group never wins and never hides its neighbours
     knn = KNearestNeighbor(1)
-    got = knn(ref, qry)
     try:
         assert _lib.lib().ape_knn_debug(1) == 0
         want = knn(ref, qry)
+        for bits in (0, 2, 4, 8, 2 | 4, 2 | 8):
+            _lib.lib().ape_knn_debug(bits)
+            assert torch.equal(knn(ref, qry), want), bits
     finally:
         _lib.lib().ape_knn_debug(0)
-    assert torch.equal(got, want)
-    assert int(got.min()) >= 1 and int(got.max()) <= nr
+    assert int(want.min()) >= 1 and int(want.max()) <= nr
 
 
 def test_knn_rejects_host_tensor_and_bad_k():

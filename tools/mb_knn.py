@@ -19,10 +19,10 @@ def t(f, n=5, rounds=5):
 for b, nr, nq in ((1, 1000, 1_000_000), (1, 1000, 4_000_000), (64, 1000, 1000), (32, 1000, 1000), (1, 500, 1_000_000)):
     ref = torch.randn(b, 3, nr, device="cuda"); qry = torch.randn(b, 3, nq, device="cuda")
     row = []
-    for dbg in (0, 1):
+    for dbg in (0, 4, 8, 2, 1):
         _lib.lib().ape_knn_debug(dbg)
         ms = t(lambda: knn(ref, qry))
         pairs = b * nr * nq / (ms * 1e-3)
-        row.append("%s %.3f ms  %.2f Tpair/s  %.2f of the fp32 lane rate" % ("auto" if dbg == 0 else "one query per lane", ms, pairs / 1e12, pairs * 11 / PEAK_LANE_OPS))
+        row.append("%s %.3f ms %.2f" % ({0: "auto", 1: "one query per lane", 2: "no group minima", 4: "four per lane", 8: "two per lane"}[dbg], ms, pairs * 11 / PEAK_LANE_OPS))
     _lib.lib().ape_knn_debug(0)
-    print("%d x %d refs x %d queries:  %s  |  %s" % (b, nr, nq, row[0], row[1]))
+    print("%d x %d refs x %d queries:  %s" % (b, nr, nq, "  |  ".join(row)))
