@@ -224,7 +224,11 @@ def test_pose_buckets_replayed_as_hip_graphs_equal_the_eager_launches(pose_strea
             assert torch.equal(got[k], want[k]), (step, k)
     assert len(sizes) >= 3 and len(graphs._graphs) == len(sizes)          # several buckets, one graph each
     # a seed that changes the sampled pixels really reaches the replayed launch
-    a = graphs.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=11)["choose"].clone()
-    b = graphs.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=12)["choose"].clone()
+    def chosen(seed):
+        out = graphs.finish(dict(handle), rgb, depth, S.REALSENSE_META, seed=seed)
+        if out.get("stream") is not None:            # (the results belong to the pose stream: its consumer waits for it, FramePipeline.__init__)
+            torch.cuda.current_stream().wait_stream(out["stream"])
+        return out["choose"].clone()
+    a, b = chosen(11), chosen(12)
     torch.cuda.synchronize()
     assert not torch.equal(a, b)
