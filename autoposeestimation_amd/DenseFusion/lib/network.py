@@ -265,9 +265,9 @@ class _PSPPlan:
         f = y
         b, h, w, _ = f.shape
         nf = self.bott_feats.cin
-        pools = E.adaptive_avgpool_multi(f, (2, 3, 6))
-        pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f.to_f32(), 1)
-        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]       # (a prior conv reads the first 512 channels of its pooled map)
+        pools = E.adaptive_avgpool_multi(f, (2, 3, 6), channels=nf)             # (the map's 64 spare channels of the folded form are not pooled)
+        pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f.to_f32()[..., :nf].contiguous(), 1)
+        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]
         if fold:
             p = E.psp_bottleneck_folded(self.bott_feats, f, zs, out_fmt=S)
         else:

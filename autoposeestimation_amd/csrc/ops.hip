@@ -93,8 +93,9 @@ struct PoolPlan {
 // keeps one accumulator per atom column
 template <bool S32IN>
 __global__ __launch_bounds__(256) void avgpool_atoms_kernel(const float4* __restrict__ x, float4* __restrict__ atoms, const PoolPlan pl,
-                                                            int H, int W, int C4)
+                                                            int H, int W, int C4, int ld4)
 {
+    // C4 = float4 groups of channels pooled, ld4 = float4 groups per pixel of x (>= C4: trailing channels are not read)
     __shared__ float4 part[3][kPoolMaxAtoms][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int ay = blockIdx.x % pl.ny, b = blockIdx.x / pl.ny;
@@ -103,13 +104,24 @@ __global__ __launch_bounds__(256) void avgpool_atoms_kernel(const float4* __rest
 #pragma unroll
     for (int a = 0; a < kPoolMaxAtoms; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < C4) {
+        auto load = [&](long pix) { return S32IN ? ape::s32_load4(x, pix, ld4, c) : x[pix * ld4 + c]; };
         for (int y = pl.ye[ay] + g; y < pl.ye[ay + 1]; y += 4) {
-            const float4* row = x + ((long)(b * H + y) * W) * C4 + c;
+            const long row = (long)(b * H + y) * W;
 #pragma unroll
             for (int a = 0; a < kPoolMaxAtoms; ++a) {
                 if (a >= pl.nx) break;
-                for (int xx = pl.xe[a]; xx < pl.xe[a + 1]; ++xx) {
-                    const float4 v = S32IN ? ape::s32_load4(x, (long)(b * H + y) * W + xx, C4, c) : row[(long)xx * C4];
+                // four pixels' loads in flight before the first add (the sum keeps its pixel order: same result as one at a time)
+                int xx = pl.xe[a];
+                const int xend = pl.xe[a + 1];
+                for (; xx + 4 <= xend; xx += 4) {
+                    const float4 v0 = load(row + xx), v1 = load(row + xx + 1), v2 = load(row + xx + 2), v3 = load(row + xx + 3);
+                    acc[a].x += v0.x; acc[a].y += v0.y; acc[a].z += v0.z; acc[a].w += v0.w;
+                    acc[a].x += v1.x; acc[a].y += v1.y; acc[a].z += v1.z; acc[a].w += v1.w;
+                    acc[a].x += v2.x; acc[a].y += v2.y; acc[a].z += v2.z; acc[a].w += v2.w;
+                    acc[a].x += v3.x; acc[a].y += v3.y; acc[a].z += v3.z; acc[a].w += v3.w;
+                }
+                for (; xx < xend; ++xx) {
+                    const float4 v = load(row + xx);
                     acc[a].x += v.x; acc[a].y += v.y; acc[a].z += v.z; acc[a].w += v.w;
                 }
             }
@@ -789,8 +801,16 @@ extern "C" int ape_adaptive_avgpool_multi_nhwc_f32(const float* x, float* const*
 extern "C" int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H,
                                                    int W, int C, void* workspace, size_t workspace_bytes, void* stream)
 {
-    if ((in_fmt != APE_FMT_F32 && in_fmt != APE_FMT_S32) || (in_fmt == APE_FMT_S32 && C % 32)) return APE_EINVAL;
-    if (!x || !ys_host || !sizes_host || !workspace || nsizes < 1 || nsizes > kPoolMaxSizes || B < 0 || H < 1 || W < 1 || C < 4 || C % 4)
+    return ape_adaptive_avgpool_multi_nhwc_ld(x, in_fmt, ys_host, sizes_host, nsizes, B, H, W, C, C, workspace, workspace_bytes, stream);
+}
+
+/* ... of the first C channels of a map with ldx channels per pixel (ldx >= C; APE_FMT_S32: both % 32 == 0); outputs [B,s,s,C] */
+extern "C" int ape_adaptive_avgpool_multi_nhwc_ld(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H,
+                                                  int W, int C, int ldx, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if ((in_fmt != APE_FMT_F32 && in_fmt != APE_FMT_S32) || (in_fmt == APE_FMT_S32 && (C % 32 || ldx % 32))) return APE_EINVAL;
+    if (!x || !ys_host || !sizes_host || !workspace || nsizes < 1 || nsizes > kPoolMaxSizes || B < 0 || H < 1 || W < 1 || C < 4 || C % 4 ||
+        ldx < C || ldx % 4)
         return APE_EINVAL;
     if (B == 0) return APE_OK;
     PoolPlan pl;
@@ -810,10 +830,10 @@ extern "C" int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, fl
     hipStream_t st = (hipStream_t)stream;
     if (in_fmt == APE_FMT_S32)
         hipLaunchKernelGGL(avgpool_atoms_kernel<true>, dim3(B * pl.ny, ape::ceil_div(C / 4, 64)), dim3(256), 0, st, (const float4*)x,
-                           (float4*)workspace, pl, H, W, C / 4);
+                           (float4*)workspace, pl, H, W, C / 4, ldx / 4);
     else
         hipLaunchKernelGGL(avgpool_atoms_kernel<false>, dim3(B * pl.ny, ape::ceil_div(C / 4, 64)), dim3(256), 0, st, (const float4*)x,
-                           (float4*)workspace, pl, H, W, C / 4);
+                           (float4*)workspace, pl, H, W, C / 4, ldx / 4);
     const long total = (long)B * bins_total * (C / 4);
     hipLaunchKernelGGL(avgpool_bins_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, (const float4*)workspace, pl, B, H, W, C / 4,
                        bins_total);

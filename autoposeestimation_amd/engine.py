@@ -476,23 +476,25 @@ def adaptive_avgpool(x, s):
     return y
 
 
-def adaptive_avgpool_multi(x, sizes):
-    """{s: AdaptiveAvgPool2d((s, s))(x)} for several sizes in one pass over x[B,H,W,C]; per-size launches when the bin edges of
-    the sizes cut an axis into more than 12 atoms."""
+def adaptive_avgpool_multi(x, sizes, channels=None):
+    """{s: AdaptiveAvgPool2d((s, s))(x[..., :channels])} for several sizes in one pass over x[B,H,W,C]; per-size launches when the bin edges
+    of the sizes cut an axis into more than 12 atoms.  `channels` (default: all) pools the leading channels only and gives [B,s,s,channels]."""
     fmt = FMT_S32 if isinstance(x, S32) else FMT_F32
     xt = x.t if fmt == FMT_S32 else x
-    b, h, w, c = xt.shape
+    b, h, w, ld = xt.shape
+    c = ld if channels is None else int(channels)
     sizes = list(sizes)
     ys = [torch.empty(b, s, s, c, dtype=torch.float32, device=xt.device) for s in sizes]
     ws = _workspace(_lib.lib().ape_adaptive_avgpool_multi_workspace_bytes(b, c), xt.device)
     ptrs = (ctypes.c_void_p * len(sizes))(*[y.data_ptr() for y in ys])
     szs = (ctypes.c_int * len(sizes))(*sizes)
-    rc = _lib.lib().ape_adaptive_avgpool_multi_nhwc_fmt(_lib.dptr(xt, torch.float32), fmt, ptrs, szs, len(sizes), b, h, w, c, _lib.dptr(ws),
-                                                        ws.numel() * ws.element_size(), _st())
+    rc = _lib.lib().ape_adaptive_avgpool_multi_nhwc_ld(_lib.dptr(xt, torch.float32), fmt, ptrs, szs, len(sizes), b, h, w, c, ld, _lib.dptr(ws),
+                                                       ws.numel() * ws.element_size(), _st())
     if rc == -1:      # APE_EINVAL: too many atoms for this geometry
         xf = x.to_f32() if fmt == FMT_S32 else x
+        xf = xf if c == ld else xf[..., :c].contiguous()
         return {s: adaptive_avgpool(xf, s) for s in sizes}
-    _lib.check(rc, "ape_adaptive_avgpool_multi_nhwc_fmt")
+    _lib.check(rc, "ape_adaptive_avgpool_multi_nhwc_ld")
     return dict(zip(sizes, ys))
 
 

@@ -134,6 +134,10 @@ int ape_conv_gemm_bf16_splitk(const float* x, const void* w_packed, const float*
                               const ape_conv_params* params, int nsplit, void* workspace, size_t workspace_bytes, void* stream);
 int ape_adaptive_avgpool_multi_nhwc_fmt(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H, int W,
                                         int C, void* workspace, size_t workspace_bytes, void* stream);
+/* ... of the first C channels of a map that holds ldx channels per pixel (the PSP module's feature map with the 64 spare channels of
+ * ape_psp_fold_operands behind its 512: pspnet.py:15 pools the 512); outputs [B,s,s,C] fp32 */
+int ape_adaptive_avgpool_multi_nhwc_ld(const void* x, int in_fmt, float* const* ys_host, const int* sizes_host, int nsizes, int B, int H, int W,
+                                       int C, int ldx, void* workspace, size_t workspace_bytes, void* stream);
 int ape_upconv3x3_gather_fmt(const float* z, const float* bias, void* out, int out_fmt, int B, int h, int w, int C, int act, float alpha,
                              void* stream);
 /* ... and with the interpolation arithmetic chosen: fma = 0 separately rounded products like ape_bilinear_nhwc_f32 (what the two entry

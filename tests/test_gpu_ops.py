@@ -122,6 +122,29 @@ def test_adaptive_avgpool_multi(shape):
         assert (got[s].cpu() - want).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("s32", [False, True])
+@pytest.mark.parametrize("shape", [(2, 60, 80, 576, 512), (3, 20, 20, 96, 64), (1, 9, 14, 64, 32)])
+def test_adaptive_avgpool_multi_of_the_leading_channels(shape, s32):
+    """ape_adaptive_avgpool_multi_nhwc_ld: the first C channels of a map with ldx channels per pixel (the PSP feature map with the folded
+    form's 64 spare channels behind it), fp32 and pre-split input: bit for bit what pooling a contiguous copy of those channels gives,
+    whatever the trailing channels hold (NaN here)"""
+    from autoposeestimation_amd import engine as E
+    b, h, w, ld, c = shape
+    x = torch.randn(b, h, w, ld, generator=torch.Generator().manual_seed(ld * h)).cuda()
+    lead = x[..., :c].contiguous()
+    if s32:
+        xs, ls = E.S32.from_f32(x), E.S32.from_f32(lead)
+        xs.t[..., c:] = float("nan")               # (the trailing chunks of the pre-split image)
+        got, want = E.adaptive_avgpool_multi(xs, (2, 3, 6), channels=c), E.adaptive_avgpool_multi(ls, (2, 3, 6))
+    else:
+        x[..., c:] = float("nan")
+        got, want = E.adaptive_avgpool_multi(x, (2, 3, 6), channels=c), E.adaptive_avgpool_multi(lead, (2, 3, 6))
+    for s in (2, 3, 6):
+        assert got[s].shape == (b, s, s, c) and torch.equal(got[s], want[s])
+        ref = F.adaptive_avg_pool2d(lead.permute(0, 3, 1, 2).cpu(), s).permute(0, 2, 3, 1)
+        assert (got[s].cpu() - ref).abs().max().item() <= (2e-4 if s32 else 2e-6)
+
+
 @pytest.mark.parametrize("div255", [True, False])
 @pytest.mark.parametrize("geom", [(3, 96, 128, None), (2, 480, 640, None), (5, 160, 160, "crops"), (4, 80, 120, "crops"), (3, 41, 57, "crops")])
 def test_stem_on_uint8_frames_equals_preprocess_then_stem_bitwise(geom, div255):
