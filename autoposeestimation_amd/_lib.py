@@ -48,6 +48,10 @@ SIGNATURES = {
     "ape_upconv3x3_fused_seghead_s32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _I, _P, _P, _I, _P],
     "ape_conv3x3_halo_s32_supported": [_P],
     "ape_conv3x3_halo_s32": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
+    "ape_conv3x3_halo_mx_supported": [_P],
+    "ape_conv3x3_halo_mx": [_P, _P, _P, _P, _I, _P, _I, _P, _P],
+    "ape_conv3x3_halo_mx_debug": [_I],
+    "ape_s32_to_f16m6": [_P, _P, _c.c_long, _I, _P],
     "ape_stem_conv_pool_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "ape_stem_conv_pool_u8": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ape_conv3x3_halo_supported": [_P],

@@ -1,0 +1,743 @@
+// 3x3 / stride 1 / pad == dilation in {1,2,4} convolution on "F16M6" operands (autoposeestimation_amd/mx6.py): conv3x3_halo_s32.hip's
+// tile, rings, LDS-DMA schedule, tile walk and epilogue, with HALF the matrix passes per product:
+//     x . w  ~  x1 w1  +  Q(x1) Q(w2)  +  Q(x2) Q(w1)        x1 = fp16(x), x2 = x - x1, Q = block-scaled e2m3 (one E8M0 scale per 32 channels)
+//   * main product: v_mfma_f32_16x16x32_f16 on the lines' first 64 bytes (4 passes per tap and 16 x 16 block, as ONE of today's three
+//     bf16 instructions);
+//   * both cross terms of TWO taps in one v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 operands (4 passes): its four 32-k sub-blocks are
+//     lane groups g = lane >> 4 = (tap t: Q(x1) Q(w2) | tap t: Q(x2) Q(w1) | tap t+1: Q(x1) Q(w2) | tap t+1: Q(x2) Q(w1)), every lane
+//     group reading ITS field (and its scale byte) of ITS tap's pixel / weight row -- issued at the even taps of a chunk, whose closing
+//     barrier of the tap before already made tap t+1's weights visible; tap 8 pairs with nothing: its lane groups 2, 3 get scale 2^-127
+//     on both sides (the product underflows to zero; e2m3 has no NaN / Inf codes, so whatever those lanes read is finite);
+//   * 6 passes per tap and block on average against 12: tools/probes/mfma_mix_probe.hip; operand layout of the scaled instruction:
+//     tools/probes/mx6_layout_probe.hip.
+// Numerics (tests/test_split_format_emulation.py): for layer 4's three 512 -> 512 convolutions the class maps move as little
+// as with bf16x3 (24 frames: 9 flipped near-tie pixels either way, largest flipped margin 2.2e-5 against 1.6e-5, band 1e-4).
+// The input image comes from ape_s32_to_f16m6 (one pass over the S32 tensor); output formats, residual, bias, activations as halo_s32.
+#include <type_traits>
+#include "common.h"
+
+// timing-only ablation switches (results wrong when set): compiled out of the ISA-audit build (tools/isa_audit.py, -DAPE_NO_ABLATIONS)
+#ifdef APE_NO_ABLATIONS
+#define ABL(bit) 0
+#else
+#define ABL(bit) (a.dbg & (bit))
+#endif
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct HaloMxArgs {
+    const char* x;          // F16M6 activations [B][H][W][ldx] (128-B lines per 32 channels)
+    const char* w;          // F16M6 weights [Cout][9 * Cin / 32][128 B], K order (tap, channel)
+    const float* bias;
+    const char* res;
+    char* y;
+    int B, H, W, Cin, Cout;
+    int ldx, xoff, ldy, yoff, ldr, roff;
+    int act;
+    float alpha;
+    int bias_bstride;
+    int out_fmt, res_fmt;
+    int tiles_x, tiles_y, n_tiles;
+    int dbg;                // ape_conv3x3_halo_mx_debug: 1 = static priority 1 for waves 4-7, 2 = one workgroup per tile instead of the
+                            // persistent walk, 16 = four rows per wave-row group in every tile (results unchanged by any of them);
+                            // timing-only ablations: 4 = no epilogue stores, 8 = no residual loads, 32 = no cross terms (reads and MFMAs), 64 = no main MFMAs,
+                            // 128 = no cross MFMAs (their reads stay), 256 = no in-loop DMA
+};
+
+// NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
+// per element: ~1.8 k scalar instructions in a 256-element epilogue); same values bit for bit (1 * v == v, also for -0 and NaN)
+__device__ __forceinline__ float act_h(float v, int act, float alpha)
+{
+    if (act == APE_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    const float neg = act == APE_ACT_RELU ? 0.f : (act == APE_ACT_PRELU ? alpha : 1.f) * v;
+    return v > 0.f ? v : neg;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define APE_DS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#else
+#define APE_DS_READ(dst, addr, off) (void)(addr)
+#endif
+
+
+// fragment reads of HALF a tap's main operands (asm operands cannot name variables captured by a generic lambda, hence free functions): the
+// fp16 piece of two pixel rows at their own ring-row addresses and of two of the four 16-channel weight blocks (2 KB apart)
+template <int JOFF>
+__device__ __forceinline__ void ds_read_half(u32x4 (&A)[2], u32x4 (&Bf)[4], unsigned a0, unsigned a1, unsigned b)
+{
+    APE_DS_READ(A[0], a0, 0);
+    APE_DS_READ(A[1], a1, 0);
+    APE_DS_READ(Bf[JOFF], b, JOFF * 2048);
+    APE_DS_READ(Bf[JOFF + 1], b, JOFF * 2048 + 2048);
+}
+// one 32-byte field (24 B of e2m3 codes | scale byte | 7 B of zeros): its two 16-B chunks sit at their own swizzled slots
+__device__ __forceinline__ void ds_read_field(u32x4 (&F)[2], unsigned lo_addr, unsigned hi_addr)
+{
+    APE_DS_READ(F[0], lo_addr, 0);
+    APE_DS_READ(F[1], hi_addr, 0);
+}
+template <int J>
+__device__ __forceinline__ void ds_read_field_b(u32x4 (&F)[2], unsigned lo_addr, unsigned hi_addr)
+{
+    APE_DS_READ(F[0], lo_addr, J * 2048);
+    APE_DS_READ(F[1], hi_addr, J * 2048);
+}
+
+// keeps asm-read destinations allocated up to this point (a free function: asm operands cannot name variables captured by a generic
+// lambda; device pass only: the host pass cannot check a "v" constraint)
+__device__ __forceinline__ void keep_regs(const u32x4& a, const u32x4& b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"(a), "v"(b));
+#endif
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediate must be a literal)
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#endif
+}
+
+constexpr int TS = 16;                  // output tile edge
+constexpr int HWP = 24;                 // pixels per ring row (3 DMA pieces); the halo needs 16 + 2 d <= 24 of them
+constexpr int ROW_B = HWP * 128;        // 3072 B
+constexpr int RING_ROWS = 32;
+constexpr int A_BYTES = RING_ROWS * ROW_B;          // 96 KB
+constexpr int B_TILE = 128 * 128;                   // one tap's weights: 128 rows x (hi 64 B | lo 64 B)
+constexpr int B_RING = 4;
+constexpr int LDS_BYTES = A_BYTES + B_RING * B_TILE;   // 160 KB
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void halo_mx_kernel(const HaloMxArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int I = TS + 2 * D;       // image rows of one chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- the tile walk: logical tile ids are dealt to the XCDs in contiguous runs (bijective remap of the dispatch id); a persistent
+    // workgroup takes dispatch ids blockIdx, + gridDim, ... -- all on its own XCD's run, and (the host sizes the grid so) all with the
+    // same channel tile n_tile, so neighbouring workgroups keep sharing one spatial tile's halo through their XCD's L2
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int nwg = a.B * tiles_per_img * a.n_tiles;
+    const int q = nwg / 8, r = nwg % 8;
+    const int grid = (int)gridDim.x;
+    const int my_tiles = (nwg - 1 - (int)blockIdx.x) / grid + 1;
+    int cur_b, cur_y0, cur_x0, n0;
+    auto decode = [&](int orig, int& tb, int& ty0, int& tx0, int& tn0) {
+        const int xcd = orig % 8;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+        const int n_tile = logical % a.n_tiles;
+        const int mt = logical / a.n_tiles;
+        tb = mt / tiles_per_img;
+        const int trem = mt - tb * tiles_per_img;
+        ty0 = (trem / a.tiles_x) * TS;
+        tx0 = (trem % a.tiles_x) * TS;
+        tn0 = n_tile * 128;
+    };
+    int cur_orig = blockIdx.x;
+    decode(cur_orig, cur_b, cur_y0, cur_x0, n0);
+    // rows per pixel-row group of waves in a tile at image row ty0 (4, or fewer when the tile holds fewer than 13 / 9 / 5 image rows), times
+    // this wave's group index: the tile row this wave's first output row is (dbg bit 16: always 4)
+    auto rows_per_wave = [&](int ty0) { const int rows = a.H - ty0 < TS ? a.H - ty0 : TS; return (a.dbg & 16) ? 4 : (rows + 3) >> 2; };
+    int rpw = rows_per_wave(cur_y0), rpw_next = rpw;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nchunks = a.Cin / 32;
+    const int K = 9 * a.Cin;
+    const int total_chunks = my_tiles * nchunks;
+    const int total_taps = total_chunks * 9;
+
+    // ---- DMA sources ---------------------------------------------------------------------------------------------------------
+    const long x_bytes = (long)a.B * a.H * a.W * a.ldx * 4;
+    const long w_bytes = (long)(a.Cout - n0) * K * 4;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.w + (long)n0 * K * 4), 0, (int)(w_bytes > 0x7FFFFFFFL ? 0x7FFFFFFFu : (unsigned)w_bytes), 0x00020000);
+    // the tile whose image is being streamed in ("DMA tile"): the current tile until its last chunk's tap 0, then the next one.
+    // a halo piece = 8 pixels of one image row: lanes 8 j .. 8 j + 7 fetch pixel j's 128-B line, chunks permuted by the column swizzle
+    int dma_b = cur_b, dma_y0 = cur_y0;
+    unsigned lane_x[3];
+    auto set_dma_tile = [&](int tb, int ty0, int tx0) {
+        dma_b = tb;
+        dma_y0 = ty0;
+        int ln = lane;          // (opaque: the lane-only parts of the offsets are loop-invariant, and hoisted out of the tile loop they get spilled --
+        asm volatile("" : "+v"(ln));       // a scratch reload per tile whose vmcnt(0) drains the DMA pipeline)
+#pragma unroll
+        for (int xp = 0; xp < 3; ++xp) {
+            const int hx = xp * 8 + (ln >> 3);
+            const int gx = tx0 - D + hx;
+            const bool ok = hx < TS + 2 * D && (unsigned)gx < (unsigned)a.W;
+            lane_x[xp] = ok ? (unsigned)((gx * a.ldx + a.xoff) * 4 + (((ln & 7) ^ ((hx >> 1) & 7)) * 16)) : 0x80000000u;
+        }
+    };
+    set_dma_tile(cur_b, cur_y0, cur_x0);
+    unsigned vb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
+        vb[i] = (unsigned)(row * K * 4 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
+    // piece (row, x-piece xp) of channel chunk `c` of the DMA tile's image, written to ring row (ring0 + row) & 31
+    auto dma_a_piece = [&](int c, int ring0, int row, int xp) {      // xp: a literal at every call site
+        const int gy = dma_y0 - D + row;
+        const bool row_ok = (unsigned)gy < (unsigned)a.H;
+        const unsigned row_off = (unsigned)(((dma_b * a.H + (row_ok ? gy : 0)) * a.W) * a.ldx * 4 + c * 128);
+        unsigned voff = lane_x[xp] + row_off;
+        if (!row_ok) voff = 0xFFFFFFFFu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + ((ring0 + row) & (RING_ROWS - 1)) * ROW_B + xp * 1024), 16, voff, 0, 0, 0);
+    };
+    // The 3 * nrows pieces of image rows [r0, r0 + nrows) are dealt to the waves by (row * 3 + xp) % 8, i.e. for x-piece xp a wave
+    // takes the rows  r = 3 (wave - xp) mod 8, + 8, ...  (3 is its own inverse mod 8).  xp stays a compile-time index: lane_x[] must
+    // not be indexed at run time (it would live in scratch, and a scratch reload's vmcnt(0) would drain the DMA pipeline).
+    auto dma_a_rows_xp = [&](int c, int ring0, int r0, int nrows, auto xp_c) -> int {
+        constexpr int xp = decltype(xp_c)::value;
+        int n = 0;
+        for (int row = (3 * (wave - xp + 8)) & 7; row < nrows; row += 8) {
+            dma_a_piece(c, ring0, r0 + row, xp);
+            ++n;
+        }
+        return n;
+    };
+    // the weights of tap `tap` of channel chunk `c` (k-group tap * nchunks + c) into ring slot `slot`
+    auto dma_b_tap = [&](int c, int tap, int slot) {
+        const int g = tap * nchunks + c;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void*)(smem + A_BYTES + slot * B_TILE + (wave * 2 + i) * 1024), 16,
+                                                     vb[i], g * 128, 0, 0);
+    };
+
+    // ---- fragment addresses --------------------------------------------------------------------------------------------------
+    const int frow = lane & 15, fc = lane >> 4;
+    unsigned a_lane[3];                 // [kx]: byte offset inside a ring row of this lane's fp16 piece (k = 8 fc .. + 7) of pixel column frow + kx * D
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int hx = frow + kx * D;
+        const int sw = (hx >> 1) & 7;
+        a_lane[kx] = (unsigned)(hx * 128 + ((fc ^ sw) * 16));
+    }
+    const int swb = (frow >> 1) & 7;
+    const unsigned b_lane = (unsigned)(A_BYTES + (wn * 64 + frow) * 128 + ((fc ^ swb) * 16));
+    // the scaled instruction's lane groups: group fc = (tap t | t | t + 1 | t + 1) x (Q(x1) Q(w2) | Q(x2) Q(w1)): this lane's field of a
+    // pixel line is chunks 4, 6 (Q(x1)) for even fc and 5, 7 (Q(x2)) for odd fc; of a weight line 5, 7 (Q(w2)) for even fc and 4, 6 (Q(w1))
+    // for odd fc -- the 16-lane groups of a ds_read_b128 mix an even and an odd fc, and chunk numbers that differ by 1 keep their slots apart
+    // under the XOR swizzle (differing by 2 they collide pairwise); the pixel column's swizzle depends on the lane's tap: formed per even tap
+    const bool oldl = ABL(512);          // (timing only: the first layout's chunk numbers -- fields in chunks 4,5 | 6,7)
+    const int xa_c0 = oldl ? 4 + 2 * (fc & 1) : 4 + (fc & 1), xb_c0 = oldl ? 6 - 2 * (fc & 1) : 5 - (fc & 1), xstep = oldl ? 1 : 2, xtap = fc >> 1;
+    const unsigned xb_lane[2] = {(unsigned)(A_BYTES + (wn * 64 + frow) * 128 + ((xb_c0 ^ swb) * 16)),
+                                 (unsigned)(A_BYTES + (wn * 64 + frow) * 128 + (((xb_c0 + xstep) ^ swb) * 16))};
+    u32x4 Ah[2][2], Bf[2][4];           // main operands: Ah[half][pixel row in the half] (one tap's rows 0,1 | 2,3); Bf[set][channel block]
+    u32x4 Xa[4][2], Xb[4][2];           // cross operands of one tap pair: [pixel row | channel block][codes 0 .. 15 | codes 16 .. 23, scale byte, zeros]
+    // read: pixel rows 2 half, 2 half + 1 of (image at ring0, tap) and weight blocks 2 half, 2 half + 1 of ring slot (tgb & 3) into B set `bset`
+    auto read_half = [&](auto half_c, auto bset_c, int ring0, int tap, int tgb) {
+        constexpr int half = decltype(half_c)::value, bset = decltype(bset_c)::value;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned ah = a_lane[kx];
+        const int rb = ring0 + rpw * wm + ky * D + 2 * half;
+        const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
+        const unsigned so = (unsigned)((tgb & (B_RING - 1)) * B_TILE);
+        ds_read_half<2 * half>(Ah[half], Bf[bset], ah + r0, ah + r1, b_lane + so);
+    };
+    // the cross operands of the tap pair (tap, tap + 1) of the image at ring0 (weights: ring slots tg, tg + 1): this lane's tap is tap + xtap
+    auto read_cross = [&](int ring0, int tap, int tg) {
+        const int tl = tap + xtap;                      // 0 .. 9 (9: the lane groups 2, 3 of a chunk's last tap -- scaled to nothing)
+        const int ky = (tl * 11) >> 5, kx = tl - 3 * ky;
+        const int hx = frow + kx * D;
+        const int sw = (hx >> 1) & 7;
+        const unsigned c_lo = (unsigned)(hx * 128 + ((xa_c0 ^ sw) * 16)), c_hi = (unsigned)(hx * 128 + (((xa_c0 + xstep) ^ sw) * 16));
+        const int rb = ring0 + rpw * wm + ky * D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned r = (unsigned)(((rb + i) & (RING_ROWS - 1)) * ROW_B);
+            ds_read_field(Xa[i], c_lo + r, c_hi + r);
+        }
+        const unsigned so = (unsigned)(((tg + xtap) & (B_RING - 1)) * B_TILE);
+        ds_read_field_b<0>(Xb[0], xb_lane[0] + so, xb_lane[1] + so);
+        ds_read_field_b<1>(Xb[1], xb_lane[0] + so, xb_lane[1] + so);
+        ds_read_field_b<2>(Xb[2], xb_lane[0] + so, xb_lane[1] + so);
+        ds_read_field_b<3>(Xb[3], xb_lane[0] + so, xb_lane[1] + so);
+    };
+    f32x4 acc[4][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+    // the 4 main MFMAs of pixel row i of one tap on register set `set`
+    auto mfma_row = [&](auto set_c, auto ic) {
+        constexpr int set = decltype(set_c)::value, i = decltype(ic)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ABL(64)) continue;
+            // weights as the row operand (D[channel 4 fc + e][pixel frow]), as conv3x3_halo_s32.hip
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Bf[set][j]), __builtin_bit_cast(f16x8, Ah[i >> 1][i & 1]), acc[i][j], 0, 0, 0);
+        }
+    };
+    // the 4 scaled MFMAs of pixel row i: both cross terms of the tap pair in Xa / Xb (alone: lane groups 2, 3 scaled to nothing)
+    auto cross_row = [&](auto ic, bool alone) {
+        constexpr int i = decltype(ic)::value;
+        if (ABL(128)) return;
+        const int dead = alone && xtap;
+        const i32x8 xa = __builtin_shufflevector(__builtin_bit_cast(i32x4, Xa[i][0]), __builtin_bit_cast(i32x4, Xa[i][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+        const int sa = dead ? 0 : (int)Xa[i][1][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const i32x8 xb = __builtin_shufflevector(__builtin_bit_cast(i32x4, Xb[j][0]), __builtin_bit_cast(i32x4, Xb[j][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+            const int sb = dead ? 0 : (int)Xb[j][1][2];
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xb, xa, acc[i][j], 2, 2, 0, sb, 0, sa);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the asm reads' destinations stay allocated until the wait behind them (conv_gemm_s32.hip keep_a / keep_b: where hipcc finds such
+    // outputs dead -- the look-ahead reads of a workgroup's last tap -- it re-uses their registers while the LDS data is on its way)
+    auto keep_half = [&](auto half_c, auto bset_c) {
+        constexpr int half = decltype(half_c)::value, bset = decltype(bset_c)::value;
+        keep_regs(Ah[half][0], Ah[half][1]);
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) keep_regs(Bf[bset][j], Bf[bset][j + 1]);
+    };
+    auto keep_cross = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { keep_regs(Xa[i][0], Xa[i][1]); keep_regs(Xb[i][0], Xb[i][1]); }
+    };
+
+    // one wave of every SIMD pair at priority 1 for the whole kernel pays in the GEMM kernel (conv_gemm_s32.hip, -1.5 .. -3 %) but not
+    // here (+-0 .. +1 % on all six layer shapes, tools/mb_halo_s32.py): off unless the debug bit asks for it
+    if ((a.dbg & 1) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    // ---- prologue (a workgroup's first tile only): the whole first image and the first three weight tiles --------------------------
+    dma_a_rows_xp(0, 0, 0, I, I0{});
+    dma_a_rows_xp(0, 0, 0, I, I1{});
+    dma_a_rows_xp(0, 0, 0, I, I2{});
+    dma_b_tap(0, 0, 0);
+    if (total_taps > 1) dma_b_tap(0, 1, 1);
+    if (total_taps > 2) dma_b_tap(0, 2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_half(I0{}, I0{}, 0, 0, 0);
+    u32x4 dummy[2];
+    {   // second half of tap 0's weights (its pixel rows 2, 3 are read during the tap's first phase)
+        const unsigned a0 = a_lane[0];
+        ds_read_half<2>(dummy, Bf[0], a0, a0, b_lane);
+    }
+    phase_end();
+    keep_half(I0{}, I0{});
+    keep_regs(dummy[0], dummy[1]);
+
+    // ---- one tap = two phases of 8 main MFMAs (pixel rows 0,1 | 2,3 against the four weight blocks of B set P).  While a phase runs, the
+    // main fragments of the NEXT phase are read: phase 0 fetches this tap's rows 2,3 and weight blocks 0,1 of tap t+1 (into the other B
+    // set), phase 1 fetches rows 0,1 and weight blocks 2,3 of tap t+1 (across a chunk or tile seam: of the next image's tap 0).  An EVEN
+    // tap of a chunk also fetches the cross operands of the pair (tap, tap + 1) in phase 0 -- tap + 1's weights became visible with the
+    // barrier that closed the tap before -- and multiplies them in phase 1 (16 scaled MFMAs: both cross terms of both taps).  The DMA
+    // pieces (image rows [ar0, ar0 + arn) of chunk dc, ring position dring) and the weights of tap t+3 go out between the MFMA rows.
+    // The closing barrier makes the weights of tap t+2 (issued one tap ago) and every older piece visible: only what this tap issued
+    // may still be in flight.
+    //   tg = flattened tap index over all of this workgroup's chunks; (c, tap) = chunk in the tile, tap in the chunk
+    auto tap_body = [&](auto set_c, int tg, int c, int tap, bool last_of_tile, int ring_cur, int ring_next, int dc, int dring, int ar0, int arn) __attribute__((always_inline)) {
+        constexpr int P = decltype(set_c)::value;
+        const bool wrap = tap == 8;
+        const bool even = (tap & 1) == 0 && !ABL(32);
+        const int nring = wrap ? ring_next : ring_cur, ntap = wrap ? 0 : tap + 1;
+        const bool more_a = arn > 0 && !ABL(256);
+        const bool more_b = tg + 3 < total_taps && !ABL(256);
+        int issued = 0;
+        // phase 0
+        {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned ah = a_lane[kx];
+            const int rb = ring_cur + rpw * wm + ky * D + 2;
+            const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
+            const unsigned so = (unsigned)(((tg + 1) & (B_RING - 1)) * B_TILE);
+            ds_read_half<0>(Ah[1], Bf[P ^ 1], ah + r0, ah + r1, b_lane + so);
+        }
+        if (even) read_cross(ring_cur, tap, tg);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(set_c, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(set_c, I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I1{});
+        phase_end();
+        keep_half(I1{}, std::integral_constant<int, P ^ 1>{});
+        if (even) keep_cross();
+        // phase 1
+        {
+            const int ky = ntap / 3, kx = ntap - ky * 3;
+            const unsigned ah = a_lane[kx];
+            const int rb = nring + ((wrap && last_of_tile) ? rpw_next : rpw) * wm + ky * D;      // (across a tile seam: the next tile's row of this wave)
+            const unsigned r0 = (unsigned)(((rb + 0) & (RING_ROWS - 1)) * ROW_B), r1 = (unsigned)(((rb + 1) & (RING_ROWS - 1)) * ROW_B);
+            const unsigned so = (unsigned)(((tg + 1) & (B_RING - 1)) * B_TILE);
+            ds_read_half<2>(Ah[0], Bf[P ^ 1], ah + r0, ah + r1, b_lane + so);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (rpw > 2) mfma_row(set_c, I2{});
+        if (even) { cross_row(I0{}, wrap); cross_row(I1{}, wrap); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_a) issued += dma_a_rows_xp(dc, dring, ar0, arn, I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (rpw > 3) mfma_row(set_c, I3{});
+        if (even) {
+            if (rpw > 2) cross_row(I2{}, wrap);
+            if (rpw > 3) cross_row(I3{}, wrap);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_b) {
+            const int t3 = tap + 3;          // (chunk, tap) of flattened tap tg + 3: the same weights for every tile of this workgroup
+            const int c3 = t3 < 9 ? c : (last_of_tile ? 0 : c + 1);
+            dma_b_tap(c3, t3 < 9 ? t3 : t3 - 9, (tg + 3) & (B_RING - 1));
+            issued += 2;
+        }
+        phase_end();
+        keep_half(I0{}, std::integral_constant<int, P ^ 1>{});
+        wait_vmcnt(issued);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- epilogue of the current tile straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel
+    // (4 wm + i, frow).  The whole residual tile is requested before the first use (16 loads in flight: one memory round trip, not one
+    // per pixel row -- the stores of row i may alias the loads of row i + 1 for all the compiler knows); the stores are not waited
+    // for here: the next tile's taps run while they drain (a tap's closing vmcnt wait covers them, they are older than its pieces).
+    // One instance of the store loop per output format; the activation of the common layers is a select, not a switch.
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        // opaque copies of the lane coordinates: the epilogue's 64-bit address parts must be formed HERE -- hoisted in front of the tile loop
+        // (they are loop-invariant) they are spilled around the 250-register tap bodies and reloaded from scratch here
+        int frow_e = frow, fc_e = fc;
+        asm volatile("" : "+v"(frow_e), "+v"(fc_e));
+        const int nq = n0 + wn * 64 + fc_e * 4;
+        const float* bp = a.bias ? a.bias + (a.bias_bstride ? (size_t)cur_b * a.bias_bstride : 0) : nullptr;
+        const int gx = cur_x0 + frow_e;
+        // 16 residual bytes per (pixel row i, channel block j), fetched as two 8-byte halves for BOTH formats (same instruction stream):
+        // S32: hi 4 x bf16 | lo 4 x bf16 (64 B apart); fp32: floats 0,1 | floats 2,3 (8 B apart)
+        uint2 rlo[4][4], rhi[4][4];
+        if (a.res && !(ABL(8))) {
+            const bool rs32 = a.res_fmt == APE_FMT_S32;
+            const long second = rs32 ? 64 : 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gy = cur_y0 + rpw * wm + i;
+                const bool pix_ok = i < rpw && gy < a.H && gx < a.W;
+                const size_t m = ((size_t)cur_b * a.H + (pix_ok ? gy : 0)) * a.W + (pix_ok ? gx : 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nq + j * 16;
+                    const int cr = a.roff + (n < a.Cout ? n : 0);       // (a clamped, never-used address for channels past Cout)
+                    const char* rp = a.res + (rs32 ? m * a.ldr * 4 + (size_t)((cr >> 5) * 128 + (cr & 31) * 2) : (m * a.ldr + cr) * 4);
+                    rlo[i][j] = *reinterpret_cast<const uint2*>(rp);
+                    rhi[i][j] = *reinterpret_cast<const uint2*>(rp + second);
+                }
+            }
+        }
+        float4 b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nq + j * 16;
+            b4[j] = (bp && n < a.Cout) ? *reinterpret_cast<const float4*>(bp + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);        // (common.h: no scalar compare-and-branch cascade per element)
+        const bool sigmoid = a.act == APE_ACT_SIGMOID;
+        auto store_tile = [&](auto s32_c) __attribute__((always_inline)) {
+            constexpr bool OUT_S32 = decltype(s32_c)::value != 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gy = cur_y0 + rpw * wm + i;
+                if (i >= rpw || gy >= a.H || gx >= a.W) continue;
+                const size_t m = ((size_t)cur_b * a.H + gy) * a.W + gx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nq + j * 16;
+                    if (n >= a.Cout || (ABL(4))) continue;
+                    float vv[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
+                    if (a.res && !(ABL(8))) {
+                        if (a.res_fmt == APE_FMT_S32) {
+                            const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[i][j]), l = __builtin_bit_cast(bf16x4, rhi[i][j]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vv[e] += (float)h[e] + (float)l[e];
+                        } else {
+                            vv[0] += __uint_as_float(rlo[i][j].x);
+                            vv[1] += __uint_as_float(rlo[i][j].y);
+                            vv[2] += __uint_as_float(rhi[i][j].x);
+                            vv[3] += __uint_as_float(rhi[i][j].y);
+                        }
+                    }
+                    if (sigmoid) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = 1.f / (1.f + __expf(-vv[e]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = ape::act_fast(vv[e], af);
+                    }
+                    if (OUT_S32) {
+                        const int cy = a.yoff + n;
+                        char* yp = a.y + m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
+                        bf16x4 h, l;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
+                        *reinterpret_cast<bf16x4*>(yp) = h;
+                        *reinterpret_cast<bf16x4*>(yp + 64) = l;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                }
+            }
+        };
+        if (a.out_fmt == APE_FMT_S32) store_tile(I1{}); else store_tile(I0{});
+    };
+
+    // ---- one channel chunk = nine taps on alternating register sets (P0 = the set its tap 0 multiplies); gc = flattened chunk index.
+    int c = 0;                  // chunk inside the current tile
+    bool tile_done = false;     // the chunk just multiplied was its tile's last: the epilogue follows at the end of the iteration
+    auto chunk = [&](auto p0_c, int gc, int ring_cur, int ring_next) __attribute__((always_inline)) {
+        constexpr int P0 = decltype(p0_c)::value;
+        using PA = std::integral_constant<int, P0>;
+        using PB = std::integral_constant<int, P0 ^ 1>;
+        const bool last_of_tile = c + 1 == nchunks;
+        const bool has_next = gc + 1 < total_chunks;       // a further chunk (of this tile or of the workgroup's next tile) follows
+        const int tg = gc * 9;
+        // tap 0: the last 2 D rows of THIS chunk's image (skipped for the workgroup's very first chunk: the prologue loaded all of it)
+        tap_body(PA{}, tg + 0, c, 0, last_of_tile, ring_cur, ring_next, c, ring_cur, I - 2 * D, gc > 0 ? 2 * D : 0);
+        // from here on the DMA side works on the next chunk's image: chunk c + 1 of this tile, or chunk 0 of the workgroup's next tile
+        int dc = c + 1;
+        if (last_of_tile) {
+            dc = 0;
+            if (has_next) {
+                int tb, ty0, tx0, tn0;
+                decode(cur_orig + grid, tb, ty0, tx0, tn0);
+                set_dma_tile(tb, ty0, tx0);
+                rpw_next = rows_per_wave(ty0);
+            }
+        }
+        constexpr int FREE = RING_ROWS - I;                // rows of the next image that land on ring rows no image uses now
+        constexpr int H1 = (FREE + 1) / 2;
+        tap_body(PB{}, tg + 1, c, 1, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, has_next ? H1 : 0);
+        tap_body(PA{}, tg + 2, c, 2, last_of_tile, ring_cur, ring_next, dc, ring_next, H1, has_next ? FREE - H1 : 0);
+        tap_body(PB{}, tg + 3, c, 3, last_of_tile, ring_cur, ring_next, dc, ring_next, FREE, has_next ? D : 0);
+        tap_body(PA{}, tg + 4, c, 4, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_body(PB{}, tg + 5, c, 5, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_body(PA{}, tg + 6, c, 6, last_of_tile, ring_cur, ring_next, dc, ring_next, FREE + D, has_next ? D : 0);
+        tap_body(PB{}, tg + 7, c, 7, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_body(PA{}, tg + 8, c, 8, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tile_done = last_of_tile;
+        c = last_of_tile ? 0 : c + 1;
+    };
+    int ring = 0;       // ring row of the current chunk's image row 0
+#pragma unroll 1
+    for (int gc = 0; gc < total_chunks; gc += 2) {
+        // two chunks per iteration: 18 taps, so the register sets alternate with a compile-time parity.  A tile ends only at the end of
+        // an iteration: the host walks several tiles per workgroup only for an even chunk count (Cin % 64 == 0); with an odd count
+        // every workgroup has ONE tile, which ends with the iteration's first chunk, the second being skipped.
+        const int ring1 = (ring + I) & (RING_ROWS - 1), ring2 = (ring1 + I) & (RING_ROWS - 1);
+        chunk(I0{}, gc, ring, ring1);
+        if (gc + 1 < total_chunks) chunk(I1{}, gc + 1, ring1, ring2);
+        ring = ring2;
+        if (tile_done) {
+            epilogue();
+            zero_acc();
+            cur_orig += grid;
+            if (gc + 2 < total_chunks) { int tn0; decode(cur_orig, cur_b, cur_y0, cur_x0, tn0); rpw = rows_per_wave(cur_y0); }
+        }
+    }
+#endif
+}
+#undef APE_DS_READ
+
+template <int D>
+int launch_halo_mx(const HaloMxArgs& a, hipStream_t st)
+{
+    auto kern = halo_mx_kernel<D>;
+    static ape::DeviceOnce once;       // (per kernel instantiation)
+    int ncu = 256;
+    if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), LDS_BYTES, &ncu)) return rc;
+    // one workgroup fills a CU (160 KB of LDS, 8 waves x 256 registers): launch one per CU and let each walk its share of the tiles.
+    // The walk keeps a workgroup on ONE channel tile (its weight descriptor is built once) when the tile stride grid / 8 is a multiple
+    // of n_tiles; otherwise, and for grids smaller than the chip, every tile gets its own workgroup as before.
+    const int nwg = a.B * a.tiles_x * a.tiles_y * a.n_tiles;
+    int grid = nwg;
+    const int unit = 8 * a.n_tiles;
+    if (!(a.dbg & 2) && nwg > ncu && ncu >= unit && (a.Cin / 32) % 2 == 0) grid = (ncu / unit) * unit;    // (kernel: a tile ends on an even chunk)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, a);
+    return ape::check_launch("ape_conv3x3_halo_mx");
+}
+
+bool halo_mx_supported(const ape_conv_params& p)
+{
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != p.dil || (p.dil != 1 && p.dil != 2 && p.dil != 4) || p.ups != 0) return false;
+    if (p.B < 0 || p.H < 1 || p.W < 1 || p.Ho != p.H || p.Wo != p.W) return false;
+    if (p.Cin < 32 || p.Cin % 32 || p.ldx % 32 || p.xoff % 32 || p.xoff + p.Cin > p.ldx) return false;
+    if (p.Cout < 128 || p.Cout % 4 || p.yoff + p.Cout > p.ldy || p.ldy % 4 || p.yoff % 4) return false;
+    if (p.act < APE_ACT_NONE || p.act > APE_ACT_SIGMOID) return false;
+    if ((long)p.B * p.H * p.W * p.ldx * 4 >= (1L << 31) || 128L * 9 * p.Cin * 4 >= (1L << 31)) return false;
+    return true;
+}
+
+}  // namespace
+
+static int g_halo_mx_dbg = 0;
+extern "C" int ape_conv3x3_halo_mx_debug(int bits) { g_halo_mx_dbg = bits; return APE_OK; }
+
+extern "C" int ape_conv3x3_halo_mx_supported(const ape_conv_params* params) { return params && halo_mx_supported(*params) ? 1 : 0; }
+
+extern "C" int ape_conv3x3_halo_mx(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
+                                    int out_fmt, const ape_conv_params* params, void* stream)
+{
+    if (!x_s32 || !w_s32k || !y || !params) return APE_EINVAL;
+    const ape_conv_params& p = *params;
+    if (!halo_mx_supported(p)) return APE_EINVAL;
+    if ((out_fmt != APE_FMT_F32 && out_fmt != APE_FMT_S32) || (residual && res_fmt != APE_FMT_F32 && res_fmt != APE_FMT_S32)) return APE_EINVAL;
+    if (out_fmt == APE_FMT_S32 && p.ldy % 32) return APE_EINVAL;
+    if (residual && (p.roff + p.Cout > p.ldr || p.ldr % 4 || p.roff % 4 || (res_fmt == APE_FMT_S32 && p.ldr % 32))) return APE_EINVAL;
+    if (p.B == 0) return APE_OK;
+    HaloMxArgs a;
+    a.dbg = g_halo_mx_dbg;
+    a.x = (const char*)x_s32; a.w = (const char*)w_s32k; a.bias = bias; a.res = (const char*)residual; a.y = (char*)y;
+    a.B = p.B; a.H = p.H; a.W = p.W; a.Cin = p.Cin; a.Cout = p.Cout;
+    a.ldx = p.ldx; a.xoff = p.xoff; a.ldy = p.ldy; a.yoff = p.yoff; a.ldr = p.ldr; a.roff = p.roff;
+    a.act = p.act; a.alpha = p.alpha; a.bias_bstride = p.bias_bstride; a.out_fmt = out_fmt; a.res_fmt = res_fmt;
+    a.tiles_x = ape::ceil_div(p.W, TS); a.tiles_y = ape::ceil_div(p.H, TS); a.n_tiles = ape::ceil_div(p.Cout, 128);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dil == 1) return launch_halo_mx<1>(a, st);
+    if (p.dil == 2) return launch_halo_mx<2>(a, st);
+    return launch_halo_mx<4>(a, st);
+}
+
+// ---- S32 -> F16M6 (mx6.py's line): one lane per (pixel, 32-channel chunk), 128 B in, 128 B out ------------------------------------
+namespace {
+
+__device__ __forceinline__ unsigned e2m3_code(float u)
+{
+    // u already divided by the block scale: |u| < 8.  Round to nearest-even on e2m3's grid (step 1/8 below 1, then 1/8, 1/4, 1/2 per binade),
+    // clamp at 7.5.  Same arithmetic as mx6.quantise_blocks.
+    const float a = fminf(fabsf(u), 7.5f);
+    unsigned code;
+    if (a < 1.f) {
+        const int m = (int)rintf(a * 8.f);                 // 0 .. 8
+        code = m == 8 ? (1u << 3) : (unsigned)m;
+    } else {
+        int ex = (int)((__float_as_uint(a) >> 23) & 255u) - 127;          // 0, 1, 2
+        int q = (int)rintf(a * __uint_as_float((unsigned)(127 + 3 - ex) << 23));      // a / 2^(ex - 3): 8 .. 16
+        if (q == 16) { ex += 1; q = 8; }
+        code = ex > 2 ? ((3u << 3) | 7u) : (((unsigned)(ex + 1) << 3) | (unsigned)(q - 8));
+    }
+    if (u < 0.f && code != 0) code |= 32u;
+    return code;
+}
+
+// codes[32] -> 24 B little-endian bit stream in o[0..5]
+__device__ __forceinline__ void pack6(const unsigned (&c)[32], unsigned (&o)[6])
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned* p = c + 16 * h;
+        const unsigned long long lo = (unsigned long long)p[0] | ((unsigned long long)p[1] << 6) | ((unsigned long long)p[2] << 12) |
+                                      ((unsigned long long)p[3] << 18) | ((unsigned long long)p[4] << 24) | ((unsigned long long)p[5] << 30) |
+                                      ((unsigned long long)p[6] << 36) | ((unsigned long long)p[7] << 42) | ((unsigned long long)p[8] << 48) |
+                                      ((unsigned long long)p[9] << 54) | ((unsigned long long)(p[10] & 15u) << 60);
+        const unsigned hi = (p[10] >> 4) | (p[11] << 2) | (p[12] << 8) | (p[13] << 14) | (p[14] << 20) | (p[15] << 26);
+        o[3 * h + 0] = (unsigned)lo;
+        o[3 * h + 1] = (unsigned)(lo >> 32);
+        o[3 * h + 2] = hi;
+    }
+}
+
+__device__ __forceinline__ void quantise_block(const float (&v)[32], unsigned (&o)[6], unsigned& e8m0)
+{
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    int es = (int)((__float_as_uint(amax) >> 23) & 255u) - 127 - 2;
+    es = es < -127 ? -127 : es;
+    if (amax == 0.f) es = 0;
+    const float inv = __uint_as_float((unsigned)(127 - es) << 23);       // 2^-es (es in [-127, 125]: the factor stays a normal float for es <= 126)
+    unsigned c[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) c[i] = e2m3_code(v[i] * inv);
+    pack6(c, o);
+    e8m0 = (unsigned)(es + 127);
+}
+
+__global__ __launch_bounds__(256) void s32_to_f16m6_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, long lines)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= lines) return;
+    uint4 in[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) in[k] = x[i * 8 + k];
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {              // hi piece k (channels 8 k .. + 7) | lo piece 4 + k
+        const bf16x8 h = __builtin_bit_cast(bf16x8, in[k]), l = __builtin_bit_cast(bf16x8, in[4 + k]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[8 * k + e] = (float)h[e] + (float)l[e];
+    }
+    float v1[32], v2[32];
+    uint4 out[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = (_Float16)v[8 * k + e];
+            v1[8 * k + e] = (float)h[e];
+            v2[8 * k + e] = v[8 * k + e] - v1[8 * k + e];
+        }
+        out[k] = __builtin_bit_cast(uint4, h);
+    }
+    unsigned o1[6], o2[6], s1, s2;
+    quantise_block(v1, o1, s1);
+    quantise_block(v2, o2, s2);
+    out[4] = make_uint4(o1[0], o1[1], o1[2], o1[3]);           // (the fields' chunks alternate: mx6.py)
+    out[5] = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+    out[6] = make_uint4(o1[4], o1[5], s1, 0u);
+    out[7] = make_uint4(o2[4], o2[5], s2, 0u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[i * 8 + k] = out[k];
+}
+
+}  // namespace
+
+/* x_s32[pixels][C] (S32, C % 32 == 0) -> y[pixels][C] in the F16M6 line format of conv3x3_halo_mx.hip (same bytes per pixel) */
+extern "C" int ape_s32_to_f16m6(const void* x_s32, void* y, long pixels, int C, void* stream)
+{
+    if (!x_s32 || !y || pixels < 0 || C < 32 || C % 32) return APE_EINVAL;
+    const long lines = pixels * (C / 32);
+    if (lines == 0) return APE_OK;
+    hipLaunchKernelGGL(s32_to_f16m6_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x_s32, (uint4*)y, lines);
+    return ape::check_launch("ape_s32_to_f16m6");
+}

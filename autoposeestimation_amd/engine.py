@@ -198,6 +198,16 @@ class Conv:
             self._ws32 = ws
         return ws
 
+    def mx6k(self):
+        """the weights as F16M6 lines ([Cout][9 * Cin / 32][128 B], mx6.pack_conv_weights) for ape_conv3x3_halo_mx; built on first use"""
+        wq = getattr(self, "_wmx6", None)
+        if wq is None:
+            from . import mx6
+            w = self.w.detach().float().cpu().numpy().reshape(self.cout, self.kh, self.kw, self.cin)       # (the unpacked layout: [Cout][kh][kw][Cin])
+            lines = mx6.pack_lines(w.reshape(self.cout, self.kh * self.kw * (self.cin // 32), 32))
+            wq = self._wmx6 = torch.from_numpy(lines).to(self.w.device)
+        return wq
+
     def _generic_variant(self, m):
         """name of the template instantiation ape_conv2d_nhwc_* dispatches to (mirrors the C++ rule; profiling label only)"""
         if self.nsplit and self.cout >= 256 and ((-(-self.cout // 256)) * 256 - self.cout) * 8 <= self.cout and m >= 65536:
@@ -322,6 +332,12 @@ class Conv:
         return S32(out) if out_fmt == FMT_S32 else out
 
 
+# 3x3 layers on S32 inputs with these input channel counts take the half-pass kernel (fp16 main product + block-scaled e2m3 cross terms,
+# conv3x3_halo_mx.hip) instead of halo_s32's three bf16 products.  Off unless asked for: not bit-identical to bf16x3.
+USE_MX6 = os.environ.get("APE_USE_MX6", "0") != "0"
+MX6_CIN = tuple(int(v) for v in os.environ.get("APE_MX6_CIN", "512").split(","))
+
+
 def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride, act, out_fmt):
     if self.nsplit != 3:
         raise ValueError("S32 operands exist only in the split-bf16 ('bf16x3') precision")
@@ -345,6 +361,20 @@ def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride,
                    KH=self.kh, KW=self.kw, stride=self.stride, pad=self.pad, dil=self.dil, act=self.act if act is None else act,
                    alpha=self.alpha, bias_bstride=bias_bstride, ldr=0 if res_t is None else res_t.shape[3], roff=roff, ups=0)
     is3 = self.kh == 3
+    if is3 and USE_MX6 and self.cin in MX6_CIN and self.cout >= 128 and self.stride == 1 and xoff == 0 and ldx == self.cin \
+            and _lib.lib().ape_conv3x3_halo_mx_supported(ctypes.byref(p)):
+        # half the matrix passes (conv3x3_halo_mx.hip): the S32 input is re-expressed once as F16M6 lines
+        xq = torch.empty_like(xt)
+        _lib.check(_lib.lib().ape_s32_to_f16m6(_lib.dptr(xt, torch.float32), _lib.dptr(xq, torch.float32), b * h * w, ldx, _st()), "ape_s32_to_f16m6")
+        label = "halo_mx_kernel<%d>" % self.dil
+        e0 = _prof_begin(label)
+        rc = _lib.lib().ape_conv3x3_halo_mx(_lib.dptr(xq, torch.float32), _lib.dptr(self.mx6k()), _lib.dptr(bias), _lib.dptr(res_t), res_fmt,
+                                            _lib.dptr(out_t, torch.float32), out_fmt, ctypes.byref(p), _st())
+        _lib.check(rc, "ape_conv3x3_halo_mx")
+        if e0 is not None:
+            _prof_end(e0, label, "%dx%dx%d %d->%d k%d s%d d%d" % (b, ho, wo, self.cin_real, self.cout, self.kh, self.stride, self.dil),
+                      *_conv_cost(self, b, h, w, ho, wo, residual is not None))
+        return S32(out_t) if out_fmt == FMT_S32 else out_t
     if is3:
         if not _lib.lib().ape_conv3x3_halo_s32_supported(ctypes.byref(p)):
             raise ValueError("no S32 kernel for this layer geometry (3x3, stride %d, dil %d, Cin %d, Cout %d)" % (self.stride, self.dil, self.cin, self.cout))

@@ -175,6 +175,16 @@ int ape_upconv3x3_fused_seghead_s32(const void* x_s32, const void* w9_s32k, cons
 int ape_conv3x3_halo_s32_supported(const ape_conv_params* params_host);
 int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
                          int out_fmt, const ape_conv_params* params_host, void* stream);
+/* The same convolution (extractors.py:29-43; layer 4's 512 -> 512 blocks) with HALF the matrix passes: operands in the "F16M6" line format
+ * (autoposeestimation_amd/mx6.py: per 32 channels fp16 values | block-scaled e2m3 codes of them | block-scaled e2m3 codes of the fp16
+ * residual), x . w ~ x1 w1 + Q(x1) Q(w2) + Q(x2) Q(w1): one v_mfma_f32_16x16x32_f16 per tap and block + one
+ * v_mfma_scale_f32_16x16x128_f8f6f4 per tap PAIR and block.  x from ape_s32_to_f16m6, w from mx6.pack_conv_weights; y / residual /
+ * bias / activation as ape_conv3x3_halo_s32.  NOT bit-identical to the bf16x3 kernels: DESIGN.md 6e prices the difference. */
+int ape_conv3x3_halo_mx_supported(const ape_conv_params* params_host);
+int ape_conv3x3_halo_mx(const void* x_f16m6, const void* w_f16m6, const float* bias, const void* residual, int res_fmt, void* y,
+                        int out_fmt, const ape_conv_params* params_host, void* stream);
+int ape_conv3x3_halo_mx_debug(int bits);
+int ape_s32_to_f16m6(const void* x_s32, void* y_f16m6, long pixels, int C, void* stream);
 /* The ResNet stem in one kernel: Conv2d(3 -> 64, 7x7, stride 2, pad 3) + ReLU + MaxPool2d(3, 2, 1)  (extractors.py:82-85, 111-117).
  * x[B][H][W][4] f32 (RGB + a zero channel), w[64][7][7][4] f32 (the UNPACKED ape_conv2d_nhwc_f32 layout: the kernel splits its
  * own weight fragments), bias[64] or NULL -> y[B][Hp][Wp][64] with Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1 (same for W).

@@ -22,6 +22,8 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 KERNELS = {
     "conv3x3_halo_s32.hip": [("halo_s32_kernelILi1E", "halo_s32_kernel<1>", True), ("halo_s32_kernelILi2E", "halo_s32_kernel<2>", True),
                              ("halo_s32_kernelILi4E", "halo_s32_kernel<4>", True)],
+    "conv3x3_halo_mx.hip": [("halo_mx_kernelILi1E", "halo_mx_kernel<1>", True), ("halo_mx_kernelILi2E", "halo_mx_kernel<2>", True),
+                            ("halo_mx_kernelILi4E", "halo_mx_kernel<4>", True)],
     "conv_gemm_s32.hip": [("gemm_s32_kernelILi128E", "gemm_s32_kernel<128>", True), ("gemm_s32_kernelILi192E", "gemm_s32_kernel<192>", True),
                           ("gemm_s32_kernelILi256E", "gemm_s32_kernel<256>", True), ("gemm_s32_res_kernelILi128E", "gemm_s32_res_kernel<128>", True),
                           ("gemm_s32_res_kernelILi192E", "gemm_s32_res_kernel<192>", True), ("gemm_s32_res_kernelILi256E", "gemm_s32_res_kernel<256>", True)],

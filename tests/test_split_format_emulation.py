@@ -11,6 +11,8 @@ a pixel may flip only where the oracle's top-2 doubly-soft-maxed probabilities a
 
 A block = 32 consecutive input channels of one pixel (one weight row and tap): what one lane of v_mfma_scale_f32_16x16x128_f8f6f4 holds.
 Minutes of CPU time, so it only runs when asked:  APE_EMULATE_SPLITS=1 python -m pytest tests/test_split_format_emulation.py -s
+(APE_EMULATE_FRAMES=24 for the table in DESIGN.md; APE_EMULATE_ONLY=512x3 applies the candidate mix to the 3 x 3 convolutions with 512
+input channels -- layer 4's three heaviest -- and keeps bf16x3 everywhere else.)
 The numbers it printed on this tree are in DESIGN.md 6e."""
 import os
 
@@ -95,6 +97,9 @@ class _Shim:
     def conv2d(self, x, w, b=None, stride=1, padding=0, dilation=1):
         up, self.pending_up = self.pending_up, None
         s32_layer = w.shape[1] >= 128 and w.shape[1] % 32 == 0
+        only = os.environ.get("APE_EMULATE_ONLY", "")            # "512x3": the candidate mix for the 3x3 convs with 512 input channels only
+        if only and (w.shape[1], w.shape[2]) != tuple(int(v) for v in only.split("x")):
+            s32_layer = s32_layer and self.scheme in ("f32", "bf16x3")
         scheme = self.scheme if s32_layer else ("f32" if self.scheme == "f32" else "bf16x3")
         src = x
         if up is not None and up[2] is x:
