@@ -211,6 +211,8 @@ class FramePipeline:
                 E.CAPTURING = False
             g = self._graphs[key] = (graph, both, seed_d, outs)
         graph, both, seed_d, outs = g
+        if os.environ.get("APE_FAN_EAGER") == "1":      # (diagnosis: the bucket's launches one by one on this stream instead of the replay)
+            return self._bucket(rgb, depth, self._static_objmap, both_h.to(rgb.device, non_blocking=True), hc, wc, meta, seed)
         both.copy_(both_h, non_blocking=True)
         seed_d.fill_(int(seed) & 0x7FFFFFFF)
         graph.replay()

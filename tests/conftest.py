@@ -6,6 +6,10 @@ import sys
 import numpy as np
 import pytest
 
+# one hardware queue per stream for the tests that run streams side by side (HIP's default of 4 lets two chains overlap, not more); read
+# by the runtime at its first HIP call, so it has to be in the environment before any test touches the GPU
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "40")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -19,7 +19,7 @@ import sys
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "autoposeestimation_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",          # = csrc/Makefile ...
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",          # = csrc/Makefile ...
          "-DAPE_NO_ABLATIONS"]     # ... without the kernels' timing-only ablation switches (wrong-result debug paths, e.g. "no barrier")
 
 
@@ -480,8 +480,10 @@ def pk_src1_swizzles(asm_path, symbol, asm_only=True):
     op_sel / op_sel_hi swizzle (anything but the natural "low result from the low dword, high result from the high dword").  On gfx950 that
     form computed the low half of lanes 48-63 from a wrong dword under back-to-back issue (csrc/upconv_fused.hip, note at APE_NO_ASM_MATH;
     reproduced in every launch of tools/stress_upfuse.py's positive control); with the swizzled pair as src0 -- the slot hipcc uses for its own
-    broadcasts -- the same instruction is clean.  asm_only: instructions inside asm statements only (hipcc's own
-    `v_pk_add_f32 d, a, a op_sel:[0,1] op_sel_hi:[1,0]` horizontal adds are reported with asm_only=False; no fault has been seen on them).
+    broadcasts -- the same instruction is clean.  asm_only: instructions inside asm statements only; asm_only=False also reports hipcc's own
+    (its SLP vectoriser forms `v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` and the like: pose_select_kernel's rotation was built from
+    them and gave wrong values in lanes 48-63 beside a busy second stream -- tools/stress_pose_select.py -- which is why the library is built
+    with -fno-slp-vectorize and every kernel is scanned).
     -> [(line, text)]"""
     blocks, _ = _parse_cfg_with_asm(asm_path, symbol)
     found = []
