@@ -56,7 +56,8 @@ struct HaloS32Args {
     int tiles_x, tiles_y, n_tiles;
     int dbg;                // ape_conv3x3_halo_s32_debug: 1 = static priority 1 for waves 4-7, 2 = one workgroup per tile instead of the
                             // persistent walk, 16 = four rows per wave-row group in every tile (results unchanged by any of them);
-                            // timing-only ablations: 4 = no epilogue stores, 8 = no residual loads, 32 = two of the three MFMAs per product
+                            // timing-only ablations: 4 = no epilogue stores, 8 = no residual loads, 32 = two of the three MFMAs per product, 64 = no fragment-read waits, 128 = no per-tap barrier, 256 = no per-tap DMA wait,
+                            // 512 = no in-loop DMA, 1024 = no MFMAs
 };
 
 // NONE / RELU / PRELU as selects on loop-invariant scalars (a `switch` per element compiled to a cascade of scalar compares and branches
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         constexpr int set = decltype(set_c)::value, i = decltype(ic)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (ABL(1024)) continue;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, Bf[set][j][0]), bl = __builtin_bit_cast(bf16x8, Bf[set][j][1]);
             const bf16x8 ah = __builtin_bit_cast(bf16x8, Ah[i >> 1][i & 1][0]), al = __builtin_bit_cast(bf16x8, Ah[i >> 1][i & 1][1]);
             // weights as the row operand (D[channel 4 fc + e][pixel frow]); product order of conv3x3_halo.hip
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     using I3 = std::integral_constant<int, 3>;
     auto phase_end = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!ABL(64)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
     // the asm reads' destinations stay allocated until the wait behind them (conv_gemm_s32.hip keep_a / keep_b: where hipcc finds such
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         constexpr int P = decltype(set_c)::value;
         const bool wrap = tap == 8;
         const int nring = wrap ? ring_next : ring_cur, ntap = wrap ? 0 : tap + 1;
-        const bool more_a = arn > 0;
-        const bool more_b = tg + 3 < total_taps;
+        const bool more_a = arn > 0 && !ABL(512);
+        const bool more_b = tg + 3 < total_taps && !ABL(512);
         int issued = 0;
         // phase 0
         {
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         }
         phase_end();
         keep_half(I0{}, std::integral_constant<int, P ^ 1>{});
-        wait_vmcnt(issued);
-        __builtin_amdgcn_s_barrier();
+        if (!ABL(256)) wait_vmcnt(issued);
+        if (!ABL(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
 
