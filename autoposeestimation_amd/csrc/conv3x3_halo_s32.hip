@@ -26,11 +26,13 @@
 #include <type_traits>
 #include "common.h"
 
-// timing-only ablation switches (results wrong when set): compiled out of the ISA-audit build (tools/isa_audit.py, -DAPE_NO_ABLATIONS)
-#ifdef APE_NO_ABLATIONS
-#define ABL(bit) 0
-#else
+// timing-only ablation switches (results wrong when set): compiled IN only by `make ablations` (-DAPE_ABLATIONS -> ../libape_hip_abl.so, what
+// tools/mb_*_abl.py load).  In the product build they cost: the run-time tests around the MFMA rows, waits and DMA statements of halo_s32
+// were 1 ms of the 33 ms step (same-box A/B).
+#ifdef APE_ABLATIONS
 #define ABL(bit) (a.dbg & (bit))
+#else
+#define ABL(bit) 0
 #endif
 
 namespace {

@@ -1,5 +1,7 @@
 """timing ablations of halo_mx on the 512 -> 512 shape (results wrong under them)"""
 import ctypes, os, sys
+# the switches exist in the ablation build only: make -C autoposeestimation_amd/csrc ablations
+os.environ.setdefault("APE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "autoposeestimation_amd", "libape_hip_abl.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from autoposeestimation_amd import _lib, engine as E
