@@ -18,7 +18,6 @@ SIGNATURES = {
     "ape_abi_version": [],
     "ape_last_error": [],
     "ape_knn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "ape_knn_debug": [_I],
     "ape_conv2d_nhwc_f32": [_P, _P, _P, _P, _P, _P, _P],
     "ape_packed_weights_bf16_elems": [_I, _I],
     "ape_pack_weights_bf16": [_P, _P, _I, _I, _P],

@@ -76,10 +76,18 @@ __global__ __launch_bounds__(kBlock) void knn1_d3(const float* __restrict__ ref,
     if (valid && s == 0) idx[q] = (int64_t)besti + 1;
 }
 
-#define ABL_SCALAR(bits) ((bits) & 2)
+// APE_ABLATIONS (make ablations -> libape_hip_abl.so, tools/mb_knn.py): the A/B forms -- four queries per lane, no group minima -- behind a
+// run-time switch; the product build has the one form it launches and no switch in its tile loop
+#ifdef APE_ABLATIONS
+#define KNN_DBG_PARAM , int g_dbg
+#define KNN_NO_GROUPS(n) ((g_dbg & 2) ? 0 : (n))
+#else
+#define KNN_DBG_PARAM
+#define KNN_NO_GROUPS(n) (n)
+#endif
 template <int Q, int G>
 __global__ __launch_bounds__(kBlock) void knn1_d3_q(const float* __restrict__ ref, const float* __restrict__ query,
-                                                    int64_t* __restrict__ idx, int ref_nb, int query_nb, int g_dbg)
+                                                    int64_t* __restrict__ idx, int ref_nb, int query_nb KNN_DBG_PARAM)
 {
     __shared__ float4 tile[kTile];
     const int b = blockIdx.y;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void knn1_d3_q(const float* __restrict__ re
         // group minimum goes through the compare-and-select against the running best -- 8 + 3/8 + 3/8 vector operations per pair instead of
         // 11.  A strict '<' on the group minimum keeps the FIRST group that holds the overall minimum; the index inside it is recovered
         // after the scan (below).  The refs behind the last full group of the last tile are groups of one.
-        const int ng = ABL_SCALAR(g_dbg) ? 0 : n / G * G;
+        const int ng = KNN_NO_GROUPS(n / G * G);
 #pragma unroll 1
         for (int r = 0; r < ng; r += G) {
             float d[Q][G];
@@ -208,7 +216,9 @@ __global__ __launch_bounds__(kBlock) void knn_general(const float* __restrict__ 
     }
 }
 
-int g_knn_q = 0;        // ape_knn_debug bits: 1 = never the several-queries-per-lane form, 2 = that form without the group minima, 4 / 8 = always four / two queries per lane (A/B and bitwise tests)
+#ifdef APE_ABLATIONS
+int g_knn_q = 0;        // ape_knn_debug bits: 1 = never the several-queries-per-lane form, 2 = that form without the group minima, 4 / 8 = always four / two queries per lane (A/B)
+#endif
 
 template <int S>
 void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, int ref_nb, int query_nb, hipStream_t st)
@@ -219,7 +229,9 @@ void launch_knn1(const float* ref, const float* query, int64_t* idx, int batch, 
 
 }  // namespace
 
+#ifdef APE_ABLATIONS
 extern "C" int ape_knn_debug(int bits) { g_knn_q = bits; return APE_OK; }
+#endif
 
 extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
                            int batch, int dim, int ref_nb, int query_nb, int k, void* stream)
@@ -235,10 +247,10 @@ extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
         int s = 1;
         while (s < 64 && total * s < target && s * 4 <= ref_nb) s *= 4;
         // enough queries to give every lane several of them and still fill the chip: the knn1_d3_q forms
+        // two queries per lane: faster than four at every size measured (10^6 queries: 0.177 vs 0.195 ms, 4 x 10^6: 0.568 vs 0.585 --
+        // twice the waves hide the vector pipe's own latencies and the LDS reads' better than the halved LDS traffic pays)
+#ifdef APE_ABLATIONS
         if (s == 1 && !(g_knn_q & 1) && total >= 4 * target && query_nb >= 4 * kBlock) {
-            // two queries per lane: faster than four at every size measured (10^6 queries: 0.177 vs 0.195 ms, 4 x 10^6: 0.568 vs 0.585 --
-            // twice the waves hide the vector pipe's own latencies and the LDS reads' better than the halved LDS traffic pays); four stay
-            // selectable for A/B
             const bool four = (g_knn_q & 4) != 0;
             if (four && !(g_knn_q & 8)) {
                 dim3 grid(ape::ceil_div(query_nb, 4 * kBlock), batch);
@@ -249,6 +261,13 @@ extern "C" int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
             }
             return ape::check_launch("ape_knn_f32");
         }
+#else
+        if (s == 1 && total >= 4 * target && query_nb >= 4 * kBlock) {
+            dim3 grid(ape::ceil_div(query_nb, 2 * kBlock), batch);
+            hipLaunchKernelGGL((knn1_d3_q<2, 8>), grid, dim3(kBlock), 0, st, ref, query, idx, ref_nb, query_nb);
+            return ape::check_launch("ape_knn_f32");
+        }
+#endif
         switch (s) {
             case 1: launch_knn1<1>(ref, query, idx, batch, ref_nb, query_nb, st); break;
             case 4: launch_knn1<4>(ref, query, idx, batch, ref_nb, query_nb, st); break;

@@ -480,7 +480,7 @@ def label_cpu_baseline(views_np, n_views=6):
                                              "the chain is sequential, so it has no multi-core form short of running chains side by side" % n_views}, acc
 
 
-def label_main(args, rank, world, device, dist):
+def label_main(args, rank, world, device, dist, embedded=False):
     """configs[4]: pose-label generation.  A step = `--views` synthetic 640x480 views in chains of 25 (one chain = one (object,
     direction) sequence of create_pointcloud.py:276-312): get_surface (back-projection, voxel / radius / statistical filters) for every
     view, spread over the ranks; one padded all-gather; then the sequential p2p + point-to-plane ICP fusion of each chain on its
@@ -568,7 +568,11 @@ def label_main(args, rank, world, device, dist):
             d = cKDTree(acc).query(gp)[0]
             line["parity"] = {"checker": "oracle/pointcloud_oracle on the cpu_baseline sample (6 views of chain 0)", "gpu_points": len(gp),
                               "oracle_points": len(acc), "max_nn_distance_mm": round(float(d.max()), 6)}
+        if embedded:
+            return line
         print(json.dumps(line))
+    if embedded:
+        return None
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -578,7 +582,7 @@ PEAK_F32_LANE_OPS = 256 * 4 * 32 * 2.4e9 / 1e12     # T lane-operations/s: 256 C
 KNN_LANE_OPS_PER_PAIR = 11                           # 3 sub, 3 mul, 2 add, 1 compare, 2 selects (csrc/knn.hip; the reference's arithmetic, no FMA)
 
 
-def pose_main(args, rank, world, device, dist):
+def pose_main(args, rank, world, device, dist, embedded=False):
     """BASELINE configs[1]: PoseNet + 2 x PoseRefineNet on --crops 160x160 crops per GPU and step (N = 1000 points), then ADD-S of every
     refined pose against its ground-truth cloud through the hand-written k-NN / ADD-S kernel (1000 x 1000 pair evaluations per crop,
     eval_linemod.py:118-130).  A step = FramePipeline.poses (choose / back-projection / crop normalisation / PoseNet / pose selection /
@@ -609,7 +613,7 @@ def pose_main(args, rank, world, device, dist):
     cls_t = torch.tensor([o[1] for o in objects], dtype=torch.float32, device=device)
     model = torch.from_numpy(np.stack([S.model_cloud(o[1]) for o in objects])).to(device)           # [n, 1000, 3] (0.1 m cubes, per class)
 
-    def step(seed, target, timed=None):
+    def step(seed, target, timed=None, gather=True):
         pose, n_cand, choose = pipe.poses(rgb, depth, objmap, objects, S.REALSENSE_META, seed=seed)
         q, t = pose[:, :4].float().contiguous(), pose[:, 4:].float().contiguous()
         if timed is not None:
@@ -620,7 +624,7 @@ def pose_main(args, rank, world, device, dist):
             e1.record()
             timed.append((e0, e1))
         block = torch.cat([cls_t[:, None], pose.float(), dis[:, None]], 1)[:, None, :]            # [n, 1, 9]
-        return pose, choose, dis, gather_results(block, dist)
+        return pose, choose, dis, gather_results(block, dist if gather else None)      # (gather=False: rank 0's profiled extra step)
 
     # ground truth of every crop: the first run's pose turned by 3 degrees about a seeded axis and moved by 3 mm (ADD-S in millimetres)
     pose0, _, _, _ = step(0, model)
@@ -663,7 +667,7 @@ def pose_main(args, rank, world, device, dist):
         # after the timed region: every conv launch of one step timed (the MFMA side of the workload), and the k-NN kernel at training size
         prof = E.LaunchProfile()
         E.PROFILE = prof
-        step(args.warmup + args.steps, target)
+        step(args.warmup + args.steps, target, gather=False)
         torch.cuda.synchronize()
         E.PROFILE = None
         top = sorted(prof.summary().items(), key=lambda kv: -kv[1]["ms"])[:3]
@@ -712,7 +716,11 @@ def pose_main(args, rank, world, device, dist):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"], line["parity"] = pose_cpu_baseline(frames, objects, est_sd, ref_sd, choose.cpu().numpy(), pose.cpu().numpy(),
                                                                      dis.cpu().numpy(), targets, device)
+        if embedded:
+            return line
         print(json.dumps(line))
+    if embedded:
+        return None
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -818,6 +826,8 @@ def main():
     ap.add_argument("--no-modes", action="store_true", help="skip the secondary `modes` leg (two steps of the exact-fp32 operand mode after the timed region)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the compact secondary `sweep` leg (4 steps of the --mixed frames, no parity block)")
     ap.add_argument("--no-latency", action="store_true", help="skip the compact secondary `latency` leg (50 runs of the batch-1 live loop)")
+    ap.add_argument("--no-pose-leg", action="store_true", help="skip the compact secondary `pose` leg (BASELINE configs[1]: 10 steps of --workload pose)")
+    ap.add_argument("--no-label-leg", action="store_true", help="skip the compact secondary `label` leg (BASELINE configs[4]: 1 step of --workload label, 200 views)")
     ap.add_argument("--mixed", action="store_true",
                     help="the full `sweep` leg (--mixed-steps steps + its own parity block; the default line carries a compact one: 4 steps, no "
                          "parity block).  `sweep`: --batch frames with 1-3 painted objects each, sizes drawn from SURVEY.md 8d's crop "
@@ -899,6 +909,8 @@ def main():
     from autoposeestimation_amd.sharding import gather_results
 
     step_poses = {}
+    kept = {}           # step -> the step's gathered [world * per_rank, 1, 8] block, for the timed steps (`parity.steps_bitwise_equal`)
+    keep_steps = set()
 
     def tail(out, item):
         # one result slot per frame: the largest detection (the painted object) wins the slot.  The rank's poses of one step collect in
@@ -919,6 +931,8 @@ def main():
                 poses[t[0], 0, 1:] = out["pose"][t[1]].float()
             if chunk == n_chunks - 1:
                 out["gathered"] = gather_results(step_poses.pop(step), dist)   # the single RCCL collective of the path: (cls, q, t) per frame
+                if step in keep_steps:
+                    kept[step] = out["gathered"]
         return out
 
     def run_steps(first, count):
@@ -973,11 +987,13 @@ def main():
             with open(args.dump_launches, "w") as f:
                 json.dump([[r[0], r[1]] for r in E.PROFILE.records], f)
     prof = E.PROFILE = E.LaunchProfile(only=top_only)
+    keep_steps.update(range(args.warmup, args.warmup + args.steps))
     t0 = time.perf_counter()
     out = run_steps(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     E.PROFILE = None
+    keep_steps.clear()
     n_found = len(out["objects"])
     crop_hist = {}
     for o in out["objects"]:
@@ -987,6 +1003,24 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+
+    # Every TIMED step's result block against the same step (same frames, same sampling seed) run again on ONE stream after the timed
+    # region: the overlapped loop must give the single-stream bits (round 5 found a co-stream fault in this arrangement; the parity block
+    # below only sees the last step).  Rank 0 reports `parity.steps_bitwise_equal`; any rank that differs fails the whole run.
+    timed_blocks = dict(kept)
+    kept.clear()
+    pipe_chk = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
+    steps_equal = 0
+    for i in range(args.warmup, args.warmup + args.steps):
+        for c in range(n_chunks):
+            o = tail(pipe_chk.run(rgb[c], depth[c], S.REALSENSE_META, seed=i), (4 * 10 ** 6 + i, c))
+        steps_equal += int(i in timed_blocks and torch.equal(o["gathered"], timed_blocks[i]))
+    fence()
+    del pipe_chk, timed_blocks
+    if dist:
+        t = torch.tensor([steps_equal], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        steps_equal = int(t[0])
 
     # With the software-pipelined loop the pose stage of the previous batch runs BESIDE the timed kernels on a second stream, so their
     # HIP-event durations in the timed region include what the co-running launches cost them (throughput goes up, every kernel takes
@@ -1108,6 +1142,21 @@ def main():
         latency = latency_leg(args, device, seg, est, ref, frames[0], runs=args.latency_runs if args.latency else 50)
     if dist and want_latency:
         dist.barrier()
+
+    # Secondary, AFTER the timed region (not part of `value`): BASELINE configs[1] and configs[4] through the same code as --workload pose /
+    # --workload label (every rank takes part: both have their own collectives), compact: 10 steps of 32 crops, 1 step of 200 views
+    pose_leg = label_leg = None
+    if not args.frames:
+        import copy
+        torch.cuda.synchronize()
+        if not args.no_pose_leg:
+            a = copy.copy(args)
+            a.steps, a.warmup, a.crops = 10, 2, 32
+            pose_leg = pose_main(a, rank, world, device, dist, embedded=True)
+        if not args.no_label_leg:
+            a = copy.copy(args)
+            a.steps, a.warmup, a.views = 1, 1, 200
+            label_leg = label_main(a, rank, world, device, dist, embedded=True)
 
     if rank == 0:
         summ = prof.summary()
@@ -1245,10 +1294,44 @@ def main():
             line["cpu_baseline"], oracle_results = cpu_baseline(last, seg_sd, est_sd, ref_sd, gpu_choose, n_frames=min(16, args.batch),
                                                                 n_frames_all=min(args.baseline_frames, args.batch))
             line["parity"] = parity_block(out, oracle_results, last, seg_sd)
+        line.setdefault("parity", {})["steps_bitwise_equal"] = "%d/%d" % (steps_equal, args.steps)
+        line["parity"]["steps_bitwise_equal_note"] = ("the [frames, 1, 8] result block of EVERY timed step (software-pipelined loop, pose stage on the "
+                                                      "second stream) against the same step re-run on one stream after the timed region, torch.equal")
+        if pose_leg is not None:
+            line["pose"] = pose_leg
+        if label_leg is not None:
+            line["label"] = label_leg
+        # the secondary legs in one short object at the END of the line (the driver's record keeps the last 2000 bytes of stdout verbatim
+        # and only the key names of everything it does not know)
+        sec = {"steps_bitwise_equal": line["parity"]["steps_bitwise_equal"]}
+        if "max_dq" in line["parity"]:
+            sec["parity"] = {k: line["parity"].get(k) for k in ("max_dq", "max_dt", "adds_delta_m", "mask_diff_px", "mask_diff_px_outside_tie_band")}
+        if staged:
+            sec["staged_frames_s"] = staged["value"]
+        if modes:
+            sec["f32_frames_s"] = modes["f32"]["value"]
+        if sweep is not None:
+            sec["sweep_frames_s"] = sweep.get("value")
+        if latency is not None:
+            sec["latency_p50_ms"] = latency.get("p50_ms")
+        if pose_leg is not None:
+            sec["pose"] = {"crops_s": pose_leg["value"], "ms_per_step": pose_leg["ms_per_step"],
+                           "knn_1e6x1000_ms": pose_leg["knn_training_size"]["ms"], "knn_frac_of_fp32_lane_rate": pose_leg["knn_training_size"]["frac"],
+                           "adds_launch_us": pose_leg["roofline"]["avg_launch_us"],
+                           "knn_indices_bit_exact": pose_leg.get("parity", {}).get("knn_indices_bit_exact"),
+                           "max_dq": pose_leg.get("parity", {}).get("max_dq"), "cpu_crops_s": pose_leg.get("cpu_baseline", {}).get("value")}
+        if label_leg is not None:
+            sec["label"] = {"views_s": label_leg["value"], "icp_pairs_s": label_leg["icp"]["point_pairs_per_s"],
+                            "icp_gb_s": label_leg["roofline"]["achieved"], "icp_frac_of_8tb_s": label_leg["roofline"]["frac"],
+                            "max_nn_distance_mm": label_leg.get("parity", {}).get("max_nn_distance_mm"),
+                            "cpu_views_s": label_leg.get("cpu_baseline", {}).get("value")}
+        line["secondary"] = sec
         print(json.dumps(line))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if steps_equal != args.steps:
+        raise SystemExit("bench.py: %d of %d timed steps of the overlapped loop differ bitwise from their single-stream re-run" % (args.steps - steps_equal, args.steps))
 
 
 if __name__ == "__main__":

@@ -44,7 +44,6 @@ const char* ape_last_error(void);
  * Returns APE_OK (the reference returns 1; the Python wrapper keeps that convention). */
 int ape_knn_f32(const float* ref, const float* query, int64_t* idx,
                 int batch, int dim, int ref_nb, int query_nb, int k, void* stream);
-int ape_knn_debug(int bits);   /* bit 0: never the four-queries-per-lane kernel of the large-query case; bit 1: that kernel without its group minima (tests / A-B); same indices whatever the bits */
 
 /* ---- dense contractions: conv2d / 1x1 / Linear, exact fp32 on the matrix cores ---------------------------
  * One entry point replaces every torch.nn.Conv2d / Conv1d(k=1) / Linear forward on the path:

@@ -73,6 +73,21 @@ def test_default_line_has_roofline_cpu_baseline_and_parity():
     assert m["unit"] == "frames/s" and 0 < m["value"] < d["value"] and m["steps"] >= 1
     assert d["ranks_seen"] == [[0, 0, d["ranks_seen"][0][2], d["ranks_seen"][0][3]]] and d["distinct_gpus"] == 1
     assert "one 160x160 detection per frame" in d["config"]["frame_selection"] and d["config"]["candidates_skipped"] >= 0
+    # every TIMED step of the overlapped loop re-run on one stream after the timed region: the same bits (a mismatch also fails the run)
+    assert p["steps_bitwise_equal"] == "2/2"
+    # BASELINE configs[1] and configs[4] ride along as compact legs (the lines of --workload pose / --workload label) ...
+    po, la = d["pose"], d["label"]
+    assert po["unit"] == "crops/s" and po["steps"] == 10 and "configs[1]" in po["config"]["workload"] and po["value"] > 0
+    assert po["parity"]["knn_indices_bit_exact"] is True and po["parity"]["max_dq"] <= 1e-4 and 0.3 < po["knn_training_size"]["frac"] < 1
+    assert la["unit"] == "views/s" and la["steps"] == 1 and "configs[4]" in la["config"]["workload"] and "200 synthetic" in la["config"]["workload"]
+    assert la["parity"]["max_nn_distance_mm"] < 1e-6 and la["icp"]["point_pairs_per_s"] > 0 and 0 < la["roofline"]["frac"] < 1
+    # ... and the LAST object of the line sums the secondary legs up in under 1500 bytes (the driver's record keeps the tail of stdout)
+    assert list(d)[-1] == "secondary" and len(json.dumps(d["secondary"])) < 1500
+    sec = d["secondary"]
+    assert sec["steps_bitwise_equal"] == "2/2" and sec["staged_frames_s"] == st["value"] and sec["f32_frames_s"] == m["value"]
+    assert sec["sweep_frames_s"] == sw["value"] and sec["latency_p50_ms"] == lat["p50_ms"]
+    assert sec["pose"]["crops_s"] == po["value"] and sec["pose"]["knn_indices_bit_exact"] is True and sec["pose"]["knn_frac_of_fp32_lane_rate"] == po["knn_training_size"]["frac"]
+    assert sec["label"]["views_s"] == la["value"] and sec["label"]["max_nn_distance_mm"] == la["parity"]["max_nn_distance_mm"]
 
 
 def test_frames_1024_line():

@@ -1,4 +1,4 @@
-"""Same-process A/B of the S32 conv kernels: the library of the previous round (tools/probes/libape_hip_r2.so, built from the round-2
+"""Same-process A/B of the S32 conv kernels: the library of the previous round (tools/attic/probes/libape_hip_r2.so, built from the round-2
 commit by `git archive dc986cc autoposeestimation_amd/csrc include` + make) against the current one, interleaved rounds, the segmentor's
 own layer shapes at bench size.  Both libraries are driven through the same C ABI entry points with the same buffers; outputs are
 compared bit for bit before timing."""
@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from autoposeestimation_amd import _lib, engine as E  # noqa: E402
 
-OLD = os.environ.get("APE_AB_OLD") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "libape_hip_r2.so")
+OLD = os.environ.get("APE_AB_OLD") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "attic", "probes", "libape_hip_r2.so")
 
 
 def bind(path):

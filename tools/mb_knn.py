@@ -1,4 +1,6 @@
-"""k-NN (k = 1, dim 3) throughput: pairs/s and the share of the fp32 vector rate at 11 lane-operations per pair, both kernels"""
+"""k-NN (k = 1, dim 3) throughput: pairs/s and the share of the fp32 vector rate at 11 lane-operations per pair, every form.
+Needs the ablation build (make -C autoposeestimation_amd/csrc ablations; APE_HIP_LIB=autoposeestimation_amd/libape_hip_abl.so): the
+product library has no ape_knn_debug and only the form it launches."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,6 +8,8 @@ from autoposeestimation_amd import _lib
 from autoposeestimation_amd.DenseFusion.lib.knn import KNearestNeighbor
 PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9       # lanes per clock x clock: one fp32 operation per lane and cycle (an FMA counts once here)
 knn = KNearestNeighbor(1)
+import ctypes
+_lib.lib().ape_knn_debug.argtypes = [ctypes.c_int]      # (exported by the ablation build only; not part of include/ape_hip.h)
 def t(f, n=5, rounds=5):
     f(); torch.cuda.synchronize()
     ts = []
