@@ -177,7 +177,8 @@ def test_software_pipelined_loop_is_bitwise_the_single_stream_loop_over_12_steps
     s = bench_setup
     bench, plain = s["bench"], s["pipe"]
     steps = 12
-    batches = [(s["rgb"].roll(5 * i, 0).contiguous(), s["depth"].roll(5 * i, 0).contiguous()) for i in range(steps)]
+    rot = lambda x, k: torch.cat([x[-k:], x[:-k]]).contiguous() if k else x          # noqa: E731  (torch.roll has no uint16 kernel)
+    batches = [(rot(s["rgb"], 5 * i), rot(s["depth"], 5 * i)) for i in range(steps)]
     want = []
     for i, (r, d) in enumerate(batches):
         o = plain.run(r, d, S.REALSENSE_META, seed=100 + i)
