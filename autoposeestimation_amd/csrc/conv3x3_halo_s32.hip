@@ -90,6 +90,19 @@ __device__ __forceinline__ void ds_read_half(u32x4 (&A)[2][2], u32x4 (&Bf)[4][2]
     APE_DS_READ(Bf[JOFF + 1][0], bh, JOFF * 2048 + 2048); APE_DS_READ(Bf[JOFF + 1][1], bl, JOFF * 2048 + 2048);
 }
 
+// PP form: one pixel row's two planes / the four weight blocks' two planes
+__device__ __forceinline__ void ds_read_pair(u32x4 (&A)[2], unsigned ah, unsigned al)
+{
+    APE_DS_READ(A[0], ah, 0); APE_DS_READ(A[1], al, 0);
+}
+__device__ __forceinline__ void ds_read_b4(u32x4 (&Bf)[4][2], unsigned bh, unsigned bl)
+{
+    APE_DS_READ(Bf[0][0], bh, 0);    APE_DS_READ(Bf[0][1], bl, 0);
+    APE_DS_READ(Bf[1][0], bh, 2048); APE_DS_READ(Bf[1][1], bl, 2048);
+    APE_DS_READ(Bf[2][0], bh, 4096); APE_DS_READ(Bf[2][1], bl, 4096);
+    APE_DS_READ(Bf[3][0], bh, 6144); APE_DS_READ(Bf[3][1], bl, 6144);
+}
+
 // keeps asm-read destinations allocated up to this point (a free function: asm operands cannot name variables captured by a generic
 // lambda; device pass only: the host pass cannot check a "v" constraint)
 __device__ __forceinline__ void keep_regs(const u32x4& a, const u32x4& b)
@@ -127,7 +140,17 @@ constexpr int B_TILE = 128 * 128;                   // one tap's weights: 128 ro
 constexpr int B_RING = 4;
 constexpr int LDS_BYTES = A_BYTES + B_RING * B_TILE;   // 160 KB
 
-template <int D>
+// PP ("ping-pong", round 6): the two waves of a SIMD (wave w and w + 4) alternate roles instead of running the tap in lockstep.  PMC of
+// the one-barrier form (profiles/r05_pmc_utilisation.txt): per tap and SIMD 1440 cycles with BOTH waves issuing matrix instructions and
+// ~730 with both in their reads / DMA issue / waits -- matrix pipe 0.64 busy.  Here a tap is two barrier-separated slots: in one a wave
+// multiplies (C: its 48 MFMAs from ONE fragment set, nothing else in the stream), in the other it loads (L: the 16 fragment reads of its
+// next tap, its DMA pieces, the waits); waves 4-7 run one slot behind waves 0-3, so every SIMD has one wave in C beside one in L.
+// Same products, same order per accumulator, same DMA duty per tap: bit-identical outputs.  The LDS protocol in slots (s = 2 t for C(t)
+// of waves 0-3): the duties of tap t are issued in slots 2t+1 (waves 0-3) / 2t+2 (waves 4-7), retired by the issuing wave's counted
+// vmcnt at the end of its NEXT L slot (2t+3 / 2t+4) and first read in slot 2t+5 (the L slot of tap t+2, which reads tap t+3's
+// fragments) -- every duty of the one-barrier schedule is needed no earlier than tap t+3; a duty overwrites rows / weight slots last read
+// for tap t-1, i.e. in slots 2t-3 / 2t-2.
+template <int D, bool PP>
 __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -296,6 +319,24 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         for (int j = 0; j < 4; ++j) keep_regs(Bf[bset][j][0], Bf[bset][j][1]);
     };
 
+    u32x4 Af[4][2], Bs[4][2];           // PP: the ONE fragment set (pixel rows 0..3 x plane, channel blocks 0..3 x plane)
+    auto read_all = [&](int ring, int tap, int rp, int tgb) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned ah = a_lane[kx][0], al = a_lane[kx][1];
+        const int rb = ring + rp * wm + ky * D;
+        const unsigned so = (unsigned)((tgb & (B_RING - 1)) * B_TILE);
+        const unsigned bh = b_lane[0] + so, bl = b_lane[1] + so;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ro = (unsigned)(((rb + i) & (RING_ROWS - 1)) * ROW_B);
+            ds_read_pair(Af[i], ah + ro, al + ro);
+        }
+        ds_read_b4(Bs, bh, bl);
+    };
+    auto keep_all = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { keep_regs(Af[i][0], Af[i][1]); keep_regs(Bs[i][0], Bs[i][1]); }
+    };
     // one wave of every SIMD pair at priority 1 for the whole kernel pays in the GEMM kernel (conv_gemm_s32.hip, -1.5 .. -3 %) but not
     // here (+-0 .. +1 % on all six layer shapes, tools/mb_halo_s32.py): off unless the debug bit asks for it
     if ((a.dbg & 1) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
@@ -308,6 +349,14 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     if (total_taps > 2) dma_b_tap(0, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    const bool group_b = PP && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;       // waves 4-7: the second wave of every SIMD
+    if constexpr (PP) {
+        read_all(0, 0, rpw, 0);
+        phase_end();
+        keep_all();
+        if (group_b) __builtin_amdgcn_s_barrier();          // waves 4-7 run one slot behind: they sit out slot 0 (C(0) of waves 0-3)
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
     read_half(I0{}, I0{}, 0, 0, 0);
     u32x4 dummy[2][2];
     {   // second half of tap 0's weights (its pixel rows 2, 3 are read during the tap's first phase)
@@ -318,6 +367,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     keep_half(I0{}, I0{});
     keep_regs(dummy[0][0], dummy[0][1]);
     keep_regs(dummy[1][0], dummy[1][1]);
+    }
 
     // ---- one tap = two phases of 24 MFMAs (pixel rows 0,1 | 2,3 against the four weight blocks of B set P).  While a phase runs, the
     // fragments of the NEXT phase are read: phase 0 fetches this tap's rows 2,3 and weight blocks 0,1 of tap t+1 (into the other B
@@ -377,6 +427,85 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         phase_end();
         keep_half(I0{}, std::integral_constant<int, P ^ 1>{});
         if (!ABL(256)) wait_vmcnt(issued);
+        if (!ABL(128)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+
+    // ---- PP form of one tap (see the note at the kernel's head): C(t) | barrier | L(t+1) + the duties of tap t | barrier ------------
+    auto mfma_all = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= rpw || ABL(1024)) continue;             // (a ragged tile: rows past rpw do not exist)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[j][0]), bl = __builtin_bit_cast(bf16x8, Bs[j][1]);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, Af[i][0]), al = __builtin_bit_cast(bf16x8, Af[i][1]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    // the halo duty of one tap in the PP form: image rows [AR0, AR0 + NR) of chunk dc (NR <= 8 in every duty of the schedule, so a wave has at
+    // most ONE row per x-piece: row roww[xp] = 3 (wave - xp) mod 8 if that is < NR -- the same dealing as dma_a_rows_xp).  Lean on purpose: a
+    // wave issues one instruction per four cycles at best, and the L slot is the longer one -- the row part of the source address goes
+    // through the instruction's SCALAR offset (no vector add), everything per tap is formed once for the three pieces.
+    const unsigned rowstride = (unsigned)(a.W * a.ldx * 4);
+    int roww[3];
+    unsigned rsw[3];
+#pragma unroll
+    for (int xp = 0; xp < 3; ++xp) {
+        roww[xp] = __builtin_amdgcn_readfirstlane((3 * (wave - xp + 8)) & 7);
+        rsw[xp] = (unsigned)roww[xp] * rowstride;
+    }
+    auto duty_pp = [&](auto ar0_c, auto nr_c, bool en, int dc, int dring) __attribute__((always_inline)) {
+        constexpr int AR0 = decltype(ar0_c)::value, NR = decltype(nr_c)::value;
+        static_assert(NR <= 8, "one row per wave and x-piece");
+        if constexpr (NR > 0) {
+            if (en && !ABL(512)) {
+                const int gy0 = dma_y0 - D + AR0;
+                const unsigned s0 = (unsigned)(((dma_b * a.H + gy0) * a.W) * a.ldx * 4 + dc * 128);
+                const int ring_b = dring + AR0;
+                auto piece = [&](auto xp_c) __attribute__((always_inline)) {
+                    constexpr int xp = decltype(xp_c)::value;
+                    if (roww[xp] < NR) {
+                        const bool ok = (unsigned)(gy0 + roww[xp]) < (unsigned)a.H;
+                        const unsigned voff = ok ? lane_x[xp] : 0x80000000u;         // (a row outside the image: every lane out of range -> zeros)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void*)(smem + ((ring_b + roww[xp]) & (RING_ROWS - 1)) * ROW_B + xp * 1024), 16,
+                                                                 voff, s0 + rsw[xp], 0, 0);
+                    }
+                };
+                piece(I0{});
+                piece(I1{});
+                piece(I2{});
+            }
+        }
+    };
+    auto tap_body_pp = [&](auto ar0_c, auto nr_c, bool en, int tg, int c, int tap, bool last_of_tile, int ring_cur, int ring_next, int dc, int dring) __attribute__((always_inline)) {
+        const bool wrap = tap == 8;
+        const int nring = wrap ? ring_next : ring_cur, ntap = wrap ? 0 : tap + 1;
+        const bool more_b = tg + 3 < total_taps && !ABL(512);
+        // C(t)
+        mfma_all();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!ABL(128)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // L(t+1): the fragments of the next tap (across a chunk or tile seam: of the next image's tap 0) ...
+        if (!ABL(2048)) read_all(nring, ntap, (wrap && last_of_tile) ? rpw_next : rpw, tg + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ... the pieces this wave issued in its previous L slot (a whole tap ago) have landed: the barrier below publishes them ...
+        if (!ABL(256)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ... and this tap's DMA duties
+        duty_pp(ar0_c, nr_c, en, dc, dring);
+        if (more_b) {
+            const int t3 = tap + 3;          // (chunk, tap) of flattened tap tg + 3: the same weights for every tile of this workgroup
+            const int c3 = t3 < 9 ? c : (last_of_tile ? 0 : c + 1);
+            dma_b_tap(c3, t3 < 9 ? t3 : t3 - 9, (tg + 3) & (B_RING - 1));
+        }
+        phase_end();
+        keep_all();
         if (!ABL(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -482,7 +611,15 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         const bool has_next = gc + 1 < total_chunks;       // a further chunk (of this tile or of the workgroup's next tile) follows
         const int tg = gc * 9;
         // tap 0: the last 2 D rows of THIS chunk's image (skipped for the workgroup's very first chunk: the prologue loaded all of it)
-        tap_body(PA{}, tg + 0, c, 0, last_of_tile, ring_cur, ring_next, c, ring_cur, I - 2 * D, gc > 0 ? 2 * D : 0);
+        // (PP: the duty's row range is a compile-time pair, its run-time part is the enable)
+        auto tap_any = [&](auto set_c, auto ar0_c, auto nr_c, bool en, int tg_, int tap_, int dc_, int dring_) __attribute__((always_inline)) {
+            if constexpr (PP) tap_body_pp(ar0_c, nr_c, en, tg_, c, tap_, last_of_tile, ring_cur, ring_next, dc_, dring_);
+            else tap_body(set_c, tg_, c, tap_, last_of_tile, ring_cur, ring_next, dc_, dring_, decltype(ar0_c)::value, en ? decltype(nr_c)::value : 0);
+        };
+        constexpr int FREE = RING_ROWS - I;                // rows of the next image that land on ring rows no image uses now
+        constexpr int H1 = (FREE + 1) / 2;
+        using Z = std::integral_constant<int, 0>;
+        tap_any(PA{}, std::integral_constant<int, I - 2 * D>{}, std::integral_constant<int, 2 * D>{}, gc > 0, tg + 0, 0, c, ring_cur);
         // from here on the DMA side works on the next chunk's image: chunk c + 1 of this tile, or chunk 0 of the workgroup's next tile
         int dc = c + 1;
         if (last_of_tile) {
@@ -494,16 +631,14 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
                 rpw_next = rows_per_wave(ty0);
             }
         }
-        constexpr int FREE = RING_ROWS - I;                // rows of the next image that land on ring rows no image uses now
-        constexpr int H1 = (FREE + 1) / 2;
-        tap_body(PB{}, tg + 1, c, 1, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, has_next ? H1 : 0);
-        tap_body(PA{}, tg + 2, c, 2, last_of_tile, ring_cur, ring_next, dc, ring_next, H1, has_next ? FREE - H1 : 0);
-        tap_body(PB{}, tg + 3, c, 3, last_of_tile, ring_cur, ring_next, dc, ring_next, FREE, has_next ? D : 0);
-        tap_body(PA{}, tg + 4, c, 4, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
-        tap_body(PB{}, tg + 5, c, 5, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
-        tap_body(PA{}, tg + 6, c, 6, last_of_tile, ring_cur, ring_next, dc, ring_next, FREE + D, has_next ? D : 0);
-        tap_body(PB{}, tg + 7, c, 7, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
-        tap_body(PA{}, tg + 8, c, 8, last_of_tile, ring_cur, ring_next, dc, ring_next, 0, 0);
+        tap_any(PB{}, Z{}, std::integral_constant<int, H1>{}, has_next, tg + 1, 1, dc, ring_next);
+        tap_any(PA{}, std::integral_constant<int, H1>{}, std::integral_constant<int, FREE - H1>{}, has_next, tg + 2, 2, dc, ring_next);
+        tap_any(PB{}, std::integral_constant<int, FREE>{}, std::integral_constant<int, D>{}, has_next, tg + 3, 3, dc, ring_next);
+        tap_any(PA{}, Z{}, Z{}, false, tg + 4, 4, dc, ring_next);
+        tap_any(PB{}, Z{}, Z{}, false, tg + 5, 5, dc, ring_next);
+        tap_any(PA{}, std::integral_constant<int, FREE + D>{}, std::integral_constant<int, D>{}, has_next, tg + 6, 6, dc, ring_next);
+        tap_any(PB{}, Z{}, Z{}, false, tg + 7, 7, dc, ring_next);
+        tap_any(PA{}, Z{}, Z{}, false, tg + 8, 8, dc, ring_next);
         tile_done = last_of_tile;
         c = last_of_tile ? 0 : c + 1;
     };
@@ -524,14 +659,18 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             if (gc + 2 < total_chunks) { int tn0; decode(cur_orig, cur_b, cur_y0, cur_x0, tn0); rpw = rows_per_wave(cur_y0); }
         }
     }
+    if (PP && !group_b) {          // waves 0-3 close the slot in which waves 4-7 multiply their last tap
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 #endif
 }
 #undef APE_DS_READ
 
-template <int D>
+template <int D, bool PP>
 int launch_halo_s32(const HaloS32Args& a, hipStream_t st)
 {
-    auto kern = halo_s32_kernel<D>;
+    auto kern = halo_s32_kernel<D, PP>;
     static ape::DeviceOnce once;       // (per kernel instantiation)
     int ncu = 256;
     if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), LDS_BYTES, &ncu)) return rc;
@@ -582,7 +721,12 @@ extern "C" int ape_conv3x3_halo_s32(const void* x_s32, const void* w_s32k, const
     a.act = p.act; a.alpha = p.alpha; a.bias_bstride = p.bias_bstride; a.out_fmt = out_fmt; a.res_fmt = res_fmt;
     a.tiles_x = ape::ceil_div(p.W, TS); a.tiles_y = ape::ceil_div(p.H, TS); a.n_tiles = ape::ceil_div(p.Cout, 128);
     hipStream_t st = (hipStream_t)stream;
-    if (p.dil == 1) return launch_halo_s32<1>(a, st);
-    if (p.dil == 2) return launch_halo_s32<2>(a, st);
-    return launch_halo_s32<4>(a, st);
+    if (g_halo_s32_dbg & 4096) {      // the one-barrier-per-tap form of rounds 2-5 (A/B: tools/mb_halo_pp.py; bit-identical outputs)
+        if (p.dil == 1) return launch_halo_s32<1, false>(a, st);
+        if (p.dil == 2) return launch_halo_s32<2, false>(a, st);
+        return launch_halo_s32<4, false>(a, st);
+    }
+    if (p.dil == 1) return launch_halo_s32<1, true>(a, st);
+    if (p.dil == 2) return launch_halo_s32<2, true>(a, st);
+    return launch_halo_s32<4, true>(a, st);
 }

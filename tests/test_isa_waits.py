@@ -20,8 +20,8 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 
 # file -> [(substring of the mangled kernel name, human name, LDS-DMA kernel?)]
 KERNELS = {
-    "conv3x3_halo_s32.hip": [("halo_s32_kernelILi1E", "halo_s32_kernel<1>", True), ("halo_s32_kernelILi2E", "halo_s32_kernel<2>", True),
-                             ("halo_s32_kernelILi4E", "halo_s32_kernel<4>", True)],
+    "conv3x3_halo_s32.hip": [("halo_s32_kernelILi%dELb%dE" % (d, pp), "halo_s32_kernel<%d, %s>" % (d, "true" if pp else "false"), True)
+                             for d in (1, 2, 4) for pp in (1, 0)],
     "conv3x3_halo_mx.hip": [("halo_mx_kernelILi1E", "halo_mx_kernel<1>", True), ("halo_mx_kernelILi2E", "halo_mx_kernel<2>", True),
                             ("halo_mx_kernelILi4E", "halo_mx_kernel<4>", True)],
     "conv_gemm_s32.hip": [("gemm_s32_kernelILi128E", "gemm_s32_kernel<128>", True), ("gemm_s32_kernelILi192E", "gemm_s32_kernel<192>", True),
@@ -48,7 +48,8 @@ def test_wait_counters_and_spills(audit_mod, hip_file, tmp_path_factory):
     for key, name, has_dma in KERNELS[hip_file]:
         sym = [s for s in symbols if key in s]
         assert len(sym) == 1, (name, sym)
-        r = audit_mod.audit(asm, sym[0])
+        # (halo_s32's ping-pong form retires a piece two barriers after its issue: tools/isa_audit.py, dma_barrier_slack)
+        r = audit_mod.audit(asm, sym[0], dma_barrier_slack=2 if (hip_file == "conv3x3_halo_s32.hip" and "true" in name) else 0)
         assert r["n_mfma"] >= 100 and r["n_dsread"] >= 60, (name, r["n_mfma"], r["n_dsread"])       # the walk saw the real kernel
         assert (r["n_dma"] > 0) == has_dma, (name, r["n_dma"])
         assert not r["findings"], "%s:\n  %s" % (name, "\n  ".join(r["findings"]))
