@@ -140,16 +140,22 @@ constexpr int B_TILE = 128 * 128;                   // one tap's weights: 128 ro
 constexpr int B_RING = 4;
 constexpr int LDS_BYTES = A_BYTES + B_RING * B_TILE;   // 160 KB
 
-// PP ("ping-pong", round 6): the two waves of a SIMD (wave w and w + 4) alternate roles instead of running the tap in lockstep.  PMC of
-// the one-barrier form (profiles/r05_pmc_utilisation.txt): per tap and SIMD 1440 cycles with BOTH waves issuing matrix instructions and
-// ~730 with both in their reads / DMA issue / waits -- matrix pipe 0.64 busy.  Here a tap is two barrier-separated slots: in one a wave
-// multiplies (C: its 48 MFMAs from ONE fragment set, nothing else in the stream), in the other it loads (L: the 16 fragment reads of its
-// next tap, its DMA pieces, the waits); waves 4-7 run one slot behind waves 0-3, so every SIMD has one wave in C beside one in L.
-// Same products, same order per accumulator, same DMA duty per tap: bit-identical outputs.  The LDS protocol in slots (s = 2 t for C(t)
-// of waves 0-3): the duties of tap t are issued in slots 2t+1 (waves 0-3) / 2t+2 (waves 4-7), retired by the issuing wave's counted
-// vmcnt at the end of its NEXT L slot (2t+3 / 2t+4) and first read in slot 2t+5 (the L slot of tap t+2, which reads tap t+3's
-// fragments) -- every duty of the one-barrier schedule is needed no earlier than tap t+3; a duty overwrites rows / weight slots last read
-// for tap t-1, i.e. in slots 2t-3 / 2t-2.
+// PP ("ping-pong", round 6): the two waves of a SIMD (wave w and w + 4) run a tap's two segments in OPPOSITE order instead of in lockstep.
+// PMC of the lockstep form (profiles/r05_pmc_utilisation.txt): per tap and SIMD 1440 cycles with BOTH waves issuing matrix instructions and
+// ~730 with both in their reads / DMA issue / waits -- matrix pipe 0.64 busy.  Here a tap is, for every wave, a matrix segment C (its 48
+// MFMAs from ONE fragment set, nothing else in the stream) and a load segment L (the 16 fragment reads of its next tap, its DMA pieces,
+// the waits), and there is still ONE barrier per tap and wave -- but waves 0-3 close their interval behind L (C(t) L(t+1) |) and waves 4-7
+// behind C (L(t) C(t) |): inside an interval one wave of every SIMD multiplies while the other loads, and neither waits for the other
+// in between.  Same products, same order per accumulator, same DMA duty per tap as the lockstep form: bit-identical outputs.
+// LDS protocol (interval t = what lies between the barriers t-1 and t): tap X's fragments are read by waves 0-3 at the end of interval
+// X-1 and by waves 4-7 at the start of interval X; the duties of tap t (they overwrite rows / the weight slot last read for tap t-1)
+// are issued at the end of interval t (waves 0-3) or at the start of interval t+1 (waves 4-7: their L(t+1) opens that interval), retired
+// by the issuing wave's vmcnt(0) in interval t+1 (waves 0-3: in front of their next duties; waves 4-7: behind their C, in front of
+// their barrier) and so published by barrier t+1; the first reads of what they bring are those of tap t+3, at the end of interval t+2
+// -- every duty of the schedule is needed no earlier.
+// (Built first with TWO barriers per tap -- a slot for C beside a slot for L, waves 4-7 one slot behind: -9.5 % over the seven layer shapes
+// against the lockstep form; this form -11.5 %.  With the fragment reads moved into C, one pair per MFMA triple on a second register set:
+// slower than either, tools/attic/halo_s32_pp2_reads_in_matrix_slot.patch.  A static priority for C: no change.)
 template <int D, bool PP>
 __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
 {
@@ -354,7 +360,6 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         read_all(0, 0, rpw, 0);
         phase_end();
         keep_all();
-        if (group_b) __builtin_amdgcn_s_barrier();          // waves 4-7 run one slot behind: they sit out slot 0 (C(0) of waves 0-3)
         __builtin_amdgcn_sched_barrier(0);
     } else {
     read_half(I0{}, I0{}, 0, 0, 0);
@@ -489,13 +494,18 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         // C(t)
         mfma_all();
         __builtin_amdgcn_sched_barrier(0);
-        if (!ABL(128)) __builtin_amdgcn_s_barrier();
+        // waves 4-7 close their interval here, behind C (waves 0-3: behind L, below).  They issued their pieces at the START of this interval and
+        // retire them now: this barrier publishes them
+        if (group_b) {
+            if (!ABL(256)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!ABL(128)) __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
         // L(t+1): the fragments of the next tap (across a chunk or tile seam: of the next image's tap 0) ...
         if (!ABL(2048)) read_all(nring, ntap, (wrap && last_of_tile) ? rpw_next : rpw, tg + 1);
         __builtin_amdgcn_sched_barrier(0);
         // ... the pieces this wave issued in its previous L slot (a whole tap ago) have landed: the barrier below publishes them ...
-        if (!ABL(256)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!group_b && !ABL(256)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // ... and this tap's DMA duties
         duty_pp(ar0_c, nr_c, en, dc, dring);
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         }
         phase_end();
         keep_all();
-        if (!ABL(128)) __builtin_amdgcn_s_barrier();
+        if (!group_b && !ABL(128)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -658,10 +668,6 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
             cur_orig += grid;
             if (gc + 2 < total_chunks) { int tn0; decode(cur_orig, cur_b, cur_y0, cur_x0, tn0); rpw = rows_per_wave(cur_y0); }
         }
-    }
-    if (PP && !group_b) {          // waves 0-3 close the slot in which waves 4-7 multiply their last tap
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
     }
 #endif
 }

@@ -120,6 +120,37 @@ def test_halo_s32_equals_halo_bitwise(shape):
     assert (got2 - got).abs().max().item() <= 2.0 ** -15 * res.abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 16, 32, 128, 1), (1, 17, 9, 96, 160, 1), (3, 60, 80, 128, 256, 2), (1, 21, 33, 64, 192, 4), (4, 30, 40, 160, 128, 2),
+                                   (64, 60, 80, 256, 256, 1), (64, 60, 80, 512, 512, 4), (40, 28, 50, 128, 384, 4), (17, 60, 80, 64, 128, 2)])
+def test_halo_s32_ping_pong_equals_the_lockstep_schedule_bitwise(shape):
+    """halo_s32's round-6 schedule (the two waves of a SIMD run a tap's matrix segment and its load segment in opposite order; waves 0-3
+    close their barrier interval behind the loads, waves 4-7 behind the MFMAs) against the one it replaced (ape_conv3x3_halo_s32_debug bit
+    4096 launches the lockstep kernel; both are in the product library): same products, same order per accumulator, same DMA duty per tap ->
+    the same bits, on one-tile and many-tile workgroups, odd and even chunk counts, ragged tiles, every dilation, with and without an S32
+    residual, fp32 and S32 outputs -- and the same bits again on every one of ten repetitions of the big shapes (an LDS-DMA piece read
+    before the barrier that publishes it would come and go with timing)."""
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd import engine as E
+    b, h, w, cin, cout, dil = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + dil + b)
+    xs = E.S32.from_f32((torch.randn(b, h, w, cin, generator=g) * 2).cuda())
+    conv = E.Conv(torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5, torch.randn(cout, generator=g), 1, dil, dil, E.ACT_PRELU, alpha=0.25,
+                  device="cuda", precision="bf16x3")
+    res = E.S32.from_f32(torch.randn(b, h, w, cout, generator=g).cuda())
+    lib = _lib.lib()
+    try:
+        lib.ape_conv3x3_halo_s32_debug(4096)
+        want = [conv(xs).clone(), conv(xs, residual=res, out_fmt=E.FMT_S32).t.clone()]
+        lib.ape_conv3x3_halo_s32_debug(0)
+        reps = 10 if b * h * w >= 64 * 60 * 80 else 2
+        for rep in range(reps):
+            got = [conv(xs), conv(xs, residual=res, out_fmt=E.FMT_S32).t]
+            for k, (gt, wt) in enumerate(zip(got, want)):
+                assert torch.equal(gt.view(torch.int32), wt.view(torch.int32)), (shape, rep, k, int((gt.view(torch.int32) != wt.view(torch.int32)).sum()))
+    finally:
+        lib.ape_conv3x3_halo_s32_debug(0)
+
+
 def test_s32_path_rejects_what_it_cannot_run():
     from autoposeestimation_amd import engine as E
     x = E.S32(torch.zeros(1, 8, 8, 64, device="cuda"))

@@ -271,9 +271,10 @@ def audit(asm_path, symbol, max_findings=20, dma_barrier_slack=0):
             stack.append((nxt, iter(sorted(succ[nxt]))))
     order.reverse()
     flat = [ins for bi in order for ins in blocks[bi]]
-    # dma_barrier_slack: how many barriers a piece may cross before its issuing wave's vmcnt wait.  0 for the one-barrier-per-tap kernels
-    # (wait, then the barrier that publishes).  2 for halo_s32's ping-pong form: a wave issues its pieces at the END of a load slot, multiplies
-    # for a slot, and retires them with vmcnt(0) in its NEXT load slot, in front of that slot's closing barrier -- the third after the issue.
+    # dma_barrier_slack: how many barriers a piece may cross before its issuing wave's vmcnt wait.  0 for the lockstep kernels (wait, then the
+    # barrier that publishes).  1 for halo_s32's ping-pong form: waves 0-3 issue their pieces at the END of an interval, in front of its
+    # barrier, and retire them with vmcnt(0) in their next load segment, in front of the NEXT barrier (waves 4-7 issue behind a barrier and
+    # wait in front of the next one).
     dma_since_wait = bars_since_dma = 0
     for ins in flat:
         if ins.kind == "wait" and ins.vm_wait is not None:
@@ -533,7 +534,7 @@ if __name__ == "__main__":
     for sym in kernel_symbols(asm):
         if pats and not any(p in sym for p in pats):
             continue
-        r = audit(asm, sym, dma_barrier_slack=2 if ("halo_s32_kernel" in sym and "Lb1E" in sym) else 0)
+        r = audit(asm, sym, dma_barrier_slack=1 if ("halo_s32_kernel" in sym and "Lb1E" in sym) else 0)
         print(sym)
         print("   %d instructions, %d MFMA, %d ds_read, %d LDS-DMA; vmcnt literals %s; %s" %
               (r["n_insns"], r["n_mfma"], r["n_dsread"], r["n_dma"], r["vmcnt_literals"], r["meta"]))
