@@ -105,6 +105,16 @@ __device__ __forceinline__ void ds_read_frags(u32x4 (&f)[TNH][2], unsigned hi, u
         APE_DS_READ(f[1][1], lo, OFF + 2048);
     }
 }
+// PP form: all N 16-row blocks x two planes of one operand (block i at + i * 2048)
+template <int N, int I = 0>
+__device__ __forceinline__ void ds_read_blocks(u32x4 (&f)[N][2], unsigned hi, unsigned lo)
+{
+    if constexpr (I < N) {
+        APE_DS_READ(f[I][0], hi, I * 2048);
+        APE_DS_READ(f[I][1], lo, I * 2048);
+        ds_read_blocks<N, I + 1>(f, hi, lo);
+    }
+}
 #undef APE_DS_READ
 
 // keeps asm-read destinations allocated up to this point (a free function: asm operands cannot name variables captured by a generic
@@ -118,6 +128,90 @@ __device__ __forceinline__ void keep_regs(const u32x4& a, const u32x4& b)
 
 constexpr int BM = 256;
 constexpr int A_STAGE = BM * 128;        // bytes of the A image of one k-tile
+
+// ---- epilogue straight from the registers (both schedules): lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel 16 i + frow ----------
+template <int BN, bool RES>
+__device__ __forceinline__ void gemm_s32_epilogue(const GemmS32Args& a, f32x4 (&acc)[8][BN / 64], int m0, int m_end, int n0, int wm, int wn, int lane)
+{
+    constexpr int TN = BN / 64;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int frow_e = lane_e & 15, fc_e = lane_e >> 4;
+    const int nq = n0 + wn * (TN * 16) + fc_e * 4;
+    const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);
+    const bool sigm = a.act == APE_ACT_SIGMOID;
+    float4 b4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nq + j * 16;
+        b4[j] = (a.bias && !a.bias_bstride && n < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // The residual tile is requested FOUR pixel rows ahead of its use, as two 8-byte halves per (row, block) for both formats (S32: hi 4 x
+    // bf16 | lo 4 x bf16, 64 B apart; fp32: floats 0,1 | 2,3): 4 x TN loads in flight per round trip instead of TN -- the stores of
+    // row i may alias the loads of row i + 1 for all the compiler knows, so the row-at-a-time form paid eight serialised round trips
+    // per tile (the PSP bottleneck, whose residual is the 1.26 GB prior sum, spent as long in its epilogue as in its k-loop).
+    const bool rs32 = a.res_fmt == APE_FMT_S32;
+    const long rsecond = rs32 ? 64 : 8;
+#pragma unroll
+    for (int i0 = 0; i0 < 8; i0 += 4) {
+        uint2 rlo[4][TN], rhi[4][TN];
+        if constexpr (RES) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int m = m0 + wm * 128 + (i0 + ii) * 16 + frow_e;
+                const size_t mc = m < a.M ? m : a.M - 1;                       // (a clamped, never-used address for rows past M)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = nq + j * 16;
+                    const int cr = a.roff + (n < a.Cout ? n : 0);
+                    const char* rp = a.res + (rs32 ? mc * a.ldr * 4 + (size_t)((cr >> 5) * 128 + (cr & 31) * 2) : (mc * a.ldr + cr) * 4);
+                    rlo[ii][j] = *reinterpret_cast<const uint2*>(rp);
+                    rhi[ii][j] = *reinterpret_cast<const uint2*>(rp + rsecond);
+                }
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = i0 + ii;
+            const int m = m0 + wm * 128 + i * 16 + frow_e;
+            if (m >= m_end) continue;
+            const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nq + j * 16;
+                if (n >= a.Cout) continue;
+                float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
+                else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
+                if constexpr (RES) {
+                    if (rs32) {
+                        const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[ii][j]), l = __builtin_bit_cast(bf16x4, rhi[ii][j]);
+                        // (hi + lo first, then the add: the order of the row-at-a-time form)
+                        vv[0] += (float)h[0] + (float)l[0]; vv[1] += (float)h[1] + (float)l[1];
+                        vv[2] += (float)h[2] + (float)l[2]; vv[3] += (float)h[3] + (float)l[3];
+                    } else {
+                        vv[0] += __uint_as_float(rlo[ii][j].x); vv[1] += __uint_as_float(rlo[ii][j].y);
+                        vv[2] += __uint_as_float(rhi[ii][j].x); vv[3] += __uint_as_float(rhi[ii][j].y);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[e] = sigm ? act_fn(vv[e], a.act, a.alpha) : ape::act_fast(vv[e], af);
+                if (ABL(256)) continue;              // (timing only: no stores)
+                if (a.out_fmt == APE_FMT_S32) {
+                    const int cy = a.yoff + n;
+                    char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
+                    bf16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
+                    *reinterpret_cast<bf16x4*>(yp) = h;
+                    *reinterpret_cast<bf16x4*>(yp + 64) = l;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
+        }
+    }
+}
 
 // RES: the build with the residual operand.  Its epilogue needs 64 more registers (the residual tile requested four rows ahead), which the
 // tile walk below cannot spare (hipcc spills 116 VGPRs in the loop form), so it stays one tile per workgroup: has_next is constant false
@@ -413,84 +507,7 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
     }
     if (kt < nk) ktile(kt, I0{});
 
-    // ---- epilogue straight from the registers: lane (frow, fc) holds channels 16 j + 4 fc .. + 3 of pixel 16 i + frow ---------
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int frow_e = lane_e & 15, fc_e = lane_e >> 4;
-    const int nq = n0 + wn * (TN * 16) + fc_e * 4;
-    const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);
-    const bool sigm = a.act == APE_ACT_SIGMOID;
-    float4 b4[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = nq + j * 16;
-        b4[j] = (a.bias && !a.bias_bstride && n < a.Cout) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // The residual tile is requested FOUR pixel rows ahead of its use, as two 8-byte halves per (row, block) for both formats (S32: hi 4 x
-    // bf16 | lo 4 x bf16, 64 B apart; fp32: floats 0,1 | 2,3): 4 x TN loads in flight per round trip instead of TN -- the stores of
-    // row i may alias the loads of row i + 1 for all the compiler knows, so the row-at-a-time form paid eight serialised round trips
-    // per tile (the PSP bottleneck, whose residual is the 1.26 GB prior sum, spent as long in its epilogue as in its k-loop).
-    const bool rs32 = a.res_fmt == APE_FMT_S32;
-    const long rsecond = rs32 ? 64 : 8;
-#pragma unroll
-    for (int i0 = 0; i0 < 8; i0 += 4) {
-        uint2 rlo[4][TN], rhi[4][TN];
-        if constexpr (RES) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int m = m0 + wm * 128 + (i0 + ii) * 16 + frow_e;
-                const size_t mc = m < a.M ? m : a.M - 1;                       // (a clamped, never-used address for rows past M)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = nq + j * 16;
-                    const int cr = a.roff + (n < a.Cout ? n : 0);
-                    const char* rp = a.res + (rs32 ? mc * a.ldr * 4 + (size_t)((cr >> 5) * 128 + (cr & 31) * 2) : (mc * a.ldr + cr) * 4);
-                    rlo[ii][j] = *reinterpret_cast<const uint2*>(rp);
-                    rhi[ii][j] = *reinterpret_cast<const uint2*>(rp + rsecond);
-                }
-            }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = i0 + ii;
-            const int m = m0 + wm * 128 + i * 16 + frow_e;
-            if (m >= m_end) continue;
-            const float* brow = (a.bias && a.bias_bstride) ? a.bias + (size_t)(m / a.rows_per_image) * a.bias_bstride : nullptr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = nq + j * 16;
-                if (n >= a.Cout) continue;
-                float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (brow) { vv[0] += brow[n]; vv[1] += brow[n + 1]; vv[2] += brow[n + 2]; vv[3] += brow[n + 3]; }
-                else { vv[0] += b4[j].x; vv[1] += b4[j].y; vv[2] += b4[j].z; vv[3] += b4[j].w; }
-                if constexpr (RES) {
-                    if (rs32) {
-                        const bf16x4 h = __builtin_bit_cast(bf16x4, rlo[ii][j]), l = __builtin_bit_cast(bf16x4, rhi[ii][j]);
-                        // (hi + lo first, then the add: the order of the row-at-a-time form)
-                        vv[0] += (float)h[0] + (float)l[0]; vv[1] += (float)h[1] + (float)l[1];
-                        vv[2] += (float)h[2] + (float)l[2]; vv[3] += (float)h[3] + (float)l[3];
-                    } else {
-                        vv[0] += __uint_as_float(rlo[ii][j].x); vv[1] += __uint_as_float(rlo[ii][j].y);
-                        vv[2] += __uint_as_float(rhi[ii][j].x); vv[3] += __uint_as_float(rhi[ii][j].y);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vv[e] = sigm ? act_fn(vv[e], a.act, a.alpha) : ape::act_fast(vv[e], af);
-                if (ABL(256)) continue;              // (timing only: no stores)
-                if (a.out_fmt == APE_FMT_S32) {
-                    const int cy = a.yoff + n;
-                    char* yp = a.y + (size_t)m * a.ldy * 4 + (cy >> 5) * 128 + (cy & 31) * 2;
-                    bf16x4 h, l;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
-                    *reinterpret_cast<bf16x4*>(yp) = h;
-                    *reinterpret_cast<bf16x4*>(yp + 64) = l;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                }
-            }
-        }
-    }
+    gemm_s32_epilogue<BN, RES>(a, acc, m0, m_end, n0, wm, wn, lane);
     if (RES || !has_next) break;
     // ---- on to the next tile: its first k-tiles are in flight or landed ----
     logical += G;
@@ -510,34 +527,293 @@ __device__ __forceinline__ void gemm_s32_body(const GemmS32Args& a)
 #endif
 }
 
-template <int BN>
-__global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
+
+// ---- PP ("ping-pong", round 6; cf. conv3x3_halo_s32.hip): the two waves of a SIMD (wave w and w + 4) run a k-tile's matrix segment C (all of
+// its MFMAs from ONE fragment set) and its load segment L (the fragment reads of the next k-tile, the DMA pieces) in OPPOSITE order, with one
+// barrier per k-tile and wave: waves 0-3 close their interval behind L (C(t) L(t+1) |), waves 4-7 behind C (L(t) C(t) |).  PMC of the lockstep
+// form: matrix pipe 0.58 busy.
+// LDS protocol (interval X = what lies between the barriers X-1 and X; stream k-tile X is multiplied in interval X): k-tile X's fragments are
+// read by waves 0-3 at the END of interval X-1 and by waves 4-7 at the START of interval X.  ALL pieces are issued by waves 4-7, at the start
+// of an interval (behind a barrier), and retired by their vmcnt(0) at its end (in front of the next barrier, which publishes them):
+//   * the pixel rows of a tile split by reader: rows 0..127 (H_A) are read by waves 0-3 only, rows 128..255 (H_B) by waves 4-7 only.  At the
+//     start of interval X:  H_A(X+2) -> ring slot X & 1 (k-tile X's H_A was read before barrier X-1; first read at the end of interval
+//     X+1, behind barrier X);  H_B(X+1) -> slot (X+1) & 1 (k-tile X-1's H_B was read at the start of interval X-1; first read at the start of
+//     interval X+1).  TWO slots of 32 KB do for the pixels, where the lockstep form needs three;
+//   * the weights are read by every wave: W(X+2) -> slot (X+2) % 3 = the slot of k-tile X-1 (last read at the start of interval X-1); first
+//     read at the end of interval X+1.  Three slots.   2 x 32 KB + 3 x BN x 128 B = 160 KB at BN = 256.
+// Same products, same order per accumulator as the lockstep form: bit-identical outputs.
+template <int BN, bool RES>
+__device__ __forceinline__ void gemm_s32_pp_body(const GemmS32Args& a)
 {
-    gemm_s32_body<BN, false>(a);
-}
-template <int BN>
-__global__ __launch_bounds__(512, 2) void gemm_s32_res_kernel(const GemmS32Args a)
-{
-    gemm_s32_body<BN, true>(a);
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TN = BN / 64;                  // 16-channel blocks per wave
+    constexpr int B_STAGE = BN * 128;
+    constexpr int B_BASE = 2 * A_STAGE;
+    constexpr int NBP = BN / 32;                 // weight pieces (8 rows) per issuing wave and k-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nwg = a.m_tiles * a.n_tiles;
+    const int G = gridDim.x;
+    const int orig = blockIdx.x;
+    const int xcd = orig % 8, q = G / 8, r = G % 8;
+    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool group_b = wave >= 4;
+    const int gi = wave & 3;                     // issuing index among waves 4-7
+    const int nk = a.nk;
+
+    auto tile_rows = [&](int mt, int& m0_, int& mend_, int& img_) {
+        if (a.img_tiles > 0) {
+            img_ = mt / a.img_tiles;
+            m0_ = img_ * a.rows_per_image + (mt - img_ * a.img_tiles) * BM;
+            mend_ = (img_ + 1) * a.rows_per_image;
+        } else {
+            img_ = 0;
+            m0_ = mt * BM;
+            mend_ = a.M;
+        }
+    };
+    auto make_rs_a = [&](int m0_, int mend_) {
+        const long a_bytes = ((long)(mend_ - m0_) * a.ldx - a.xoff) * 4;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((long)m0_ * a.ldx + a.xoff) * 4), 0,
+                                                 (int)(a_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)a_bytes), 0x00020000);
+    };
+    auto make_rs_b = [&](int n0_, int img_) {
+        const long b_bytes = (long)(a.Cout - n0_) * a.K * 4;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long)img_ * a.w_img_stride + (long)n0_ * a.K * 4), 0,
+                                                 (int)(b_bytes > 0xFFFFFFFFL ? 0xFFFFFFFFu : (unsigned)b_bytes), 0x00020000);
+    };
+    int m0, m_end, img, n0 = (logical % a.n_tiles) * BN;
+    tile_rows(logical / a.n_tiles, m0, m_end, img);
+    __amdgpu_buffer_rsrc_t rs_a = make_rs_a(m0, m_end), rs_b = make_rs_b(n0, img);
+    __amdgpu_buffer_rsrc_t rs_a_n = rs_a, rs_b_n = rs_b;      // the NEXT tile's descriptors (valid while has_next)
+    bool has_next = false;
+    auto next_tile_descriptors = [&]() {
+        has_next = !RES && logical + G < nwg;
+        if (has_next) {
+            const int nl = logical + G;
+            int nm0, nmend, nimg;
+            tile_rows(nl / a.n_tiles, nm0, nmend, nimg);
+            rs_a_n = make_rs_a(nm0, nmend);
+            rs_b_n = make_rs_b((nl % a.n_tiles) * BN, nimg);
+        }
+    };
+    next_tile_descriptors();
+
+    // ---- DMA (waves 4-7): a piece = 8 rows x 128 B; lanes 8 r .. 8 r + 7 fetch ONE row, its 16-B chunks permuted by the row's XOR swizzle
+    // ((row >> 1) & 7).  Wave gi owns the pieces gi * 4 + i (i = 0..3) of a pixel half and gi * NBP + i of the weights; a piece's 8-row offset
+    // goes through the instruction's SCALAR offset (it is part of the range check on gfx950: tools/attic/probes/soffset_range_probe.hip), so two
+    // lane offsets per operand (the swizzle depends on the piece's parity) serve all pieces.
+    unsigned va_par[2], vb_par[2];
+    auto setup_dma_lane = [&](int ln) {
+        const int r8 = ln >> 3, c8 = ln & 7;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int sw = (4 * p + (r8 >> 1)) & 7;
+            va_par[p] = (unsigned)((gi * 32 + r8) * a.ldx * 4 + ((c8 ^ sw) * 16));
+            vb_par[p] = (unsigned)((gi * NBP * 8 + r8) * a.K * 4 + ((c8 ^ sw) * 16));
+        }
+    };
+    setup_dma_lane(lane);
+    const unsigned a_row8 = (unsigned)(8 * a.ldx * 4), b_row8 = (unsigned)(8 * a.K * 4);
+    // stream k-tile `idx` counted from this tile's k-tile 0 (idx >= nk: the next tile's idx - nk)
+    auto dma_half = [&](int idx, int slot, int half) {      // pixel rows half * 128 + [0, 128) into A ring slot `slot`
+        const bool nxt = idx >= nk;
+        if (nxt && !has_next) return;
+        const __amdgpu_buffer_rsrc_t rs = nxt ? rs_a_n : rs_a;
+        const unsigned so = (unsigned)((nxt ? idx - nk : idx) * 128) + (unsigned)half * 16u * a_row8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + slot * A_STAGE + (half * 16 + gi * 4 + i) * 1024), 16, va_par[i & 1],
+                                                     so + (unsigned)i * a_row8, 0, 0);
+    };
+    auto dma_w = [&](int idx, int slot) {
+        const bool nxt = idx >= nk;
+        if (nxt && !has_next) return;
+        const __amdgpu_buffer_rsrc_t rs = nxt ? rs_b_n : rs_b;
+        const unsigned so = (unsigned)((nxt ? idx - nk : idx) * 128);
+#pragma unroll
+        for (int i = 0; i < NBP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + B_BASE + slot * B_STAGE + (gi * NBP + i) * 1024), 16, vb_par[i & 1],
+                                                     so + (unsigned)i * b_row8, 0, 0);
+    };
+
+    // ---- fragment addresses (cf. the lockstep form) ----------------------------------------------------------------------------------------
+    unsigned a_lane[2], b_lane[2];
+    auto setup_frag_lane = [&](int ln) {
+        const int frow = ln & 15, fc = ln >> 4;
+        const int swz = (frow >> 1) & 7;
+        const int lane_hi = frow * 128 + ((fc ^ swz) * 16), lane_lo = frow * 128 + (((4 + fc) ^ swz) * 16);
+        a_lane[0] = (unsigned)(wm * 16 * 1024 + lane_hi);
+        a_lane[1] = (unsigned)(wm * 16 * 1024 + lane_lo);
+        b_lane[0] = (unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_hi);
+        b_lane[1] = (unsigned)(B_BASE + wn * (TN * 2) * 1024 + lane_lo);
+    };
+    setup_frag_lane(lane);
+    u32x4 Af[8][2], Bfr[TN][2];
+    auto read_all = [&](int sa, int sb) {
+        const unsigned ao = (unsigned)(sa * A_STAGE), bo = (unsigned)(sb * B_STAGE);
+        ds_read_blocks<TN>(Bfr, b_lane[0] + bo, b_lane[1] + bo);
+        ds_read_blocks<8>(Af, a_lane[0] + ao, a_lane[1] + ao);
+    };
+    auto keep_all = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep_regs(Af[i][0], Af[i][1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) keep_regs(Bfr[j][0], Bfr[j][1]);
+    };
+    f32x4 acc[8][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    };
+    zero_acc();
+    auto mfma_all = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4& c = acc[i][j];
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, Bfr[j][0]), bl = __builtin_bit_cast(bf16x8, Bfr[j][1]);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, Af[i][0]), al = __builtin_bit_cast(bf16x8, Af[i][1]);
+                // weights as the row operand: D[channel 4 fc + e][pixel frow]; same products and k order as conv_gemm.hip
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, c, 0, 0, 0);
+            }
+    };
+    auto phase_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the duties at the start of interval X (waves 4-7): `kt` = X counted from the current tile's k-tile 0; sa / sb = the ring slots of k-tile X
+    auto duties = [&](int x, int sa, int sb) {
+        dma_half(x + 1, sa ^ 1, 1);                      // H_B(X+1)
+        dma_half(x + 2, sa, 0);                          // H_A(X+2)
+        dma_w(x + 2, sb == 0 ? 2 : sb - 1);              // W(X+2) -> slot (X+2) % 3 = (X-1) % 3
+    };
+
+    // ---- prologue: k-tile 0 whole, H_A and the weights of k-tile 1; then every wave reads k-tile 0's fragments ---------------------------------
+    if (group_b) {
+        dma_half(0, 0, 0);
+        dma_half(0, 0, 1);
+        dma_w(0, 0);
+        dma_half(1, 1, 0);
+        dma_w(1, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int sa = 0, sb = 0;                                  // ring slots of the k-tile whose fragments are in the registers
+    read_all(0, 0);
+    phase_end();
+    keep_all();
+    __builtin_amdgcn_s_barrier();                        // (waves 0-3 have read k-tile 0's H_A: its slot may take H_A(2))
+    if (group_b) duties(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One flat loop over the stream of k-tiles.  A tile's epilogue sits BETWEEN its last matrix segment and whatever follows it (waves 4-7: their
+    // barrier; waves 0-3: the reads of the next tile's first k-tile): the fragment registers are dead there, so the accumulators' 128 and
+    // the epilogue's own do not meet the 96 of a fragment set (with the epilogue behind L: 28 spilled registers at BN = 256).
+    int kt = 0;
+    bool done = false;
+#pragma unroll 1
+    for (;;) {
+        // C(kt)
+        mfma_all();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt == nk - 1) {
+            // (RES, one tile per workgroup: its epilogue -- 64 more registers for the residual tile -- runs behind the loop, where nothing
+            // of the loop is live any more)
+            if constexpr (!RES) gemm_s32_epilogue<BN, RES>(a, acc, m0, m_end, n0, wm, wn, lane);
+            if (RES || !has_next) {
+                done = true;
+            } else {        // on to the next tile: the stream simply continues (its first k-tiles are in flight or landed)
+                logical += G;
+                tile_rows(logical / a.n_tiles, m0, m_end, img);
+                n0 = (logical % a.n_tiles) * BN;
+                rs_a = rs_a_n;
+                rs_b = rs_b_n;
+                next_tile_descriptors();
+                zero_acc();
+                kt = -1;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (group_b) {          // waves 4-7 close their interval here: what they issued at its start has landed, the barrier publishes it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (done) break;
+        // L(kt + 1): the next k-tile of the stream
+        ++kt;
+        sa ^= 1;
+        sb = sb == 2 ? 0 : sb + 1;
+        read_all(sa, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (group_b) duties(kt, sa, sb);
+        phase_end();
+        keep_all();
+        if (!group_b) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!group_b) {             // (waves 0-3 close the interval in which waves 4-7 multiplied their last k-tile)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (RES) gemm_s32_epilogue<BN, RES>(a, acc, m0, m_end, n0, wm, wn, lane);
+#endif
 }
 
-template <int BN, bool RES>
-int launch_s32_res(GemmS32Args& a, hipStream_t st)
+// PP: the ping-pong schedule (gemm_s32_pp_body, round 6) / the lockstep schedule of rounds 3-5, which stays the product: same-process A/B over
+// the ten 1x1 shapes of the step (tools/mb_gemm_pp.py), bit-identical outputs, PP 8.6 % SLOWER (up_1 mix 3.91 vs 3.67 ms).  Unlike halo_s32
+// (24 KB per tap and CU), this kernel moves 64 KB per k-tile and CU from L2, and the LDS budget forces ALL of it onto waves 4-7 at the start
+// of their interval (a piece issued by waves 0-3 would need a fourth ring slot): 16 pieces per wave in one burst in front of their own MFMAs,
+// where the lockstep form spreads 8 per wave between its MFMA rows.  ape_conv_gemm_s32_debug bit 8192 launches the PP kernels (A/B, bitwise test).
+template <int BN, bool PP>
+__global__ __launch_bounds__(512, 2) void gemm_s32_kernel(const GemmS32Args a)
 {
-    constexpr size_t lds = 3 * (size_t)A_STAGE + 2 * (size_t)BN * 128;
-    auto kern = RES ? gemm_s32_res_kernel<BN> : gemm_s32_kernel<BN>;
+    if constexpr (PP) gemm_s32_pp_body<BN, false>(a); else gemm_s32_body<BN, false>(a);
+}
+template <int BN, bool PP>
+__global__ __launch_bounds__(512, 2) void gemm_s32_res_kernel(const GemmS32Args a)
+{
+    if constexpr (PP) gemm_s32_pp_body<BN, true>(a); else gemm_s32_body<BN, true>(a);
+}
+
+template <int BN, bool RES, bool PP>
+int launch_s32_form(GemmS32Args& a, hipStream_t st)
+{
+    // lockstep: three pixel slots + two weight slots; ping-pong: two + three
+    constexpr size_t lds = PP ? 2 * (size_t)A_STAGE + 3 * (size_t)BN * 128 : 3 * (size_t)A_STAGE + 2 * (size_t)BN * 128;
+    auto kern = RES ? gemm_s32_res_kernel<BN, PP> : gemm_s32_kernel<BN, PP>;
     static ape::DeviceOnce once;       // (one per instantiation of this function, i.e. per kernel)
     int ncu_dev = 0;
     if (int rc = ape::device_once(once, reinterpret_cast<const void*>(kern), (int)lds, &ncu_dev)) return rc;
     a.m_tiles = a.img_tiles > 0 ? (a.M / a.rows_per_image) * a.img_tiles : ape::ceil_div(a.M, BM);
     a.n_tiles = ape::ceil_div(a.Cout, BN);
-    // persistent walk (one workgroup per CU) where the k-tile stream can run through the tile boundary: an even number of k-tiles (the
-    // weight stage parity repeats) and at least four (the look-ahead of three stays inside one tile); dbg bit 64: one tile per workgroup
+    // persistent walk (one workgroup per CU) where the k-tile stream can run through the tile boundary: at least four k-tiles (the look-ahead
+    // of three stays inside one tile) and, in the lockstep form, an even number of them (its weight stage parity repeats); dbg bit 64: one
+    // tile per workgroup
     const int ncu = ncu_dev > 8 ? ncu_dev / 8 * 8 : 8;
     const int tiles = a.m_tiles * a.n_tiles;
-    const bool walk = !RES && !(a.dbg & 64) && a.nk >= 4 && a.nk % 2 == 0 && tiles > ncu;
+    const bool walk = !RES && !(a.dbg & 64) && a.nk >= 4 && (PP || a.nk % 2 == 0) && tiles > ncu;
     hipLaunchKernelGGL(kern, dim3(walk ? ncu : tiles), dim3(512), lds, st, a);
     return ape::check_launch("ape_conv_gemm_s32");
+}
+
+template <int BN, bool RES>
+int launch_s32_res(GemmS32Args& a, hipStream_t st)
+{
+    return (a.dbg & 8192) ? launch_s32_form<BN, RES, true>(a, st) : launch_s32_form<BN, RES, false>(a, st);
 }
 
 template <int BN>

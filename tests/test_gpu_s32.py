@@ -151,6 +151,31 @@ def test_halo_s32_ping_pong_equals_the_lockstep_schedule_bitwise(shape):
         lib.ape_conv3x3_halo_s32_debug(0)
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (3, 19, 23, 96, 160), (8, 60, 80, 128, 256), (64, 60, 80, 256, 512), (4, 120, 160, 256, 576), (2, 1000, 1, 384, 1920)])
+def test_gemm_s32_ping_pong_form_equals_the_lockstep_form_bitwise(shape):
+    """gemm_s32's ping-pong schedule (round 6, ape_conv_gemm_s32_debug bit 8192; the lockstep form stays the product: tools/mb_gemm_pp.py) --
+    opposite segment order on the two waves of a SIMD, every DMA piece from waves 4-7, two pixel slots + three weight slots -- gives the
+    lockstep form's bits: one-tile and walking workgroups, odd k-tile counts, ragged row and channel tiles, all three channel-tile widths,
+    with and without a residual, repeated"""
+    from autoposeestimation_amd import _lib
+    from autoposeestimation_amd import engine as E
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(cin + cout + b)
+    xs = E.S32.from_f32((torch.randn(b, h, w, cin, generator=g) * 2).cuda())
+    conv = E.Conv(torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g), act=E.ACT_PRELU, alpha=0.25, device="cuda", precision="bf16x3")
+    res = torch.randn(b, h, w, cout, generator=g).cuda()
+    lib = _lib.lib()
+    try:
+        want = [conv(xs).clone(), conv(xs, residual=res, out_fmt=E.FMT_S32).t.clone()]
+        lib.ape_conv_gemm_s32_debug(8192)
+        for rep in range(3):
+            got = [conv(xs), conv(xs, residual=res, out_fmt=E.FMT_S32).t]
+            for k, (gt, wt) in enumerate(zip(got, want)):
+                assert torch.equal(gt.view(torch.int32), wt.view(torch.int32)), (shape, rep, k)
+    finally:
+        lib.ape_conv_gemm_s32_debug(0)
+
+
 def test_s32_path_rejects_what_it_cannot_run():
     from autoposeestimation_amd import engine as E
     x = E.S32(torch.zeros(1, 8, 8, 64, device="cuda"))

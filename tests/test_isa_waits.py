@@ -24,9 +24,8 @@ KERNELS = {
                              for d in (1, 2, 4) for pp in (1, 0)],
     "conv3x3_halo_mx.hip": [("halo_mx_kernelILi1E", "halo_mx_kernel<1>", True), ("halo_mx_kernelILi2E", "halo_mx_kernel<2>", True),
                             ("halo_mx_kernelILi4E", "halo_mx_kernel<4>", True)],
-    "conv_gemm_s32.hip": [("gemm_s32_kernelILi128E", "gemm_s32_kernel<128>", True), ("gemm_s32_kernelILi192E", "gemm_s32_kernel<192>", True),
-                          ("gemm_s32_kernelILi256E", "gemm_s32_kernel<256>", True), ("gemm_s32_res_kernelILi128E", "gemm_s32_res_kernel<128>", True),
-                          ("gemm_s32_res_kernelILi192E", "gemm_s32_res_kernel<192>", True), ("gemm_s32_res_kernelILi256E", "gemm_s32_res_kernel<256>", True)],
+    "conv_gemm_s32.hip": [("gemm_s32%s_kernelILi%dELb%dE" % (res, bn, pp), "gemm_s32%s_kernel<%d, %s>" % (res, bn, "true" if pp else "false"), True)
+                          for res in ("", "_res") for bn in (128, 192, 256) for pp in (1, 0)],
     "conv3x3_halo.hip": [("conv3x3_halo_kernelILi3ELi1ELi64ELb1ELb1E", "conv3x3_halo_kernel<3,1,64,true,true>", False),
                          ("conv3x3_halo_kernelILi3ELi1ELi64ELb0ELb0E", "conv3x3_halo_kernel<3,1,64,false,false>", False)],
 }
@@ -49,7 +48,7 @@ def test_wait_counters_and_spills(audit_mod, hip_file, tmp_path_factory):
         sym = [s for s in symbols if key in s]
         assert len(sym) == 1, (name, sym)
         # (halo_s32's ping-pong form retires a piece in front of the SECOND barrier after its issue: tools/isa_audit.py, dma_barrier_slack)
-        r = audit_mod.audit(asm, sym[0], dma_barrier_slack=1 if (hip_file == "conv3x3_halo_s32.hip" and "true" in name) else 0)
+        r = audit_mod.audit(asm, sym[0], dma_barrier_slack=1 if (hip_file in ("conv3x3_halo_s32.hip", "conv_gemm_s32.hip") and "true" in name) else 0)
         assert r["n_mfma"] >= 100 and r["n_dsread"] >= 60, (name, r["n_mfma"], r["n_dsread"])       # the walk saw the real kernel
         assert (r["n_dma"] > 0) == has_dma, (name, r["n_dma"])
         assert not r["findings"], "%s:\n  %s" % (name, "\n  ".join(r["findings"]))

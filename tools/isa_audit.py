@@ -534,7 +534,7 @@ if __name__ == "__main__":
     for sym in kernel_symbols(asm):
         if pats and not any(p in sym for p in pats):
             continue
-        r = audit(asm, sym, dma_barrier_slack=1 if ("halo_s32_kernel" in sym and "Lb1E" in sym) else 0)
+        r = audit(asm, sym, dma_barrier_slack=1 if (("halo_s32_kernel" in sym or "gemm_s32_" in sym) and "Lb1E" in sym) else 0)
         print(sym)
         print("   %d instructions, %d MFMA, %d ds_read, %d LDS-DMA; vmcnt literals %s; %s" %
               (r["n_insns"], r["n_mfma"], r["n_dsread"], r["n_dma"], r["vmcnt_literals"], r["meta"]))
