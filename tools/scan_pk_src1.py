@@ -45,13 +45,20 @@ def code_objects(path, tmp):
                 if j < 0:
                     break
                 ne = struct.unpack_from("<Q", m, j + 24)[0]
-                q, end = j + 32, j + 32
-                for _ in range(ne):
+                q, end, ok = j + 32, j + 32, 0 < ne <= 64
+                for _ in range(ne if ok else 0):
+                    if q + 24 > len(m):
+                        ok = False
+                        break
                     o, s, ts = struct.unpack_from("<QQQ", m, q)
+                    if ts > 256 or j + o + s > len(m):          # (the magic string inside some other data, e.g. the bundler's own code)
+                        ok = False
+                        break
                     end = max(end, j + o + s)
                     q += 24 + ts
-                blobs.append((j, end - j))
-                pos = max(end, j + 24)
+                if ok:
+                    blobs.append((j, end - j))
+                pos = max(end, j + 24) if ok else j + 24
         else:
             blobs.append((0, len(m)))
         out = []
