@@ -11,17 +11,17 @@ O=gpurun_out/$R
 mkdir -p $O
 T="timeout -k 10 280"
 # 1. single stream under the kernel trace: per-kernel stats, timed region, one step's launch list
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_no -- python3 bench.py --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-overlap --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg > $O/prof_no.log 2>&1 || exit 1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_no -- python3 bench.py --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-overlap --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg --no-step-check > $O/prof_no.log 2>&1 || exit 1
 cp $O/prof_no/*/*_kernel_stats.csv $O/${R}_bf16x3_kernel_stats.csv
 python tools/prof_summary.py $O/prof_no/*/*_kernel_trace.csv --steps $PSTEPS --warmup 2 > $O/${R}_bf16x3_timed_region.json || exit 1
 python tools/prof_step_list.py $O/prof_no/*/*_kernel_trace.csv > $O/${R}_step_launch_list.txt || exit 1
 # 2. the DEFAULT command (software-pipelined loop) under the kernel trace
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_def -- python3 bench.py --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg > $O/prof_def.log 2>&1 || exit 1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_def -- python3 bench.py --steps $PSTEPS --warmup 1 --no-cpu-baseline --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg --no-step-check > $O/prof_def.log 2>&1 || exit 1
 cp $O/prof_def/*/*_kernel_stats.csv $O/${R}_default_overlap_kernel_stats.csv
 python tools/prof_summary.py $O/prof_def/*/*_kernel_trace.csv --steps $PSTEPS --warmup 2 --tail-steps 3 > $O/${R}_default_overlap_timed_region.json || exit 1
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, split per layer shape
-$T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg --dump-launches $O/launches.json > $O/pmc_fetch.log 2>&1 || exit 1
-$T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg > $O/pmc_write.log 2>&1 || exit 1
+$T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg --no-step-check --dump-launches $O/launches.json > $O/pmc_fetch.log 2>&1 || exit 1
+$T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-overlap --no-modes --no-staged --no-sweep --no-latency --no-pose-leg --no-label-leg --no-step-check > $O/pmc_write.log 2>&1 || exit 1
 python tools/pmc_summary.py $O/pmc_fetch/*/*_counter_collection.csv $O/pmc_write/*/*_counter_collection.csv --shapes $O/launches.json > $O/${R}_pmc_traffic.json || exit 1
 cp $O/${R}_pmc_traffic.json profiles/      # (this box's copy of the tree: step 6's bench line reads its `traffic` fields from the newest profiles/*_pmc_traffic.json)
 # 4. matrix-pipe / vector / LDS counters of the largest kernels
