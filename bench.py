@@ -413,26 +413,35 @@ def latency_leg(args, device, seg, est, ref, frame, runs):
     detections, crop, PoseNet, 2 x refiner, pose D2H: ~140 dependent launches on one stream).  p50 / p99 / min over `runs` runs
     behind 10 warm-up runs.  Rank 0 only (a latency, not a throughput: it does not aggregate over ranks)."""
     from autoposeestimation_amd.pipeline.utils import FramePipeline
-    pipe = FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False)
     rgb = torch.from_numpy(frame[0][None]).to(device)
     depth = torch.from_numpy(frame[1][None]).to(device)
-    for i in range(10):
-        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
-        out["pose"].cpu()
-    torch.cuda.synchronize()
-    ts = []
-    for i in range(runs):
-        t0 = time.perf_counter()
-        out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
-        out["pose"].cpu()
-        ts.append(time.perf_counter() - t0)
-    ts = np.sort(np.asarray(ts)) * 1e3
-    pick = lambda q: float(ts[min(len(ts) - 1, int(np.ceil(q * len(ts))) - 1)])  # noqa: E731
-    return {"p50_ms": round(pick(0.50), 3), "p99_ms": round(pick(0.99), 3), "min_ms": round(float(ts[0]), 3), "mean_ms": round(float(ts.mean()), 3),
-            "runs": int(len(ts)), "objects": len(out["objects"]), "frames": 1,
+    pick = lambda ts, q: float(ts[min(len(ts) - 1, int(np.ceil(q * len(ts))) - 1)])  # noqa: E731
+
+    def measure(pipe):
+        for i in range(10):
+            out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+            out["pose"].cpu()
+        torch.cuda.synchronize()
+        ts = []
+        for i in range(runs):
+            t0 = time.perf_counter()
+            out = pipe.run(rgb, depth, S.REALSENSE_META, seed=i)
+            pose = out["pose"].cpu()
+            ts.append(time.perf_counter() - t0)
+        return np.sort(np.asarray(ts)) * 1e3, out, pose
+
+    # the pose stage's ~60 launches can only be enqueued once the detections are on the host; with pose_graphs the crop-size bucket is ONE
+    # replayed HIP graph (the same kernels in the same order: bit-identical poses, checked on the last run).  Measured round 6: p50 3.97 ms
+    # against 3.95 eager -- the host cost is not what the frame waits for; both are reported
+    te, out_e, pose_e = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False))
+    ts, out, pose_g = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False, pose_graphs=True))
+    return {"p50_ms": round(pick(te, 0.50), 3), "p99_ms": round(pick(te, 0.99), 3), "min_ms": round(float(te[0]), 3), "mean_ms": round(float(te.mean()), 3),
+            "pose_graph_p50_ms": round(pick(ts, 0.50), 3), "pose_graph_min_ms": round(float(ts[0]), 3), "graph_equals_eager_bitwise": bool(torch.equal(pose_e, pose_g)),
+            "runs": int(len(te)), "objects": len(out_e["objects"]), "frames": 1,
             "note": "one resident 640x480 frame, one object, batch 1, one stream, eager launches; host wall clock from FramePipeline.run() to the pose "
-                    "on the host (includes the detections' D2H sync in the middle and the pose D2H at the end); after the timed region, never part "
-                    "of `value`"}
+                    "on the host (includes the detections' D2H sync in the middle and the pose D2H at the end); pose_graph_*: the same with the pose "
+                    "stage as ONE replayed HIP graph (FramePipeline(pose_graphs=True)) -- no faster: the frame is its ~140 dependent small kernels, "
+                    "not their host cost; after the timed region, never part of `value`"}
 
 
 def kernel_peak(label):
