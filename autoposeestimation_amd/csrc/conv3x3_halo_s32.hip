@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     auto mfma_all = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i >= rpw || ABL(1024)) continue;             // (a ragged tile: rows past rpw do not exist)
+            if (i >= rpw || ABL(1024) || (ABL(32) && i >= 2)) continue;             // (a ragged tile: rows past rpw do not exist; ABL 32: half the MFMAs)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[j][0]), bl = __builtin_bit_cast(bf16x8, Bs[j][1]);

@@ -174,7 +174,7 @@ def test_bench_under_torch_distributed_run_exercises_rccl():
 
 
 @pytest.mark.parametrize("flags", [("--steps", "2", "--warmup", "1"), ("--frames", "256", "--steps", "1", "--warmup", "1"),
-                                   ("--workload", "label", "--steps", "1", "--warmup", "1")])
+                                   ("--workload", "label", "--steps", "1", "--warmup", "1"), ("--workload", "pose", "--steps", "2", "--warmup", "1")])
 def test_two_rank_rehearsal_on_one_gpu(flags):
     """The driver's N = 2 launch line with both ranks on the one GPU of the box (APE_DIST_BACKEND=gloo: RCCL needs a GPU per rank):
     rank-dependent frames / view shards, the collectives of every step, max-over-ranks timing, rank 0's single line."""
@@ -188,10 +188,14 @@ def test_two_rank_rehearsal_on_one_gpu(flags):
     assert len(lines) == 1                              # rank 0 alone prints
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0
-    if "--workload" in flags:
+    if "pose" in flags:         # (rank 0's profiled extra step must not call the collective: it hung N > 1 before round 6)
+        assert d["unit"] == "crops/s" and d["scaling"] == "weak" and "dp2" in d["config"]["parallelism"]
+    elif "--workload" in flags:
         assert d["unit"] == "views/s" and "2 ranks" in d["config"]["parallelism"]
     elif "--frames" in flags:
         assert d["scaling"] == "strong" and d["config"]["frames_per_gpu_per_step"] == 128
     else:
         assert d["scaling"] == "weak" and d["config"]["frames_per_gpu_per_step"] == 64 and d["config"]["objects_found_last_step"] == 64
         assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2e-3)) < 0.02 * d["value"]
+        # every rank re-ran its timed steps on one stream and compared; the compact configs[1] / configs[4] legs ran on both ranks
+        assert d["parity"]["steps_bitwise_equal"] == "2/2" and d["pose"]["n_gpus"] == 2 and d["label"]["n_gpus"] == 2 and list(d)[-1] == "secondary"

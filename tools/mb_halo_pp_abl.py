@@ -25,7 +25,7 @@ def run():
                                                E.FMT_S32, ctypes.byref(p), None), "s32")
 for bits, name in ((0, "pp as built"), (4096, "old schedule"), (64, "no fragment-read waits"), (256, "no DMA wait"), (512, "no in-loop DMA"), (2048, "no fragment reads"),
                    (2048 | 512, "no reads, no DMA (C + bookkeeping + barriers)"), (1024, "no MFMAs"), (1024 | 512, "no MFMAs, no DMA"), (1024 | 2048, "no MFMAs, no reads"),
-                   (1024 | 2048 | 512, "bookkeeping + waits + barriers only"), (128, "no barriers (races; timing only)"), (4, "no stores"), (0, "pp as built again")):
+                   (1024 | 2048 | 512, "bookkeeping + waits + barriers only"), (128, "no barriers (races; timing only)"), (32, "half the MFMAs (rows 0, 1 only)"), (32 | 512, "half the MFMAs, no DMA"), (4, "no stores"), (0, "pp as built again")):
     _lib.lib().ape_conv3x3_halo_s32_debug(bits)
     print("%-50s %.3f ms" % (name, t(run)), flush=True)
 _lib.lib().ape_conv3x3_halo_s32_debug(0)
