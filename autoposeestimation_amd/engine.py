@@ -378,11 +378,11 @@ def _conv_call_s32(self, x, out, xoff, yoff, residual, roff, bias, bias_bstride,
     if is3:
         if not _lib.lib().ape_conv3x3_halo_s32_supported(ctypes.byref(p)):
             raise ValueError("no S32 kernel for this layer geometry (3x3, stride %d, dil %d, Cin %d, Cout %d)" % (self.stride, self.dil, self.cin, self.cout))
-        label = "halo_s32_kernel<%d>" % self.dil
+        label = "halo_s32_kernel<%d, true>" % self.dil          # (the kernel's name in a rocprofv3 trace: <dilation, ping-pong schedule>)
     else:
         if not _lib.lib().ape_conv_gemm_s32_supported(ctypes.byref(p)):
             raise ValueError("no S32 kernel for this layer geometry (%dx%d, stride %d, Cin %d, Cout %d)" % (self.kh, self.kw, self.stride, self.cin, self.cout))
-        label = ("gemm_s32_res_kernel<%d>" if res_t is not None else "gemm_s32_kernel<%d>") % (128 if self.cout <= 128 else 192 if (-(-self.cout // 192) * 192 - self.cout) < (-(-self.cout // 256) * 256 - self.cout) else 256)
+        label = ("gemm_s32_res_kernel<%d, false>" if res_t is not None else "gemm_s32_kernel<%d, false>") % (128 if self.cout <= 128 else 192 if (-(-self.cout // 192) * 192 - self.cout) < (-(-self.cout // 256) * 256 - self.cout) else 256)
     e0 = _prof_begin(label)
     fn = _lib.lib().ape_conv3x3_halo_s32 if is3 else _lib.lib().ape_conv_gemm_s32
     rc = fn(_lib.dptr(xt, torch.float32), _lib.dptr(self.s32k()), _lib.dptr(bias), _lib.dptr(res_t), res_fmt,
@@ -569,7 +569,7 @@ def psp_bottleneck_folded(conv, x576, zs, out_fmt=FMT_S32):
     out = torch.empty(b, h, w, conv.cout, dtype=torch.float32, device=xt.device)
     p = ConvParams(B=b, H=h, W=w, Cin=ld, ldx=ld, xoff=0, Ho=h, Wo=w, Cout=conv.cout, ldy=conv.cout, yoff=0, KH=1, KW=1, stride=1, pad=0, dil=1,
                    act=conv.act, alpha=conv.alpha, bias_bstride=0, ldr=0, roff=0, ups=0)
-    label = "gemm_s32_kernel<%d>" % (128 if conv.cout <= 128 else 192 if (-(-conv.cout // 192) * 192 - conv.cout) < (-(-conv.cout // 256) * 256 - conv.cout) else 256)
+    label = "gemm_s32_kernel<%d, false>" % (128 if conv.cout <= 128 else 192 if (-(-conv.cout // 192) * 192 - conv.cout) < (-(-conv.cout // 256) * 256 - conv.cout) else 256)
     e0 = _prof_begin(label)
     rc = _lib.lib().ape_conv_gemm_s32_per_image(_lib.dptr(xt, torch.float32), _lib.dptr(wimg), conv.cout * groups * 128, _lib.dptr(conv.bias),
                                                 _lib.dptr(out), out_fmt, ctypes.byref(p), _st())
