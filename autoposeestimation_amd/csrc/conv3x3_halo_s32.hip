@@ -35,6 +35,11 @@
 #define ABL(bit) 0
 #endif
 
+// S32 output: one 16-byte store per lane instead of two 8-byte ones (round 6, conv_gemm_s32.hip); APE_S32_WIDE_STORE=0 builds the two-store form
+#ifndef APE_S32_WIDE_STORE
+#define APE_S32_WIDE_STORE 1
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -562,6 +567,9 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
         }
         const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);        // (common.h: no scalar compare-and-branch cascade per element)
         const bool sigmoid = a.act == APE_ACT_SIGMOID;
+#if APE_S32_WIDE_STORE
+        const bool wide = a.Cout % 8 == 0 && a.yoff % 8 == 0;              // (a pair of lanes = two adjacent channel quads: both inside Cout or both outside)
+#endif
         auto store_tile = [&](auto s32_c) __attribute__((always_inline)) {
             constexpr bool OUT_S32 = decltype(s32_c)::value != 0;
 #pragma unroll
@@ -599,8 +607,21 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
                         bf16x4 h, l;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
-                        *reinterpret_cast<bf16x4*>(yp) = h;
-                        *reinterpret_cast<bf16x4*>(yp + 64) = l;
+#if APE_S32_WIDE_STORE
+                        if (wide) {
+                            // ONE 16-byte store per lane (cf. conv_gemm_s32.hip): the lanes fc and fc ^ 1 of a pixel hold adjacent channel quads;
+                            // after the swap of the odd 16-lane rows of `hi` with the even rows of `lo` an even-fc lane owns the hi halves of both
+                            // quads (16 contiguous bytes at its own hi address), the odd-fc lane both lo halves (at its own hi address - 8 + 64)
+                            uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
+                            const auto r0 = __builtin_amdgcn_permlane16_swap(hu.x, lu.x, false, false);
+                            const auto r1 = __builtin_amdgcn_permlane16_swap(hu.y, lu.y, false, false);
+                            *reinterpret_cast<uint4*>((fc_e & 1) ? yp + 56 : yp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                        } else
+#endif
+                        {
+                            *reinterpret_cast<bf16x4*>(yp) = h;
+                            *reinterpret_cast<bf16x4*>(yp + 64) = l;
+                        }
                     } else {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                     }

@@ -34,6 +34,12 @@
 #define ABL(bit) 0
 #endif
 
+// S32 output: one 16-byte store per lane and (pixel block, channel block) instead of two 8-byte ones (round 6; same bytes at the same addresses:
+// bit-identical tensors; up_2 mix -3.7 %, up_1 mix -1.8 %, tools/mb_gemm_s32.py).  APE_S32_WIDE_STORE=0 builds the two-store form.
+#ifndef APE_S32_WIDE_STORE
+#define APE_S32_WIDE_STORE 1
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -140,6 +146,9 @@ __device__ __forceinline__ void gemm_s32_epilogue(const GemmS32Args& a, f32x4 (&
     const int nq = n0 + wn * (TN * 16) + fc_e * 4;
     const ape::ActFast af = ape::act_fast_make(a.act, a.alpha);
     const bool sigm = a.act == APE_ACT_SIGMOID;
+#if APE_S32_WIDE_STORE
+    const bool wide = a.Cout % 8 == 0 && a.yoff % 8 == 0;          // (a pair of lanes = two adjacent channel quads: both inside Cout or both outside)
+#endif
     float4 b4[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -203,8 +212,22 @@ __device__ __forceinline__ void gemm_s32_epilogue(const GemmS32Args& a, f32x4 (&
                     bf16x4 h, l;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { h[e] = (__bf16)vv[e]; l[e] = (__bf16)(vv[e] - (float)h[e]); }
-                    *reinterpret_cast<bf16x4*>(yp) = h;
-                    *reinterpret_cast<bf16x4*>(yp + 64) = l;
+#if APE_S32_WIDE_STORE
+                    if (wide) {
+                        // ONE 16-byte store per lane instead of two 8-byte ones: the lanes fc and fc ^ 1 of a pixel (16 lanes apart) hold adjacent
+                        // channel quads; v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its
+                        // second, so with (hi, lo) an even-fc lane ends up with the hi halves of BOTH quads (16 contiguous bytes at its own hi
+                        // address) and the odd-fc lane with both lo halves (at the even lane's lo address = its own hi address - 8 + 64)
+                        uint2 hu = __builtin_bit_cast(uint2, h), lu = __builtin_bit_cast(uint2, l);
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(hu.x, lu.x, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(hu.y, lu.y, false, false);
+                        *reinterpret_cast<uint4*>((fc_e & 1) ? yp + 56 : yp) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    } else
+#endif
+                    {
+                        *reinterpret_cast<bf16x4*>(yp) = h;
+                        *reinterpret_cast<bf16x4*>(yp + 64) = l;
+                    }
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (size_t)m * a.ldy + a.yoff + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 }
