@@ -177,11 +177,21 @@ __global__ __launch_bounds__(512, 2) void halo_s32_kernel(const HaloS32Args a)
     const int grid = (int)gridDim.x;
     const int my_tiles = (nwg - 1 - (int)blockIdx.x) / grid + 1;
     int cur_b, cur_y0, cur_x0, n0;
+    // dbg bit 8 (experiment): ONE channel tile per XCD -- XCD x multiplies channel tile x % n_tiles for its share of the
+    // spatial tiles, so its 2.4 MB of weights stay in its L2 while every halo is fetched by n_tiles XCDs (results unchanged)
+    const bool xcd_ntile = (a.dbg & 8) && (8 % a.n_tiles) == 0 && ((a.B * tiles_per_img) % (8 / a.n_tiles)) == 0 && r == 0;
     auto decode = [&](int orig, int& tb, int& ty0, int& tx0, int& tn0) {
         const int xcd = orig % 8;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-        const int n_tile = logical % a.n_tiles;
-        const int mt = logical / a.n_tiles;
+        int n_tile, mt;
+        if (xcd_ntile) {
+            const int groups = 8 / a.n_tiles, per = a.B * tiles_per_img / groups;
+            n_tile = xcd % a.n_tiles;
+            mt = (xcd / a.n_tiles) * per + orig / 8;
+        } else {
+            const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+            n_tile = logical % a.n_tiles;
+            mt = logical / a.n_tiles;
+        }
         tb = mt / tiles_per_img;
         const int trem = mt - tb * tiles_per_img;
         ty0 = (trem / a.tiles_x) * TS;

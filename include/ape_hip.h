@@ -101,7 +101,7 @@ int ape_pack_weights_s32k(const float* w, void* out, int cout, int K, void* stre
 /* x[rows][C] f32 -> y[rows][C] S32 (to_s32 = 1) or back (to_s32 = 0: hi + lo); C % 32 == 0.  Tests and format boundaries only. */
 int ape_convert_s32(const void* x, void* y, long rows, int C, int to_s32, void* stream);
 int ape_conv_gemm_s32_supported(const ape_conv_params* params_host);
-int ape_conv3x3_halo_s32_debug(int bits);   /* development aid, results unchanged by any bit: 1 = a static wave priority for waves 4-7 (lockstep kernel); 2 = one workgroup per tile; 16 = four rows per wave-row group in every tile; 4096 = launch the lockstep (one-barrier, in-phase) kernel of rounds 2-5 instead of the ping-pong one (tools/mb_halo_pp.py, tests/test_gpu_s32.py) */
+int ape_conv3x3_halo_s32_debug(int bits);   /* development aid, results unchanged by any bit: 1 = a static wave priority for waves 4-7 (lockstep kernel); 2 = one workgroup per tile; 8 = one channel tile per XCD (weights L2-resident, halos fetched n_tiles times: DESIGN.md 6f); 16 = four rows per wave-row group in every tile; 4096 = launch the lockstep (one-barrier, in-phase) kernel of rounds 2-5 instead of the ping-pong one (tools/mb_halo_pp.py, tests/test_gpu_s32.py) */
 int ape_conv_gemm_s32_debug(int bits);   /* development aid: 16 / 32 / 64 / 8192 leave the results unchanged (k-tile rotation, no static priority, one tile per workgroup, 8192 = launch the ping-pong kernels: bit-identical, slower, tools/mb_gemm_pp.py); the ablation build (make ablations) also knows timing-only bits that break the results */
 int ape_conv_gemm_s32(const void* x_s32, const void* w_s32k, const float* bias, const void* residual, int res_fmt, void* y,
                       int out_fmt, const ape_conv_params* params_host, void* stream);

@@ -29,7 +29,7 @@ for name, b, h, w, cin, cout, dil in shapes:
             _lib.lib().ape_conv3x3_halo_s32_debug(0)
             return r
         return f
-    arms = {"pp": arm(0, "pp"), "old": arm(4096, "old"), "pp + s32 residual": arm(0, "ppr", residual=res32), "old + s32 residual": arm(4096, "oldr", residual=res32)}
+    arms = {"pp": arm(0, "pp"), "old": arm(4096, "old"), "pp, one channel tile per XCD": arm(8, "old"), "pp + s32 residual": arm(0, "ppr", residual=res32), "old + s32 residual": arm(4096, "oldr", residual=res32)}
     got = {k: f().to_f32().clone() for k, f in arms.items()}
     torch.cuda.synchronize()
     same = torch.equal(got["pp"], got["old"]) and torch.equal(got["pp + s32 residual"], got["old + s32 residual"])
