@@ -453,6 +453,7 @@ class PoseNet(_HipModule):
         pl.l3 = [E.Conv(sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"], act=E.ACT_RELU, device=dev, precision=pr) for h in "rtc"]
         pl.l4 = [t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).contiguous()
                  for h in "rtc" for t in (sd[f"conv4_{h}.weight"], sd[f"conv4_{h}.bias"])]
+        E.allow_splitk(pl)          # (batch-1 frames: the crop's small-M layers may split K; never the segmentor's)
         return pl
 
     def forward_batch(self, img4, points4, choose, obj, taps=None):
@@ -559,6 +560,7 @@ class PoseRefineNet(_HipModule):
         pl.l2 = [E.Conv(sd[f"conv2_{h}.weight"], sd[f"conv2_{h}.bias"], act=E.ACT_RELU, device=dev, precision=pr) for h in "rt"]
         pl.l3 = [t.detach().to(dev, torch.float32).contiguous()
                  for h in "rt" for t in (sd[f"conv3_{h}.weight"], sd[f"conv3_{h}.bias"])]
+        E.allow_splitk(pl)
         return pl
 
     def forward_batch(self, points4, emb, obj):

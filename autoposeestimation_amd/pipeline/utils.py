@@ -33,7 +33,7 @@ def _pose_stream():
 
 class FramePipeline:
     def __init__(self, segmentor, estimator, refiner, class_names, num_points=1000, refine_mode="live_compat",
-                 min_pixels=100, iterations=2, pose_stream=False, pose_graphs=False):
+                 min_pixels=100, iterations=2, pose_stream=False, pose_graphs=False, low_latency=False):
         if refine_mode not in ("live_compat", "iterative"):
             raise ValueError(refine_mode)
         self.segmentor, self.estimator, self.refiner = segmentor, estimator, refiner
@@ -64,6 +64,11 @@ class FramePipeline:
         self._graphs = {}
         self._seen = set()
         self._static_objmap = None
+        # low_latency: the pose networks' small-M layers (ONE crop: 4..16 output tiles per layer on a 256-CU chip) take the split-K form of
+        # ape_conv_gemm_bf16_splitk -- the batch-1 live loop (main.py:517-553, full_prediction): 3.9 -> 3.0 ms per frame.  Off by default:
+        # the split changes the fp32 summation order (poses move by <= 1e-5, still 10x inside the 1e-4 bar), and a batched run is held to
+        # 1e-6 against its frames run alone (tests/test_gpu_bench_parity.py); a batch that fills the chip never splits anyway
+        self.low_latency = bool(low_latency)
         self.host_poses_s = 0.0        # host time spent inside poses() (enqueue only: nothing in there waits for the GPU once the graphs exist)
 
     # -- stage 1: segmentation + components, all on device ---------------------------------------------------------
@@ -89,9 +94,11 @@ class FramePipeline:
         """objects: list of (frame, cls, rmin, rmax, cmin, cmax).  Returns (pose[n,7] f64 cuda, n_cand[n] i32 cuda,
         choose[n,N] i64 cuda) in the order of `objects`."""
         t_host = time.perf_counter()
+        prev, E.SPLITK_SMALL_M = E.SPLITK_SMALL_M, self.low_latency
         try:
             return self._poses(rgb, depth, objmap, objects, meta, choose_override, seed)
         finally:
+            E.SPLITK_SMALL_M = prev
             self.host_poses_s += time.perf_counter() - t_host
 
     def _poses(self, rgb, depth, objmap, objects, meta, choose_override, seed):
@@ -292,7 +299,7 @@ def full_prediction(image, depth, meta, segmentor, estimator, refiner, to_tensor
         depth_np = depth_np.astype(np.uint16)
     rgb = torch.from_numpy(rgb_np).to(device).unsqueeze(0)
     dep = torch.from_numpy(depth_np).to(device).unsqueeze(0)
-    pipe = FramePipeline(segmentor, estimator, refiner, class_names, refine_mode=refine_mode)
+    pipe = FramePipeline(segmentor, estimator, refiner, class_names, refine_mode=refine_mode, low_latency=True)       # (one frame per call: the live loop)
     objmap, det = pipe.segment(rgb)
     det_h = det.cpu().numpy()
     objmap_h = objmap[0].cpu().numpy()

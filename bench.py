@@ -433,13 +433,18 @@ def latency_leg(args, device, seg, est, ref, frame, runs):
     # the pose stage's ~60 launches can only be enqueued once the detections are on the host; with pose_graphs the crop-size bucket is ONE
     # replayed HIP graph (the same kernels in the same order: bit-identical poses, checked on the last run).  Measured round 6: p50 3.97 ms
     # against 3.95 eager -- the host cost is not what the frame waits for; both are reported
-    te, out_e, pose_e = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False))
-    ts, out, pose_g = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False, pose_graphs=True))
+    # low_latency=True: what full_prediction (the reference's live API, one frame per call) runs -- the crop's small-M layers split K
+    te, out_e, pose_e = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False, low_latency=True))
+    ts, out, pose_g = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False, pose_graphs=True,
+                                            low_latency=True))
+    tn, out_n, pose_n = measure(FramePipeline(seg, est, ref, CLASSES, num_points=N_POINTS, refine_mode="live_compat", pose_stream=False))
     return {"p50_ms": round(pick(te, 0.50), 3), "p99_ms": round(pick(te, 0.99), 3), "min_ms": round(float(te[0]), 3), "mean_ms": round(float(te.mean()), 3),
             "pose_graph_p50_ms": round(pick(ts, 0.50), 3), "pose_graph_min_ms": round(float(ts[0]), 3), "graph_equals_eager_bitwise": bool(torch.equal(pose_e, pose_g)),
+            "unsplit_p50_ms": round(pick(tn, 0.50), 3), "split_vs_unsplit_max_abs_pose_diff": float((pose_e - pose_n).abs().max()),
             "runs": int(len(te)), "objects": len(out_e["objects"]), "frames": 1,
-            "note": "one resident 640x480 frame, one object, batch 1, one stream, eager launches; host wall clock from FramePipeline.run() to the pose "
-                    "on the host (includes the detections' D2H sync in the middle and the pose D2H at the end); pose_graph_*: the same with the pose "
+            "note": "one resident 640x480 frame, one object, batch 1, one stream, eager launches, FramePipeline(low_latency=True) as full_prediction uses it "
+                    "(the crop's small-M layers split K; unsplit_p50_ms: the default batched pipeline's form at batch 1); host wall clock from "
+                    "FramePipeline.run() to the pose on the host (includes the detections' D2H sync in the middle and the pose D2H at the end); pose_graph_*: the same with the pose "
                     "stage as ONE replayed HIP graph (FramePipeline(pose_graphs=True)) -- no faster: the frame is its ~140 dependent small kernels, "
                     "not their host cost; after the timed region, never part of `value`"}
 
