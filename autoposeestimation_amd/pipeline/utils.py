@@ -67,7 +67,8 @@ class FramePipeline:
         # low_latency: the pose networks' small-M layers (ONE crop: 4..16 output tiles per layer on a 256-CU chip) take the split-K form of
         # ape_conv_gemm_bf16_splitk -- the batch-1 live loop (main.py:517-553, full_prediction): 3.9 -> 3.0 ms per frame.  Off by default:
         # the split changes the fp32 summation order (poses move by <= 1e-5, still 10x inside the 1e-4 bar), and a batched run is held to
-        # 1e-6 against its frames run alone (tests/test_gpu_bench_parity.py); a batch that fills the chip never splits anyway
+        # 1e-6 against its frames run alone (tests/test_gpu_bench_parity.py); in a batch that fills the chip only the layers that are small at any
+        # batch size would split (the PSP prior branches, the heads' per-crop bias)
         self.low_latency = bool(low_latency)
         self.host_poses_s = 0.0        # host time spent inside poses() (enqueue only: nothing in there waits for the GPU once the graphs exist)
 

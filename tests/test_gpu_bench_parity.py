@@ -213,8 +213,8 @@ def test_low_latency_pipeline_keeps_masks_and_points_and_moves_poses_by_1e5_at_m
     main.py:517-553), runs: the pose networks' small-M layers take the split-K form (one crop's 20 x 20 maps are 4..16 output tiles per layer
     on a 256-CU chip; 3.9 -> 3.0 ms per frame).  The split changes the fp32 summation order of those layers only: on eight frames of the bench
     batch run alone, objects, object maps and chosen pixels are bit-identical to the default pipeline's, poses move by <= 2e-5 (the 1e-4 bar
-    against the oracle is checked through full_prediction in tests/test_gpu_pipeline.py), and a batch that fills the chip never splits: the
-    64-frame run is bit-identical with and without the switch."""
+    against the oracle is checked through full_prediction in tests/test_gpu_pipeline.py); in the 64-frame batch only the layers that stay small
+    at any batch size split (the PSP prior branches on 1x1 .. 6x6 maps, the per-crop bias of the heads): the same bound holds there."""
     from autoposeestimation_amd.pipeline.utils import FramePipeline
     s = bench_setup
     bench, plain = s["bench"], s["pipe"]
@@ -229,4 +229,5 @@ def test_low_latency_pipeline_keeps_masks_and_points_and_moves_poses_by_1e5_at_m
     print("low_latency vs default at batch 1: max |pose diff| %.3g" % worst)
     assert 0.0 < worst <= 2e-5          # (> 0: the split form really ran)
     full = fast.run(s["rgb"], s["depth"], S.REALSENSE_META, seed=0)
-    assert torch.equal(full["pose"], s["out"]["pose"]) and torch.equal(full["objmap"], s["out"]["objmap"])
+    assert torch.equal(full["objmap"], s["out"]["objmap"]) and torch.equal(full["choose"], s["out"]["choose"])
+    assert float((full["pose"] - s["out"]["pose"]).abs().max()) <= 2e-5
