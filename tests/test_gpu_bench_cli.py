@@ -46,6 +46,8 @@ def test_default_line_has_roofline_cpu_baseline_and_parity():
     assert sw["steps"] == 4 and sw["unit"] == "frames/s" and 0 < sw["value"] < d["value"] * 1.2 and len(sw["crop_buckets_last_step"]) >= 4
     assert "parity" not in sw and sw["pose_graphs"] is True
     assert lat["runs"] == 50 and lat["objects"] == 1 and 0 < lat["min_ms"] <= lat["p50_ms"] <= lat["p99_ms"] < 50
+    # the leg runs the low-latency pipeline (split-K for the crop's small-M layers) and reports the unsplit form and the graph replay beside it
+    assert lat["graph_equals_eager_bitwise"] is True and lat["unsplit_p50_ms"] > 0 and 0 < lat["split_vs_unsplit_max_abs_pose_diff"] <= 2e-5
     ks = d["roofline"]["kernels"]
     assert len(ks) == 5 and d["roofline"]["kernel"] == ks[0]["kernel"]
     for k in ks:
