@@ -28,6 +28,8 @@ constexpr int PTY = 4, PTX = 8;                 // pooled tile
 constexpr int CR = 2 * PTY + 1, CC = 2 * PTX + 1;   // conv outputs under it: 9 x 17
 constexpr int NCV = CR * CC;                    // 153
 constexpr int NRB = (NCV + 15) / 16;            // 10 row blocks
+constexpr int NRW = NRB / 2;                    // row blocks per wave (a wave = a pair of channel blocks x half of the row blocks)
+static_assert(NRB % 2 == 0, "the row blocks are dealt to two waves");
 constexpr int PR = 2 * CR + 5, PC = 2 * CC + 5 + 1; // input patch 23 x 40 (one extra column for the zero-weight kernel column 7)
 constexpr int NPATCH = PR * PC;                 // 920 pixels
 constexpr int ELD = 68;                         // floats per staged conv pixel (64 channels + pad)
@@ -60,33 +62,41 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
 
-    // ---- this wave's weights: 16 output channels x (7 kernel rows x [8 columns x 4 channels]) as MFMA B fragments -----------
-    bf16x8 bh[7], bl[7];
-    {
-        const int co = wave * 16 + r16;
+    // ---- this wave's weights: 2 x 16 output channels x (7 kernel rows x [8 columns x 4 channels]) as MFMA B fragments.  A wave owns the
+    // channel blocks 2 cp, 2 cp + 1 and HALF of the row blocks (mh): every A fragment it reads feeds six matrix instructions instead of
+    // three, the four waves read the patch twice per tile instead of four times (it was 573 KB of ds_read_b128 per tile) ----------------
+    const int cp = wave >> 1, mh = wave & 1;
+    bf16x8 bh[2][7], bl[2][7];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int co = (2 * cp + cb) * 16 + r16;
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int kx = 2 * kq + (j >> 2), ch = j & 3;
                 const float v = kx < 7 ? w[((co * 7 + ky) * 7 + kx) * 4 + ch] : 0.f;
-                bh[ky][j] = (__bf16)v;
-                bl[ky][j] = (__bf16)(v - (float)bh[ky][j]);
+                bh[cb][ky][j] = (__bf16)v;
+                bl[cb][ky][j] = (__bf16)(v - (float)bh[cb][ky][j]);
             }
     }
     // ---- this lane's A fragment origin per row block: element offset of patch pixel (2 cy, 2 cx + 2 kq) ----------------------
-    int abase[NRB];
+    int abase[NRW];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-        int m = rb * 16 + r16;
+    for (int i = 0; i < NRW; ++i) {
+        int m = (mh * NRW + i) * 16 + r16;
         m = m < NCV ? m : NCV - 1;
         const int cy = m / CC, cx = m - cy * CC;
-        abase[rb] = ((2 * cy) * PC + 2 * cx + 2 * kq) * 4;
+        abase[i] = ((2 * cy) * PC + 2 * cx + 2 * kq) * 4;
     }
-    const float cbias = bias ? bias[wave * 16 + r16] : 0.f;
+    const float cbias0 = bias ? bias[(2 * cp) * 16 + r16] : 0.f, cbias1 = bias ? bias[(2 * cp + 1) * 16 + r16] : 0.f;
 
     const int ntiles = B * tiles_y * tiles_x;
-    float4 preg[PITEMS];
+    // U8: the pixel's raw bytes wait in `pu` (+ one validity bit each) and go through the table in store_patch(), i.e. AFTER the matrix
+    // phase and the pooling they were requested under -- a table look-up in load_patch() made the wave wait for the loads right there
+    float4 preg[U8 ? 1 : PITEMS];
+    unsigned int pu[U8 ? PITEMS : 1];
+    unsigned int pok = 0;
     auto load_patch = [&](int tile) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int iy0 = 4 * ty * PTY - 5, ix0 = 4 * tx * PTX - 5;
@@ -97,19 +107,18 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
             const int iy = iy0 + pr, ix = ix0 + pc;
             const bool ok = e < NPATCH && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const int cyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cxc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            float4 v;
             if (U8) {
                 const int fb = rects ? rects[b * 3] : b, fr = (rects ? rects[b * 3 + 1] : 0) + cyc, fc = (rects ? rects[b * 3 + 2] : 0) + cxc;
                 // the pixel's three bytes by ONE (unaligned) 32-bit load; the very last pixel of the buffer is read one byte early and shifted
                 const long pi = ((long)fb * Hf + fr) * Wf + fc;
                 const int last = pi == npix - 1 ? 1 : 0;
                 typedef unsigned int u32_unaligned __attribute__((aligned(1)));
-                const unsigned int u = *reinterpret_cast<const u32_unaligned*>(x8 + pi * 3 - last) >> (8 * last);
-                v = make_float4(lut[u & 255u], lut[256 + ((u >> 8) & 255u)], lut[512 + ((u >> 16) & 255u)], 0.f);
+                pu[i] = *reinterpret_cast<const u32_unaligned*>(x8 + pi * 3 - last) >> (8 * last);
+                pok = (pok & ~(1u << i)) | ((ok ? 1u : 0u) << i);
             } else {
-                v = x[((long)b * H + cyc) * W + cxc];                       // unconditional (clamped), zeroed below: conv zero padding
+                const float4 v = x[((long)b * H + cyc) * W + cxc];          // unconditional (clamped), zeroed below: conv zero padding
+                preg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            preg[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_patch = [&]() {
@@ -117,7 +126,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
         for (int i = 0; i < PITEMS; ++i) {
             const int e = tid + 256 * i;
             if (e >= NPATCH) continue;
-            const float4 v = preg[i];
+            float4 v;
+            if (U8) {
+                const unsigned int u = pu[i];
+                v = (pok >> i) & 1u ? make_float4(lut[u & 255u], lut[256 + ((u >> 8) & 255u)], lut[512 + ((u >> 16) & 255u)], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                v = preg[i];
+            }
             bf16x4 hi, lo;
             hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
             *reinterpret_cast<bf16x4*>(patch + e * 4) = hi;
@@ -137,32 +152,39 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
         const int next = tile + gridDim.x;
         if (next < ntiles) load_patch(next);                 // flies under the MFMAs and the pooling of this tile
 
-        f32x4 acc[NRB];
+        f32x4 acc[NRW][2];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int i = 0; i < NRW; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[rb][e] = cbias;
+            for (int e = 0; e < 4; ++e) { acc[i][0][e] = cbias0; acc[i][1][e] = cbias1; }
+        // (per output element the same chain as ever: ky ascending, lo x hi, hi x lo, hi x hi)
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                const int o = abase[rb] + ky * PC * 4;
+            for (int i = 0; i < NRW; ++i) {
+                const int o = abase[i] + ky * PC * 4;
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(patch + o);
                 if (NPL == 2) {
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(patch + NPATCH * 4 + o);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ky], acc[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ky], acc[rb], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[cb][ky], acc[i][cb], 0, 0, 0);
+                        acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[cb][ky], acc[i][cb], 0, 0, 0);
+                    }
                 }
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ky], acc[rb], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc[i][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[cb][ky], acc[i][cb], 0, 0, 0);
             }
         // ReLU'd conv outputs -> LDS [conv pixel][channel]   (C/D map: row = 4 kq + e is the pixel, column = r16 the channel)
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int i = 0; i < NRW; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = rb * 16 + kq * 4 + e;
-                if (m < NCV) stage[m * ELD + wave * 16 + r16] = fmaxf(acc[rb][e], 0.f);
-            }
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = (mh * NRW + i) * 16 + kq * 4 + e;
+                    if (m < NCV) stage[m * ELD + (2 * cp + cb) * 16 + r16] = fmaxf(acc[i][cb][e], 0.f);
+                }
         __syncthreads();
         // 3x3 / stride 2 / pad 1 max-pool over the staged conv tile; conv pixels outside the conv image do not take part
         {

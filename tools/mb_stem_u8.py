@@ -20,4 +20,5 @@ for name, hc, wc, rects, d in (("64 frames 480x640", 480, 640, torch.tensor([[i,
                                ("64 crops 160x160", 160, 160, torch.tensor([[i, 100 + i, 200 + 2 * i] for i in range(64)], dtype=torch.int32).cuda(), False)):
     a = t(lambda: E.stem_pool(conv, E.preprocess_u8(rgb, rects, hc, wc, d)))
     b = t(lambda: E.stem_pool(conv, E.U8Frames(rgb, rects, hc, wc, d)))
-    print("%-20s preprocess + stem %.3f ms   stem on u8 %.3f ms" % (name, a, b))
+    y = E.stem_pool(conv, E.U8Frames(rgb, rects, hc, wc, d))
+    print("%-20s preprocess + stem %.3f ms   stem on u8 %.3f ms   output checksum %s" % (name, a, b, hex(int(y.view(torch.int32).to(torch.int64).sum().item()) & 0xffffffffffff)))
