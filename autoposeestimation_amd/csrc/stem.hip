@@ -195,16 +195,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const void* __restric
                 const int ly = pp / PTX, lx = pp - ly * PTX;
                 const int py = py0 + ly, px = px0 + lx;
                 if (py >= Hp || px >= Wp) continue;
+                // branch-free: a window position outside the conv image reads the window's CENTRE instead (conv pixel (2 py, 2 px) always
+                // exists and is in the maximum anyway), so the nine reads are issued back to back -- behind a `continue` each one sat in
+                // its own block with its own wait
                 float4 m4 = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    const int oy = 2 * py - 1 + dy;
-                    if ((unsigned)oy >= (unsigned)Ho) continue;
+                    const int sy = (unsigned)(2 * py - 1 + dy) < (unsigned)Ho ? 2 * ly + dy : 2 * ly + 1;
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        const int ox = 2 * px - 1 + dx;
-                        if ((unsigned)ox >= (unsigned)Wo) continue;
-                        const float4 v = *reinterpret_cast<const float4*>(&stage[((2 * ly + dy) * CC + 2 * lx + dx) * ELD + c4 * 4]);
+                        const int sx = (unsigned)(2 * px - 1 + dx) < (unsigned)Wo ? 2 * lx + dx : 2 * lx + 1;
+                        const float4 v = *reinterpret_cast<const float4*>(&stage[(sy * CC + sx) * ELD + c4 * 4]);
                         m4.x = fmaxf(m4.x, v.x); m4.y = fmaxf(m4.y, v.y); m4.z = fmaxf(m4.z, v.z); m4.w = fmaxf(m4.w, v.w);
                     }
                 }
