@@ -225,7 +225,7 @@ class _PSPPlan:
         pools = E.adaptive_avgpool_multi(f, (2, 3, 6))
         # the 1x1 pool is the mean of the four 2x2 bins when they tile the map evenly (one workgroup per frame otherwise)
         pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f, 1)
-        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]
+        zs = E.conv1x1_multi(self.prior, [pools[s] for s in (1, 2, 3, 6)])       # (the four stage convolutions in one launch)
         p = self.bott_feats(f, residual=E.psp_prior_sum(zs, h, w))
         if taps is not None:
             taps["feats"], taps["psp"] = f, p
@@ -267,7 +267,7 @@ class _PSPPlan:
         nf = self.bott_feats.cin
         pools = E.adaptive_avgpool_multi(f, (2, 3, 6), channels=nf)             # (the map's 64 spare channels of the folded form are not pooled)
         pools[1] = E.adaptive_avgpool(pools[2], 1) if h % 2 == 0 and w % 2 == 0 else E.adaptive_avgpool(f.to_f32()[..., :nf].contiguous(), 1)
-        zs = [self.prior[i](pools[s]) for i, s in enumerate((1, 2, 3, 6))]
+        zs = E.conv1x1_multi(self.prior, [pools[s] for s in (1, 2, 3, 6)])       # (the four stage convolutions in one launch)
         if fold:
             p = E.psp_bottleneck_folded(self.bott_feats, f, zs, out_fmt=S)
         else:

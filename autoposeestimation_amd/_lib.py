@@ -35,6 +35,7 @@ SIGNATURES = {
     "ape_conv_gemm_bf16_fmt": [_P, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "ape_conv_gemm_splitk_workspace_bytes": [_P],
     "ape_conv_gemm_bf16_splitk": [_P, _P, _P, _P, _P, _P, _I, _P, _c.c_size_t, _P],
+    "ape_conv_gemm_bf16_multi": [_I, _P, _P, _P, _P, _P, _I, _P],
     "ape_adaptive_avgpool_multi_nhwc_fmt": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_adaptive_avgpool_multi_nhwc_ld": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _c.c_size_t, _P],
     "ape_upconv3x3_gather_fmt": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],

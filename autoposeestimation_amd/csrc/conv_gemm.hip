@@ -77,7 +77,7 @@ __device__ __forceinline__ int lds_off(int row, int c) { return row * BK + ((c ^
 // read of tile t-1 and >= 2 barriers before the first read of tile t+1 by either group).
 // SK: the split-K build (training tape only; the inference instantiations do not carry its code or registers)
 template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP, bool SK>
-__device__ __forceinline__ void conv_gemm_body(const GemmArgs& a)
+__device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int orig)
 {
     static_assert(!PP || WM == 2, "the ping-pong schedule pairs the two row halves of an 8-wave block");
     constexpr int NT = WM * WN * 64;
@@ -98,7 +98,6 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a)
 
     const ape_conv_params& p = a.p;
     const int nwg = a.m_tiles * a.n_tiles;
-    const int orig = blockIdx.x;
     const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
     const int n_tile = logical % a.n_tiles;
@@ -347,13 +346,31 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a)
 template <int NSPLIT, int BM, int BN, int WM, int WN, bool PURE, bool PP>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm_kernel(const GemmArgs a)
 {
-    conv_gemm_body<NSPLIT, BM, BN, WM, WN, PURE, PP, false>(a);
+    conv_gemm_body<NSPLIT, BM, BN, WM, WN, PURE, PP, false>(a, (int)blockIdx.x);
 }
 
 template <int NSPLIT, bool PURE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_splitk_kernel(const GemmArgs a)
 {
-    conv_gemm_body<NSPLIT, 128, 128, 2, 2, PURE, false, true>(a);
+    conv_gemm_body<NSPLIT, 128, 128, 2, 2, PURE, false, true>(a, (int)blockIdx.x);
+}
+
+// Up to four independent 1x1 problems in ONE launch (ape_conv_gemm_bf16_multi): workgroups first[i] .. first[i + 1] - 1 are problem i's tiles.
+// For problems of a few tiles each, whose launches would run one after the other with most of the chip idle (the four PSP stage
+// convolutions: 1, 2, 5 and 18 tiles at 64 frames, ~25 us each -- a k-loop's latency chain, not work).
+constexpr int kMultiMax = 4;
+struct GemmMultiArgs {
+    GemmArgs a[kMultiMax];
+    int first[kMultiMax + 1];       // (entries past the last problem hold the total)
+};
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_gemm_multi_kernel(const GemmMultiArgs m)
+{
+    const int blk = (int)blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMultiMax; ++i) pi = blk >= m.first[i] ? i : pi;
+    conv_gemm_body<NSPLIT, 128, 128, 2, 2, true, false, false>(m.a[pi], blk - m.first[pi]);
 }
 
 template <int NSPLIT, int BM, int BN, int WM, int WN, bool PP = false>
@@ -488,6 +505,42 @@ extern "C" int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, cons
         if (nsplit == 3) launch<3, 128, 192, 2, 2>(a, pure, st); else launch<1, 128, 192, 2, 2>(a, pure, st);
     }
     return ape::check_launch("ape_conv_gemm_bf16");
+}
+
+/* n <= 4 independent 1x1 / stride-1 convolutions (fp32 in, fp32 out, no residual) in ONE launch of the 128 x 128 block: problem i multiplies
+ * x[i] by w_packed[i] under params[i].  Every output element is the very sum ape_conv_gemm_bf16 forms (same k order in every block shape). */
+extern "C" int ape_conv_gemm_bf16_multi(int n, const float* const* x, const void* const* w_packed, const float* const* bias, float* const* y,
+                                        const ape_conv_params* params, int nsplit, void* stream)
+{
+    if (n < 1 || n > kMultiMax || !x || !w_packed || !y || !params || (nsplit != 1 && nsplit != 3)) return APE_EINVAL;
+    GemmMultiArgs m;
+    int total = 0;
+    for (int i = 0; i < kMultiMax; ++i) {
+        m.first[i] = total;
+        if (i >= n) { m.a[i] = m.a[0]; continue; }
+        const ape_conv_params& p = params[i];
+        if (!x[i] || !w_packed[i] || !y[i] || !supported(p) || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0) return APE_EINVAL;
+        const long M = (long)p.B * p.Ho * p.Wo;
+        GemmArgs& a = m.a[i];
+        a.x = x[i]; a.w = (const __bf16*)w_packed[i]; a.bias = bias ? bias[i] : nullptr; a.res = nullptr; a.y = y[i]; a.p = p;
+        a.M = (int)M;
+        a.Kp = (p.Cin + 7) / 8 * 8;
+        a.nk = p.Cin / BK;
+        a.plane_stride = (long)p.Cout * a.Kp;
+        a.dbg = 0;
+        a.out_fmt = APE_FMT_F32;
+        a.nk_per = 0;
+        a.split_stride = 0;
+        a.m_tiles = ape::ceil_div(a.M, 128);
+        a.n_tiles = ape::ceil_div(p.Cout, 128);
+        total += a.m_tiles * a.n_tiles;       // (an empty problem, M = 0, has no tiles)
+    }
+    m.first[kMultiMax] = total;
+    if (total == 0) return APE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (nsplit == 3) hipLaunchKernelGGL((conv_gemm_multi_kernel<3>), dim3(total), dim3(256), 0, st, m);
+    else hipLaunchKernelGGL((conv_gemm_multi_kernel<1>), dim3(total), dim3(256), 0, st, m);
+    return ape::check_launch("ape_conv_gemm_bf16_multi");
 }
 
 /* Split-K form for the training tape's batch-1 layers (a 20 x 20 map is 4 row tiles: 4..16 workgroups walking K = 4608 alone took 89 us):

@@ -85,6 +85,7 @@ PRECISIONS = ("f32", "bf16x3", "bf16")
 SPLITK_SMALL_M = False     # split-K for the pose networks' layers whose grid would not fill the chip: FramePipeline(low_latency=True) sets it around its pose stage (round 6)
 USE_HALO_KERNEL = True    # route eligible 3x3 convs of the bf16 paths to the LDS-halo kernel (conv3x3_halo.hip)
 USE_GEMM_KERNEL = os.environ.get("APE_USE_GEMM_KERNEL", "1") != "0"    # route Cin % 32 == 0 layers the halo kernel does not take to conv_gemm.hip (else conv_bf16.hip)
+USE_CONV_MULTI = os.environ.get("APE_USE_CONV_MULTI", "1") != "0"     # the PSP stage convolutions in one launch (conv1x1_multi); 0: one launch each (A/B)
 GEMM_VARIANT = int(os.environ.get("APE_GEMM_VARIANT", "0"))          # 0 = chosen from the shape; 1..4 force a block shape (tools/microbench_generic.py)
 
 
@@ -553,6 +554,30 @@ def adaptive_avgpool_multi(x, sizes, channels=None):
         return {s: adaptive_avgpool(xf, s) for s in sizes}
     _lib.check(rc, "ape_adaptive_avgpool_multi_nhwc_ld")
     return dict(zip(sizes, ys))
+
+
+def conv1x1_multi(convs, xs):
+    """[conv(x) for conv, x in zip(convs, xs)] for up to four independent 1x1 / stride-1 convolutions of fp32 maps in ONE launch
+    (ape_conv_gemm_bf16_multi): the PSP module's stage convolutions (pspnet.py:15-18, 22), problems of 1 .. 18 tiles each whose separate
+    launches ran one after the other with the chip idle.  Bit for bit what the separate calls give; they are what runs where the
+    launch does not apply (more than four problems, other precisions, geometries the GEMM kernel does not take)."""
+    convs, xs = list(convs), list(xs)
+    n = len(convs)
+    ok = (1 <= n <= 4 and USE_CONV_MULTI and USE_GEMM_KERNEL and not (GEMM_VARIANT & 15) and
+          all(c.nsplit and c.nsplit == convs[0].nsplit and c.kh == 1 and c.kw == 1 and c.stride == 1 and c.pad == 0 and not isinstance(x, S32)
+              and x.shape[3] == c.cin and x.is_contiguous() for c, x in zip(convs, xs)))
+    if ok:
+        outs = [torch.empty(x.shape[0], x.shape[1], x.shape[2], c.cout, dtype=torch.float32, device=x.device) for c, x in zip(convs, xs)]
+        ps = (ConvParams * n)(*[ConvParams(B=x.shape[0], H=x.shape[1], W=x.shape[2], Cin=c.cin, ldx=x.shape[3], xoff=0, Ho=x.shape[1], Wo=x.shape[2],
+                                           Cout=c.cout, ldy=c.cout, yoff=0, KH=1, KW=1, stride=1, pad=0, dil=1, act=c.act, alpha=c.alpha, bias_bstride=0,
+                                           ldr=0, roff=0, ups=0) for c, x in zip(convs, xs)])
+        ok = all(_lib.lib().ape_conv_gemm_supported(ctypes.byref(ps[i])) for i in range(n))
+    if not ok:
+        return [c(x) for c, x in zip(convs, xs)]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])  # noqa: E731
+    rc = _lib.lib().ape_conv_gemm_bf16_multi(n, arr(xs), arr([c.wp for c in convs]), arr([c.bias for c in convs]), arr(outs), ps, convs[0].nsplit, _st())
+    _lib.check(rc, "ape_conv_gemm_bf16_multi")
+    return outs
 
 
 def bilinear(x, ho, wo, align_corners, out=None, yoff=0, accumulate=False):

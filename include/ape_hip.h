@@ -124,6 +124,12 @@ int ape_psp_fold_operands(const void* wf_s32k, const float* z1, const float* z2,
  * feeds up_2's S32 channel mixing).  Declared further down next to their fp32 forms' documentation. */
 int ape_conv_gemm_bf16_fmt(const float* x, const void* w_packed, const float* bias, const float* residual, void* y, int out_fmt,
                            const ape_conv_params* params_host, int nsplit, int variant, void* stream);
+/* The PSP module's stage convolutions (pspnet.py:15-18, 22: `stage(feats) for stage in self.stages` -- four bias-free 1x1 convolutions of the
+ * 1x1 / 2x2 / 3x3 / 6x6 pooled maps) are independent problems of 1 .. 18 tiles each: n <= 4 such 1x1 / stride-1 convolutions (fp32 in, fp32 out,
+ * no residual) in ONE launch.  Problem i multiplies x[i] by w_packed[i] (ape_pack_weights_bf16 layout) under params_host[i]; bias may be NULL
+ * or hold NULL entries.  Every output element is bit for bit what ape_conv_gemm_bf16 gives for that problem alone. */
+int ape_conv_gemm_bf16_multi(int n, const float* const* x, const void* const* w_packed, const float* const* bias, float* const* y,
+                             const ape_conv_params* params_host, int nsplit, void* stream);
 /* Split-K form for the training tape's batch-1 layers (train.py:205-238 runs ONE 160x160 crop per step: its 20 x 20 feature maps are 4
  * row tiles of the 128 x 128 block, K up to 4608): the k-tiles are dealt to several workgroups per output tile, raw sums go to the
  * workspace, a second pass adds them in a fixed order with bias / residual / activation.  Same products, another summation order than

@@ -179,3 +179,39 @@ def test_halo_conv_with_fused_seg_head_is_bit_identical_to_the_unfused_pair(prec
     assert len(torch.unique(label)) > 1
 
 
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("batch,sizes,cin,cout", [(64, (1, 2, 3, 6), 512, 512), (3, (1, 2, 3, 6), 512, 512), (1, (6,), 64, 200), (5, (2, 7, 1), 96, 33)])
+def test_multi_problem_1x1_launch_is_bit_identical_to_the_separate_launches(batch, sizes, cin, cout, precision):
+    """ape_conv_gemm_bf16_multi (the PSP module's stage convolutions, pspnet.py:15-18, 22, in one launch) against one ape_conv_gemm_bf16 call per
+    problem: different weights, maps and tile counts per problem, ragged M and Cout; bitwise."""
+    from autoposeestimation_amd import engine as E
+    g = torch.Generator().manual_seed(5)
+    convs = [E.Conv(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, torch.randn(cout, generator=g) if i % 2 else None, act=E.ACT_RELU if i == 1 else E.ACT_NONE,
+                    device="cuda", precision=precision) for i in range(len(sizes))]
+    xs = [torch.randn(batch, s, s, cin, generator=g).cuda() for s in sizes]
+    want = [c(x) for c, x in zip(convs, xs)]
+    got = E.conv1x1_multi(convs, xs)
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # it is the one-launch path that ran, not the fall-back: the library takes these problems
+    assert all(c.nsplit for c in convs)
+
+
+def test_multi_problem_launch_rejects_what_it_does_not_take():
+    import ctypes
+    from autoposeestimation_amd import _lib, engine as E
+    conv3 = E.Conv(torch.randn(64, 64, 3, 3) / 24, None, 1, 1, 1, device="cuda", precision="bf16x3")
+    x = torch.randn(1, 8, 8, 64).cuda()
+    y = torch.empty(1, 8, 8, 64).cuda()
+    p = (E.ConvParams * 1)(E.ConvParams(B=1, H=8, W=8, Cin=64, ldx=64, xoff=0, Ho=8, Wo=8, Cout=64, ldy=64, yoff=0, KH=3, KW=3, stride=1, pad=1, dil=1, act=0, alpha=0.0,
+                                        bias_bstride=0, ldr=0, roff=0, ups=0))
+    arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())  # noqa: E731
+    assert _lib.lib().ape_conv_gemm_bf16_multi(1, arr(x), arr(conv3.wp), None, arr(y), p, 3, None) == -1      # a 3x3 problem
+    assert _lib.lib().ape_conv_gemm_bf16_multi(5, arr(x), arr(conv3.wp), None, arr(y), p, 3, None) == -1      # more than four
+    assert _lib.lib().ape_conv_gemm_bf16_multi(0, arr(x), arr(conv3.wp), None, arr(y), p, 3, None) == -1
+    # and the engine helper falls back to the separate launches for them
+    assert torch.equal(E.conv1x1_multi([conv3], [x])[0], conv3(x))

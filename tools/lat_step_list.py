@@ -15,7 +15,7 @@ fit = [S.synthetic_frame(900 + 7 * c + k, cls=c, box=(30 + 45 * c + 20 * k, 20 +
 seg, est, ref, *_ = bench.build_models(dev, fit)
 for m in (seg, est, ref):
     m.set_precision("bf16x3")
-pipe = FramePipeline(seg, est, ref, bench.CLASSES, num_points=1000, refine_mode="live_compat", pose_stream=False)
+pipe = FramePipeline(seg, est, ref, bench.CLASSES, num_points=1000, refine_mode="live_compat", pose_stream=False, low_latency=os.environ.get("APE_LOW_LATENCY", "1") != "0")
 rgb = torch.from_numpy(frames[0][0][None]).to(dev)
 depth = torch.from_numpy(frames[0][1][None]).to(dev)
 for i in range(12):
