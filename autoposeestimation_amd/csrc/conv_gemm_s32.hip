@@ -999,11 +999,12 @@ __device__ __forceinline__ float psp_axis_weight(int o, int n, int S, int i)
 // (pixel, 4 cells)
 __global__ void psp_fill_coeffs_kernel(char* __restrict__ x, int B, int h, int w, int ld, int coff)
 {
-    const long total = (long)B * h * w * (PSP_KPAD / 4);
+    // the coefficients depend on the pixel's position alone: formed once per (oy, ox, channel quad) and written to every frame
+    const long total = (long)h * w * (PSP_KPAD / 4);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = (int)(i % (PSP_KPAD / 4));
-        const long pix = i / (PSP_KPAD / 4);
-        const int ox = (int)(pix % w), oy = (int)((pix / w) % h);
+        const long pix0 = i / (PSP_KPAD / 4);
+        const int ox = (int)(pix0 % w), oy = (int)(pix0 / w);
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1019,9 +1020,12 @@ __global__ void psp_fill_coeffs_kernel(char* __restrict__ x, int B, int h, int w
 #pragma unroll
         for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
         const int c = coff + q * 4;
-        char* p = x + pix * ld * 4 + (c >> 5) * 128 + (c & 31) * 2;
-        *reinterpret_cast<bf16x4*>(p) = hi;
-        *reinterpret_cast<bf16x4*>(p + 64) = lo;
+        char* p = x + pix0 * ld * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        const long frame = (long)h * w * ld * 4;
+        for (int b = 0; b < B; ++b, p += frame) {
+            *reinterpret_cast<bf16x4*>(p) = hi;
+            *reinterpret_cast<bf16x4*>(p + 64) = lo;
+        }
     }
 }
 // out[b][co][g] (128-B groups, G = K/32 + 2 per row): g < K/32: the shared weights' group; the last two: frame b's Z values of row co
@@ -1069,7 +1073,7 @@ extern "C" int ape_psp_fold_operands(const void* wf_s32k, const float* z1, const
     if (B == 0) return APE_OK;
     hipStream_t st = (hipStream_t)stream;
     {
-        const long total = (long)B * h * w * (PSP_KPAD / 4);
+        const long total = (long)h * w * (PSP_KPAD / 4);
         long g = (total + 255) / 256;
         g = g > 65536 ? 65536 : g;
         hipLaunchKernelGGL(psp_fill_coeffs_kernel, dim3((int)g), dim3(256), 0, st, (char*)x_s32, B, h, w, ld, Cin);
