@@ -144,7 +144,9 @@ __global__ void ccl_merge_kernel(const uint8_t* __restrict__ label, int* __restr
         }
     }
 }
-__global__ void ccl_compress_kernel(int* __restrict__ L, long npix)
+// sum / cnt (may be null): the per-component score accumulators live at the ROOT pixel's index; a root zeroes its own pair here instead of a
+// pass that zeroed all npix pairs (236 MB per 64 frames) before the labelling
+__global__ void ccl_compress_kernel(int* __restrict__ L, long npix, unsigned long long* __restrict__ sum, unsigned int* __restrict__ cnt)
 {
     for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
         int a = L[p];
@@ -155,6 +157,7 @@ __global__ void ccl_compress_kernel(int* __restrict__ L, long npix)
             a = q;
         }
         L[p] = a;   // benign race: other lanes may read either the old parent or the root, both lead to the root
+        if (sum && a == (int)p) { sum[p] = 0ull; cnt[p] = 0u; }
     }
 }
 
@@ -211,11 +214,6 @@ __global__ void seg_stats_kernel(const uint8_t* __restrict__ label, const float*
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += blockDim.x)
         if (lh[i]) atomicAdd(&hist[(long)b * C + i], lh[i]);
-}
-
-__global__ void seg_zero_stats_kernel(unsigned long long* __restrict__ sum, unsigned int* __restrict__ cnt, long n)
-{
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { sum[i] = 0ull; cnt[i] = 0u; }
 }
 
 __global__ void seg_small_init_kernel(unsigned int* hist, unsigned long long* best_key, int* best_root, int* tight, int n)
@@ -590,13 +588,13 @@ extern "C" int ape_seg_components_scored(const uint8_t* label, const float* scor
     int* best_root = (int*)ws;                                    ws += (size_t)B * C * 4;
     int* tight = (int*)ws;
     const int g = grid_for(npix);
-    // (a kernel, not hipMemsetAsync: memset nodes of a captured HIP graph did not re-zero these on replay -- tools/probes/graph_probe.py)
-    hipLaunchKernelGGL(seg_zero_stats_kernel, dim3(g), dim3(kT), 0, st, sum, cnt, npix);
+    // (sum / cnt are zeroed where they are used, at the component roots, by ccl_compress_kernel.  Kernels, not hipMemsetAsync: memset nodes of a
+    // captured HIP graph did not re-zero on replay -- tools/probes/graph_probe.py)
     const int BC = B * C;
     hipLaunchKernelGGL(seg_small_init_kernel, dim3(ape::ceil_div(BC, kT)), dim3(kT), 0, st, hist, best_key, best_root, tight, BC);
     hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(kT), 0, st, label, L, W, npix);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(kT), 0, st, label, L, H, W, npix);
-    hipLaunchKernelGGL(ccl_compress_kernel, dim3(g), dim3(kT), 0, st, L, npix);
+    hipLaunchKernelGGL(ccl_compress_kernel, dim3(g), dim3(kT), 0, st, L, npix, sum, cnt);
     int gx = ape::ceil_div((long)H * W, kT);
     gx = gx > 64 ? 64 : gx;
     hipLaunchKernelGGL(seg_stats_kernel, dim3(gx, B), dim3(kT), 0, st, label, score, L, sum, cnt, hist, H * W, C);
