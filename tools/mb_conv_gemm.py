@@ -8,7 +8,10 @@ from autoposeestimation_amd import engine as E
 # (name, B, H, W, Cin, Cout, k, dil)
 shapes = [("crop layer4 256->512 3x3", 64, 20, 20, 256, 512, 3, 1), ("crop layer4 512->512 3x3 d1", 64, 20, 20, 512, 512, 3, 1), ("crop layer4 512->512 3x3 d4", 64, 20, 20, 512, 512, 3, 4),
           ("crop psp 512->1024 1x1", 64, 20, 20, 512, 1024, 1, 1), ("crop up_1 mix 1024->2304 1x1", 64, 20, 20, 1024, 2304, 1, 1), ("crop up_2 mix 256->576", 64, 40, 40, 256, 576, 1, 1),
-          ("crop layer3 256->256 3x3 d2", 64, 20, 20, 256, 256, 3, 2), ("crop layer2 128->128 3x3", 64, 20, 20, 128, 128, 3, 1)]
+          ("crop layer3 256->256 3x3 d2", 64, 20, 20, 256, 256, 3, 2), ("crop layer2 128->128 3x3", 64, 20, 20, 128, 128, 3, 1),
+          # the 4-wave blocks (128 x 128, 256 x 64): the crop's layers 1-2, the PointNet layers, the segmentor's 1/4-resolution stride-2 entry
+          ("crop layer1 64->64 3x3", 64, 40, 40, 64, 64, 3, 1), ("crop layer2 64->128 3x3 (s1 here)", 64, 40, 40, 64, 128, 3, 1), ("pose e_conv2 64->128", 64, 1000, 1, 64, 128, 1, 1),
+          ("pose conv2 64->128 / e_conv1 32->64", 64, 1000, 1, 32, 64, 1, 1), ("psp stage 512->512 6x6", 64, 6, 6, 512, 512, 1, 1), ("seg layer2 entry 64->128 3x3", 64, 60, 80, 64, 128, 3, 1)]
 torch.manual_seed(0)
 tot = 0.0
 for name, b, h, w, cin, cout, k, dil in shapes:
