@@ -226,13 +226,28 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int orig
     };
     constexpr int TMH = TM / 2;
     bf16x8 ah[TMH], al[TMH];
-    auto read_a = [&](int stage, int i0) {
+    // fragment rows [i0, i0 + n) of the tile -> registers ah / al [r0, r0 + n)
+    auto read_a_rows = [&](int stage, int i0, int r0, int n) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TMH; ++i) {
+        for (int i = 0; i < n; ++i) {
             const int o = lds_off(a_row0 + (i0 + i) * 16, fc);
-            ah[i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, 0) + o);
-            if (NPL == 2) al[i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, NPL - 1) + o);
+            ah[r0 + i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, 0) + o);
+            if (NPL == 2) al[r0 + i] = *reinterpret_cast<const bf16x8*>(a_tile(stage, NPL - 1) + o);
         }
+    };
+    auto read_a = [&](int stage, int i0) { read_a_rows(stage, i0, 0, TMH); };
+    // the matrix instructions of accumulator rows [i0 + r0, i0 + r0 + n) from registers ah / al [r0, r0 + n)
+    auto mfma_rows = [&](int i0, int r0, int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = r0; i < r0 + n; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (NPL == 2) {
+                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i0 + i][j], 0, 0, 0);
+                    acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i0 + i][j], 0, 0, 0);
+                }
+                acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i0 + i][j], 0, 0, 0);
+            }
     };
     auto mfma_half = [&](int i0) {
 #pragma unroll
@@ -275,12 +290,28 @@ __device__ __forceinline__ void conv_gemm_body(const GemmArgs& a, const int orig
         // iterations restage and load a clamped, never-read tile
         store_tiles(cur ^ 1);      // tile kt+1: registers -> the stage last read in iteration kt-1
         load_tiles();              // tile kt+2: lands during this iteration's MFMAs
-        seg();
-        mfma_half(0);
-        seg();
-        read_a(cur, TMH);
-        seg();
-        mfma_half(TMH);
+        if constexpr (!PP && TMH % 2 == 0) {
+            // the second half's fragment reads in two pieces, each issued BEHIND a quarter's matrix instructions into the registers that quarter has
+            // just read: left as "all MFMAs of the first half, then all reads of the second" every k-tile stood still for one LDS round trip
+            constexpr int Q = TMH / 2;
+            mfma_rows(0, 0, Q);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a_rows(cur, TMH, 0, Q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_rows(0, Q, Q);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a_rows(cur, TMH + Q, Q, Q);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_rows(TMH, 0, Q);
+            mfma_rows(TMH, Q, Q);
+        } else {
+            seg();
+            mfma_half(0);
+            seg();
+            read_a(cur, TMH);
+            seg();
+            mfma_half(TMH);
+        }
         __syncthreads();
     }
     if (PP && !behind) __syncthreads();
