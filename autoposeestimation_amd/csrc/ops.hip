@@ -534,11 +534,25 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
     const int ni = ix_hi - ix_lo + 1;                   // <= kUpCols (host checks)
     const int c4 = threadIdx.x & 15, hi4 = threadIdx.x >> 4;
     const int c = slab * 16 + c4;
-    // phase 1 role: low-resolution column ix_lo + hi4 (idle beyond ni), all 9 taps
-    const bool p1 = hi4 < ni;
+    // phase 1 role: the 3 * ni (<= 33) pairs (low-resolution column, kx) are dealt to the 16 column slots of the workgroup, slot hi4 takes
+    // items hi4, hi4 + 16 (and hi4 + 32: slot 0 of an 11-column tile only), item = 3 * column + kx.  (One column with its three kx per
+    // slot left 6 of the 16 slots idle -- and loading: a third of the tap loads and of the y interpolation were thrown away.)
+    constexpr int NIT = 3;
+    bool p1[NIT];
+    int it_s[NIT];                                      // the item's S slot: (kx * kUpCols + column) * 16 + c4
     const long rs = (long)w * 9 * C4;                   // float4 per low-resolution row of z
-    const float4* zc = z + (long)b * h * rs + (long)(ix_lo + (p1 ? hi4 : 0)) * 9 * C4 + c;
-    float4 v0[3][3], v1[3][3];                          // [ky][kx]: the held row pair of every tap
+    const float4* zi[NIT];                              // tap row ky of the item's (column, kx) at zi + iy * rs + ky * 3 * C4
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+        const int item = hi4 + 16 * r;
+        p1[r] = item < 3 * ni;
+        const int col = p1[r] ? item / 3 : 0, kx = p1[r] ? item - 3 * col : 0;
+        it_s[r] = (kx * kUpCols + col) * 16 + c4;
+        zi[r] = z + (long)b * h * rs + (long)(ix_lo + col) * 9 * C4 + kx * C4 + c;
+    }
+    // (wave-uniform: does any lane of this wave hold a third item?  lanes of a wave: hi4 = 4 wave .. 4 wave + 3)
+    const bool third = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4 + 32 < 3 * ni;
+    float4 v0[3][NIT], v1[3][NIT];                      // [ky][item]: the held row pair of every tap
     int hy0[3];
     // phase 2 role: output column X0 + hi4
     const int X = X0 + hi4;
@@ -574,20 +588,20 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
     {                                                                                                                                      \
         APE_UPS_ROWS(YY, ky, iy0, iy1)                                                                                                     \
         const bool keep = iy0 == hy0[ky];                                                                                                  \
-        const float4* zr1 = zc + (long)iy1 * rs + (ky) * 3 * C4;                                                                           \
-        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                                                 \
-            v0[ky][kx].x = keep ? v0[ky][kx].x : v1[ky][kx].x; v0[ky][kx].y = keep ? v0[ky][kx].y : v1[ky][kx].y;                          \
-            v0[ky][kx].z = keep ? v0[ky][kx].z : v1[ky][kx].z; v0[ky][kx].w = keep ? v0[ky][kx].w : v1[ky][kx].w;                          \
-            v1[ky][kx] = zr1[kx * C4];                                                                                                     \
+        const long o1 = (long)iy1 * rs + (ky) * 3 * C4;                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < NIT; ++r) {                                                                                  \
+            if (r == 2 && !third) break;                                                                                                   \
+            v0[ky][r].x = keep ? v0[ky][r].x : v1[ky][r].x; v0[ky][r].y = keep ? v0[ky][r].y : v1[ky][r].y;                                \
+            v0[ky][r].z = keep ? v0[ky][r].z : v1[ky][r].z; v0[ky][r].w = keep ? v0[ky][r].w : v1[ky][r].w;                                \
+            v1[ky][r] = zi[r][o1];                                                                                                         \
         }                                                                                                                                  \
         hy0[ky] = iy0;                                                                                                                     \
     }
 #define APE_UPS_INIT(YY, ky)                                                                                                               \
     {                                                                                                                                      \
         APE_UPS_ROWS(YY, ky, iy0, iy1)                                                                                                     \
-        const float4* zr0 = zc + (long)iy0 * rs + (ky) * 3 * C4;                                                                           \
-        const float4* zr1 = zc + (long)iy1 * rs + (ky) * 3 * C4;                                                                           \
-        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) { v0[ky][kx] = zr0[kx * C4]; v1[ky][kx] = zr1[kx * C4]; }                         \
+        const long o0 = (long)iy0 * rs + (ky) * 3 * C4, o1 = (long)iy1 * rs + (ky) * 3 * C4;                                               \
+        _Pragma("unroll") for (int r = 0; r < NIT; ++r) { v0[ky][r] = zi[r][o0]; v1[ky][r] = zi[r][o1]; }                                  \
         hy0[ky] = iy0;                                                                                                                     \
     }
     // S_kx of output row YY from the window -> LDS buffer Sb
@@ -602,7 +616,8 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
             ly1[ky] = fy - (float)(int)fy;                                                                                                 \
             ly0[ky] = 1.f - ly1[ky];                                                                                                       \
         }                                                                                                                                  \
-        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                                                 \
+        _Pragma("unroll") for (int kx = 0; kx < NIT; ++kx) {             /* (kx: the thread's item index here) */                        \
+            if (kx == 2 && !third) break;                                                                                                  \
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                                                                  \
             _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                                                             \
                 if (!yok[ky]) continue;                                                                                                    \
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
                 acc.z += ly0[ky] * a0.z + ly1[ky] * a1.z;                                                                                  \
                 acc.w += ly0[ky] * a0.w + ly1[ky] * a1.w;                                                                                  \
             }                                                                                                                              \
-            if (p1) (Sb)[(kx * kUpCols + hi4) * 16 + c4] = acc;                                                                            \
+            if (p1[kx]) (Sb)[it_s[kx]] = acc;                                                                                              \
         }                                                                                                                                  \
     }
     // the x interpolation, epilogue and store of output row YY from LDS buffer Sb
