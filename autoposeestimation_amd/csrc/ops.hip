@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
             acc.x = acc.x > 0.f ? acc.x : alpha * acc.x; acc.y = acc.y > 0.f ? acc.y : alpha * acc.y;                                      \
             acc.z = acc.z > 0.f ? acc.z : alpha * acc.z; acc.w = acc.w > 0.f ? acc.w : alpha * acc.w;                                      \
         }                                                                                                                                  \
-        if (S32OUT) ape::s32_store4(out, (long)(b * Ho + (YY)) * Wo + X, C4, c, acc);                                                      \
+        if (S32OUT) ape::s32_store4_pair(out, (long)(b * Ho + (YY)) * Wo + X, C4, c, acc);    /* (p2 is the same for both lanes of a pair) */ \
         else out[((long)(b * Ho + (YY)) * Wo + X) * C4 + c] = acc;                                                                         \
     }
 
