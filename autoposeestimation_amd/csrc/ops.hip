@@ -509,6 +509,7 @@ __global__ __launch_bounds__(256) void upconv_gather_kernel(const float4* __rest
 // -- one new row load, on average 1.5 per output row instead of 6 -- and the loads for row Y + 1 are issued before row Y's x interpolation,
 // so they fly during it.  The arithmetic per output is the row kernel's, operation for operation (same S_kx, same x interpolation, same
 // epilogue): bit-identical outputs.
+typedef float ups_f32x2 __attribute__((ext_vector_type(2)));
 template <bool S32OUT, bool FMA>
 __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* __restrict__ z, const float* __restrict__ bias,
                                                                   float4* __restrict__ out, int B, int h, int w, int C4, float sh, float sw,
@@ -629,10 +630,12 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
                     acc.w = fmaf(ly1[ky], a1.w, fmaf(ly0[ky], a0.w, acc.w));                                                               \
                     continue;                                                                                                              \
                 }                                                                                                                          \
-                acc.x += ly0[ky] * a0.x + ly1[ky] * a1.x;                                                                                  \
-                acc.y += ly0[ky] * a0.y + ly1[ky] * a1.y;                                                                                  \
-                acc.z += ly0[ky] * a0.z + ly1[ky] * a1.z;                                                                                  \
-                acc.w += ly0[ky] * a0.w + ly1[ky] * a1.w;                                                                                  \
+                /* two channels per instruction (v_pk_mul_f32 / v_pk_add_f32): the same separately rounded products and sums */          \
+                const ups_f32x2 w0 = {ly0[ky], ly0[ky]}, w1 = {ly1[ky], ly1[ky]};                                                          \
+                const ups_f32x2 tl = w0 * ups_f32x2{a0.x, a0.y} + w1 * ups_f32x2{a1.x, a1.y};                                              \
+                const ups_f32x2 th = w0 * ups_f32x2{a0.z, a0.w} + w1 * ups_f32x2{a1.z, a1.w};                                              \
+                const ups_f32x2 sl = ups_f32x2{acc.x, acc.y} + tl, sh2 = ups_f32x2{acc.z, acc.w} + th;                                     \
+                acc = make_float4(sl.x, sl.y, sh2.x, sh2.y);                                                                               \
             }                                                                                                                              \
             if (p1[kx]) (Sb)[it_s[kx]] = acc;                                                                                              \
         }                                                                                                                                  \
@@ -651,10 +654,13 @@ __global__ __launch_bounds__(256) void upconv_gather_strip_kernel(const float4* 
                 acc.w = fmaf(lx1[kx], s1.w, fmaf(lx0[kx], s0.w, acc.w));                                                                   \
                 continue;                                                                                                                  \
             }                                                                                                                              \
-            acc.x += lx0[kx] * s0.x + lx1[kx] * s1.x;                                                                                      \
-            acc.y += lx0[kx] * s0.y + lx1[kx] * s1.y;                                                                                      \
-            acc.z += lx0[kx] * s0.z + lx1[kx] * s1.z;                                                                                      \
-            acc.w += lx0[kx] * s0.w + lx1[kx] * s1.w;                                                                                      \
+            {                                                                                                                              \
+                const ups_f32x2 w0 = {lx0[kx], lx0[kx]}, w1 = {lx1[kx], lx1[kx]};                                                          \
+                const ups_f32x2 tl = w0 * ups_f32x2{s0.x, s0.y} + w1 * ups_f32x2{s1.x, s1.y};                                              \
+                const ups_f32x2 th = w0 * ups_f32x2{s0.z, s0.w} + w1 * ups_f32x2{s1.z, s1.w};                                              \
+                const ups_f32x2 sl = ups_f32x2{acc.x, acc.y} + tl, sh2 = ups_f32x2{acc.z, acc.w} + th;                                     \
+                acc = make_float4(sl.x, sl.y, sh2.x, sh2.y);                                                                               \
+            }                                                                                                                              \
         }                                                                                                                                  \
         if (bias) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }                                                          \
         if (act == APE_ACT_RELU) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); } \
